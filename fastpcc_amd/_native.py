@@ -1,0 +1,83 @@
+"""ctypes loaders for the in-tree native libraries.  Fail loudly: there is no fallback implementation."""
+import ctypes as C
+import os
+
+from . import _build
+
+_host = None
+_hip = None
+
+i64 = C.c_int64
+i32 = C.c_int
+f32 = C.c_float
+vp = C.c_void_p
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def _load(path, what):
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            f'{what} not built ({path}); run `python -c "import __graft_entry__ as g; g.build()"` at the repo root')
+    return C.CDLL(path)
+
+
+def host():
+    """libfpcc_host.so with argtypes set."""
+    global _host
+    if _host is None:
+        L = _load(_build.HOST_LIB, 'libfpcc_host.so')
+        L.fpcc_host_strerror.restype = C.c_char_p
+        L.fpcc_host_strerror.argtypes = [i64]
+        sig = {
+            'fpcc_pmf_to_quantized_cdf': [vp, i64, i32, vp, vp],
+            'fpcc_rans_indexed_encode': [vp, vp, i64, vp, vp, vp, vp, i64, i32, vp, i64],
+            'fpcc_rans_indexed_decode': [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp],
+            'fpcc_rans_binary_encode': [vp, vp, i64, vp, i64],
+            'fpcc_rans_binary_decode': [vp, i64, vp, i64, vp],
+            'fpcc_rans_binary_encode_multi': [vp, vp, vp, i64, vp, i64, vp, i32],
+            'fpcc_simple_enc_push': [vp, vp, i64, i64, vp, i64],
+            'fpcc_simple_enc_push_bin': [vp, vp, i64, vp, i64],
+            'fpcc_simple_enc_push_ranges': [vp, vp, vp, i64],
+            'fpcc_simple_enc_finish': [vp, vp, i64],
+            'fpcc_simple_dec_pop': [vp, vp, i64, i64, vp, i64],
+            'fpcc_simple_dec_pop_bin': [vp, vp, i64, vp, i64],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.restype = i64
+            fn.argtypes = args
+        L.fpcc_simple_enc_new.restype = vp
+        L.fpcc_simple_enc_new.argtypes = [i64]
+        L.fpcc_simple_enc_free.restype = None
+        L.fpcc_simple_enc_free.argtypes = [vp]
+        L.fpcc_simple_dec_new.restype = vp
+        L.fpcc_simple_dec_new.argtypes = [vp, i64]
+        L.fpcc_simple_dec_free.restype = None
+        L.fpcc_simple_dec_free.argtypes = [vp]
+        _host = L
+    return _host
+
+
+def host_check(code):
+    if code < 0:
+        raise RuntimeError('libfpcc_host: ' + host().fpcc_host_strerror(code).decode())
+    return code
+
+
+HOST_SYMBOLS = (
+    'fpcc_host_strerror', 'fpcc_pmf_to_quantized_cdf', 'fpcc_rans_indexed_encode', 'fpcc_rans_indexed_decode',
+    'fpcc_rans_binary_encode', 'fpcc_rans_binary_decode', 'fpcc_rans_binary_encode_multi', 'fpcc_simple_enc_new',
+    'fpcc_simple_enc_free', 'fpcc_simple_enc_push', 'fpcc_simple_enc_push_bin', 'fpcc_simple_enc_push_ranges',
+    'fpcc_simple_enc_finish', 'fpcc_simple_dec_new', 'fpcc_simple_dec_free', 'fpcc_simple_dec_pop',
+    'fpcc_simple_dec_pop_bin')
+
+
+def hip():
+    """libfpcc_hip.so (kernels for gfx950).  Signatures are attached in fastpcc_amd/hipops.py."""
+    global _hip
+    if _hip is None:
+        _hip = _load(_build.HIP_LIB, 'libfpcc_hip.so')
+    return _hip

@@ -1,0 +1,394 @@
+// libfpcc_host.so -- host-side entropy coders of the hot path (C ABI in include/fpcc_host.h).
+//
+// Byte-wise rANS with a 32-bit state, L = 2^23, 16-bit probabilities: the stream format of the reference's
+// rans_ext_cpp / simple_rans_ext_cpp (format description: /root/reference/lib/entropy_models/rans_coder/rans_byte.h:66-165),
+// so streams are interchangeable with the reference's.  Written from the format, not from the reference sources:
+// one templated writer/reader pair serves the indexed, binary and persistent-stream coders.
+#include "../../../include/fpcc_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t kLow = 1u << 23;   // lower bound of the normalised state interval
+constexpr uint32_t kProbBits = 16;
+constexpr uint32_t kProbOne = 1u << kProbBits;
+
+// Writes a stream backwards into [base, base + cap).
+class BackWriter {
+public:
+    BackWriter(uint8_t *base, int64_t cap) : base_(base), cur_(base + cap), end_(base + cap), state_(kLow) {}
+
+    // range [start, start + freq) out of 2^bits; freq >= 1
+    template <uint32_t BITS>
+    inline void put(uint32_t start, uint32_t freq) {
+        uint32_t x = state_;
+        const uint32_t ceiling = ((kLow >> BITS) << 8) * freq;
+        while (x >= ceiling) {
+            if (cur_ == base_) { full_ = true; break; }
+            *--cur_ = static_cast<uint8_t>(x);
+            x >>= 8;
+        }
+        const uint32_t q = x / freq;
+        state_ = (q << BITS) + (x - q * freq) + start;
+    }
+
+    // emit the state and return the stream length, or a negative code
+    int64_t finish() {
+        if (full_ || cur_ - base_ < 4) return FPCC_HOST_E_BUFFER;
+        cur_ -= 4;
+        cur_[0] = static_cast<uint8_t>(state_);
+        cur_[1] = static_cast<uint8_t>(state_ >> 8);
+        cur_[2] = static_cast<uint8_t>(state_ >> 16);
+        cur_[3] = static_cast<uint8_t>(state_ >> 24);
+        return end_ - cur_;
+    }
+
+    const uint8_t *head() const { return cur_; }
+    int64_t buffered() const { return end_ - cur_; }
+    bool full() const { return full_; }
+    void reset() { cur_ = end_; state_ = kLow; full_ = false; }
+
+private:
+    uint8_t *base_, *cur_, *end_;
+    uint32_t state_;
+    bool full_ = false;
+};
+
+class FrontReader {
+public:
+    FrontReader(const uint8_t *p, int64_t len) : p_(p + 4), end_(p + len) {
+        state_ = uint32_t(p[0]) | uint32_t(p[1]) << 8 | uint32_t(p[2]) << 16 | uint32_t(p[3]) << 24;
+    }
+    template <uint32_t BITS>
+    inline uint32_t peek() const { return state_ & ((1u << BITS) - 1u); }
+    template <uint32_t BITS>
+    inline void take(uint32_t start, uint32_t freq) {
+        uint32_t x = freq * (state_ >> BITS) + (state_ & ((1u << BITS) - 1u)) - start;
+        while (x < kLow) {
+            // reading past the end yields zeros: a truncated stream decodes to garbage, never out of bounds
+            uint32_t b = p_ < end_ ? *p_ : 0u;
+            ++p_;
+            x = (x << 8) | b;
+        }
+        state_ = x;
+    }
+
+private:
+    const uint8_t *p_, *end_;
+    uint32_t state_;
+};
+
+struct Tables {
+    const uint32_t *cdf;
+    const int64_t *start;
+    const int64_t *len;
+    const int32_t *offsets;
+    int64_t count;
+};
+
+template <bool ESCAPE>
+int64_t indexed_encode(const int32_t *sym, const int32_t *index, int64_t n, const Tables &t, uint8_t *out, int64_t cap) {
+    BackWriter w(out, cap);
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const int64_t ti = index ? index[i] : i % t.count;
+        if (ti < 0 || ti >= t.count) return FPCC_HOST_E_ARG;
+        const uint32_t *c = t.cdf + t.start[ti];
+        const int32_t bins = static_cast<int32_t>(t.len[ti]) - 1;
+        int32_t v = sym[i] - t.offsets[ti];
+        if (ESCAPE) {
+            // Values outside [0, bins-2] go through the last bin followed by an Elias-gamma-like tail of 1-bit
+            // uniform symbols.  Pushed in reverse of the decoder's reading order.
+            const int32_t esc = bins - 1;
+            const bool neg = v < 0;
+            uint32_t mag = 0;
+            if (neg) { mag = static_cast<uint32_t>(-static_cast<int64_t>(v)); v = esc; }
+            else if (v >= esc) { mag = static_cast<uint32_t>(v - esc + 1); v = esc; }
+            if (v == esc) {
+                w.put<1>(neg ? 1u : 0u, 1u);
+                int width = 0;
+                for (; mag != 0; mag >>= 1, ++width) w.put<1>(mag & 1u, 1u);
+                for (int z = 1; z < width; ++z) w.put<1>(0u, 1u);
+            }
+        } else if (v < 0 || v >= bins) {
+            return FPCC_HOST_E_ARG;
+        }
+        const uint32_t lo = c[v], hi = c[v + 1];
+        if (hi <= lo) return FPCC_HOST_E_ARG;
+        w.put<kProbBits>(lo, hi - lo);
+    }
+    return w.finish();
+}
+
+template <bool ESCAPE>
+int64_t indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t *index, int64_t n, const Tables &t,
+                       int32_t *out) {
+    if (stream_len < 4) return FPCC_HOST_E_ARG;
+    FrontReader r(stream, stream_len);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t ti = index ? index[i] : i % t.count;
+        if (ti < 0 || ti >= t.count) return FPCC_HOST_E_ARG;
+        const uint32_t *c = t.cdf + t.start[ti];
+        const int32_t bins = static_cast<int32_t>(t.len[ti]) - 1;
+        const uint32_t target = r.peek<kProbBits>();
+        // bin whose range holds `target`: first edge above it, minus one
+        int32_t v = static_cast<int32_t>(std::upper_bound(c + 1, c + bins + 1, target) - c) - 1;
+        r.take<kProbBits>(c[v], c[v + 1] - c[v]);
+        if (ESCAPE && v == bins - 1) {
+            int width = 0;
+            while (r.peek<1>() == 0) { r.take<1>(0u, 1u); ++width; }
+            r.take<1>(1u, 1u);
+            int32_t mag = 1;
+            for (int b = 0; b < width; ++b) {
+                const uint32_t bit = r.peek<1>();
+                r.take<1>(bit, 1u);
+                mag = (mag << 1) | static_cast<int32_t>(bit);
+            }
+            const uint32_t neg = r.peek<1>();
+            r.take<1>(neg, 1u);
+            v = neg ? -mag : mag + (bins - 1) - 1;
+        }
+        out[i] = v + t.offsets[ti];
+    }
+    return FPCC_HOST_OK;
+}
+
+int64_t binary_encode(const uint8_t *bits, const uint16_t *p1, int64_t n, uint8_t *out, int64_t cap) {
+    BackWriter w(out, cap);
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const uint32_t p = p1[i];
+        if (p == 0) return FPCC_HOST_E_ARG;
+        // ones sit at the top of the interval: [65536 - p, 65536); zeros at [0, 65536 - p)
+        if (bits[i]) w.put<kProbBits>(kProbOne - p, p);
+        else w.put<kProbBits>(0u, kProbOne - p);
+    }
+    return w.finish();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fpcc_host_strerror(int64_t code) {
+    switch (code) {
+        case FPCC_HOST_OK: return "ok";
+        case FPCC_HOST_E_BUFFER: return "output buffer too small";
+        case FPCC_HOST_E_ARG: return "invalid argument";
+        case FPCC_HOST_E_CDF: return "cdf cannot be made strictly increasing";
+        default: return "unknown error";
+    }
+}
+
+int64_t fpcc_pmf_to_quantized_cdf(const double *pmf, int64_t n, int overflow, int32_t *offset, uint32_t *cdf) {
+    if (!pmf || !cdf || n < 1 || (overflow && !offset)) return FPCC_HOST_E_ARG;
+    double mass = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(pmf[i] >= 0.0) || !std::isfinite(pmf[i])) return FPCC_HOST_E_ARG;
+        mass += pmf[i];
+    }
+    double denom = mass;
+    if (overflow) denom += std::max(1.0 - mass, 0.0);   // the escape bin takes what is left of 1
+
+    std::vector<uint32_t> edges(static_cast<size_t>(n) + (overflow ? 2 : 1));
+    double running = 0.0;
+    edges[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        running += pmf[i];
+        edges[i + 1] = static_cast<uint32_t>(std::round(double(kProbOne) * (running / denom)));
+    }
+    edges.back() = kProbOne;
+
+    if (overflow) {
+        const int64_t m = static_cast<int64_t>(edges.size());
+        int64_t head = 0, tail = 0;
+        for (int64_t i = 0; i + 1 < m; ++i) if (edges[i + 1] != edges[i]) { head = i; break; }
+        for (int64_t i = m - 2; i > 0; --i) if (edges[i - 1] != edges[i]) { tail = i; break; }
+        *offset += static_cast<int32_t>(head);
+        if (head > tail) { head = m - 3; tail = head + 1; }   // all mass in the escape bin
+        std::vector<uint32_t> kept(edges.begin() + head, edges.begin() + tail + 1);
+        kept.push_back(kProbOne);
+        edges.swap(kept);
+    }
+
+    const int64_t bins = static_cast<int64_t>(edges.size()) - 1;
+    for (int64_t i = 0; i < bins; ++i) {
+        if (edges[i + 1] != edges[i]) continue;
+        int64_t donor = -1;
+        uint32_t narrowest = ~0u;
+        for (int64_t j = 0; j < bins; ++j) {
+            const uint32_t f = edges[j + 1] - edges[j];
+            if (f > 1 && f < narrowest) { narrowest = f; donor = j; }
+        }
+        if (donor < 0) return FPCC_HOST_E_CDF;
+        if (donor < i) for (int64_t j = donor + 1; j <= i; ++j) --edges[j];
+        else for (int64_t j = i + 1; j <= donor; ++j) ++edges[j];
+    }
+    std::memcpy(cdf, edges.data(), edges.size() * sizeof(uint32_t));
+    return static_cast<int64_t>(edges.size());
+}
+
+int64_t fpcc_rans_indexed_encode(const int32_t *symbols, const int32_t *index, int64_t n, const uint32_t *cdf,
+                                 const int64_t *cdf_start, const int64_t *cdf_len, const int32_t *offsets,
+                                 int64_t n_tables, int overflow, uint8_t *out, int64_t cap) {
+    if (!symbols || !cdf || !cdf_start || !cdf_len || !offsets || !out || n < 0 || n_tables < 1) return FPCC_HOST_E_ARG;
+    const Tables t{cdf, cdf_start, cdf_len, offsets, n_tables};
+    return overflow ? indexed_encode<true>(symbols, index, n, t, out, cap)
+                    : indexed_encode<false>(symbols, index, n, t, out, cap);
+}
+
+int64_t fpcc_rans_indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t *index, int64_t n,
+                                 const uint32_t *cdf, const int64_t *cdf_start, const int64_t *cdf_len,
+                                 const int32_t *offsets, int64_t n_tables, int overflow, int32_t *symbols_out) {
+    if (!stream || !cdf || !cdf_start || !cdf_len || !offsets || !symbols_out || n < 0 || n_tables < 1)
+        return FPCC_HOST_E_ARG;
+    const Tables t{cdf, cdf_start, cdf_len, offsets, n_tables};
+    return overflow ? indexed_decode<true>(stream, stream_len, index, n, t, symbols_out)
+                    : indexed_decode<false>(stream, stream_len, index, n, t, symbols_out);
+}
+
+int64_t fpcc_rans_binary_encode(const uint8_t *bits, const uint16_t *prob1, int64_t n, uint8_t *out, int64_t cap) {
+    if (!bits || !prob1 || !out || n < 0) return FPCC_HOST_E_ARG;
+    return binary_encode(bits, prob1, n, out, cap);
+}
+
+int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
+                                uint8_t *bits_out) {
+    if (!stream || !prob1 || !bits_out || n < 0 || stream_len < 4) return FPCC_HOST_E_ARG;
+    FrontReader r(stream, stream_len);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t p = prob1[i];
+        const uint32_t split = kProbOne - p;
+        if (r.peek<kProbBits>() < split) { bits_out[i] = 0; r.take<kProbBits>(0u, split); }
+        else { bits_out[i] = 1; r.take<kProbBits>(split, p); }
+    }
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_rans_binary_encode_multi(const uint8_t *bits, const uint16_t *prob1, const int64_t *start,
+                                      int64_t n_streams, uint8_t *out, int64_t cap_each, int64_t *len_out,
+                                      int n_threads) {
+    if (!bits || !prob1 || !start || !out || !len_out || n_streams < 0) return FPCC_HOST_E_ARG;
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t s = next.fetch_add(1);
+            if (s >= n_streams) return;
+            len_out[s] = binary_encode(bits + start[s], prob1 + start[s], start[s + 1] - start[s],
+                                       out + s * cap_each, cap_each);
+        }
+    };
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(n_threads, n_streams));
+    std::vector<std::thread> pool;
+    for (int64_t k = 1; k < want; ++k) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    for (int64_t s = 0; s < n_streams; ++s) if (len_out[s] < 0) return len_out[s];
+    return FPCC_HOST_OK;
+}
+
+// ---- persistent single-stream coder ----------------------------------------------------------------------------
+struct fpcc_simple_enc {
+    std::vector<uint8_t> store;
+    BackWriter w;
+    explicit fpcc_simple_enc(int64_t bytes) : store(static_cast<size_t>(bytes)), w(store.data(), bytes) {}
+};
+
+struct fpcc_simple_dec {
+    FrontReader r;
+    fpcc_simple_dec(const uint8_t *p, int64_t n) : r(p, n) {}
+};
+
+static inline void edge_range(const uint16_t *row, int64_t width, uint32_t s, uint32_t &lo, uint32_t &hi) {
+    lo = s ? row[s - 1] : 0u;
+    hi = (int64_t(s) == width - 1) ? kProbOne : row[s];
+}
+
+fpcc_simple_enc *fpcc_simple_enc_new(int64_t buf_bytes) {
+    if (buf_bytes < 16) return nullptr;
+    return new (std::nothrow) fpcc_simple_enc(buf_bytes);
+}
+void fpcc_simple_enc_free(fpcc_simple_enc *e) { delete e; }
+
+int64_t fpcc_simple_enc_push(fpcc_simple_enc *e, const uint16_t *rows, int64_t n_rows, int64_t width,
+                             const uint16_t *symbols, int64_t n) {
+    if (!e || !rows || !symbols || width < 1 || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const uint16_t *row = rows + (n_rows == 1 ? 0 : i * width);
+        const uint32_t s = symbols[i];
+        if (int64_t(s) >= width) return FPCC_HOST_E_ARG;
+        uint32_t lo, hi;
+        edge_range(row, width, s, lo, hi);
+        if (hi <= lo) return FPCC_HOST_E_ARG;
+        e->w.put<kProbBits>(lo, hi - lo);
+    }
+    return e->w.full() ? int64_t(FPCC_HOST_E_BUFFER) : e->w.buffered();
+}
+
+int64_t fpcc_simple_enc_push_bin(fpcc_simple_enc *e, const uint16_t *edge, int64_t n_rows, const uint8_t *bits, int64_t n) {
+    if (!e || !edge || !bits || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const uint32_t c = edge[n_rows == 1 ? 0 : i];
+        if (bits[i]) e->w.put<kProbBits>(c, kProbOne - c);
+        else e->w.put<kProbBits>(0u, c);
+    }
+    return e->w.full() ? int64_t(FPCC_HOST_E_BUFFER) : e->w.buffered();
+}
+
+int64_t fpcc_simple_enc_push_ranges(fpcc_simple_enc *e, const uint16_t *start, const uint16_t *freq_m1, int64_t n) {
+    if (!e || !start || !freq_m1) return FPCC_HOST_E_ARG;
+    for (int64_t i = n - 1; i >= 0; --i) e->w.put<kProbBits>(start[i], uint32_t(freq_m1[i]) + 1u);
+    return e->w.full() ? int64_t(FPCC_HOST_E_BUFFER) : e->w.buffered();
+}
+
+int64_t fpcc_simple_enc_finish(fpcc_simple_enc *e, uint8_t *out, int64_t cap) {
+    if (!e || !out) return FPCC_HOST_E_ARG;
+    int64_t n = e->w.finish();
+    if (n >= 0) {
+        if (n > cap) n = FPCC_HOST_E_BUFFER;
+        else std::memcpy(out, e->w.head(), static_cast<size_t>(n));
+    }
+    e->w.reset();
+    return n;
+}
+
+fpcc_simple_dec *fpcc_simple_dec_new(const uint8_t *stream, int64_t stream_len) {
+    if (!stream || stream_len < 4) return nullptr;
+    return new (std::nothrow) fpcc_simple_dec(stream, stream_len);
+}
+void fpcc_simple_dec_free(fpcc_simple_dec *d) { delete d; }
+
+int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_rows, int64_t width,
+                            uint16_t *symbols_out, int64_t n) {
+    if (!d || !rows || !symbols_out || width < 1 || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t *row = rows + (n_rows == 1 ? 0 : i * width);
+        const uint32_t target = d->r.peek<kProbBits>();
+        int64_t s = std::upper_bound(row, row + width, static_cast<uint16_t>(target)) - row;
+        s = std::min<int64_t>(s, width - 1);
+        uint32_t lo, hi;
+        edge_range(row, width, static_cast<uint32_t>(s), lo, hi);
+        d->r.take<kProbBits>(lo, hi - lo);
+        symbols_out[i] = static_cast<uint16_t>(s);
+    }
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_simple_dec_pop_bin(fpcc_simple_dec *d, const uint16_t *edge, int64_t n_rows, uint8_t *bits_out, int64_t n) {
+    if (!d || !edge || !bits_out || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t c = edge[n_rows == 1 ? 0 : i];
+        const bool one = d->r.peek<kProbBits>() >= c;
+        if (one) d->r.take<kProbBits>(c, kProbOne - c);
+        else d->r.take<kProbBits>(0u, c);
+        bits_out[i] = one;
+    }
+    return FPCC_HOST_OK;
+}
+
+}  // extern "C"

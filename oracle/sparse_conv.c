@@ -1,0 +1,83 @@
+/*
+ * TEST ORACLE -- NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the float sparse convolution the reference obtains from MinkowskiEngine
+ * (un-vendored third-party dependency, "MinkowskiEngine ~= 0.5.4", /root/reference/README.md:49-50; call sites
+ * /root/reference/lib/minkowski_sparse_conv_layers.py:67-91).  Published algorithm restated:
+ *
+ *      out[o, :] = sum_k  X[in_k(o), :] @ W[k]  + bias        (fp32; W laid out [K, C_in, C_out])
+ *
+ * for every kernel offset k that has an input row in_k(o) for output row o (the "kernel map").  How the map is
+ * built is in oracle/coords.py; this file only does the arithmetic.
+ *
+ * Parity: UNPINNED against MinkowskiEngine (it cannot be built or run in this image).  It is
+ * pinned against oracle/sparse_conv.py's torch formulation (index_select -> mm -> index_add_, the structure of ME's
+ * CPU backend) in tests/test_oracle_conv.py.
+ *
+ * fp32 addition is not associative and the reference leaves the summation order to cuBLAS.  This restatement fixes
+ * one: a single fused-multiply-add chain per output element, kernel offsets ascending, input channels in the order
+ * selected by `order`:
+ *      order 0: natural 0,1,2,...
+ *      order 1: inside every aligned group of 8 channels: 0,4,1,5,2,6,3,7  (the order in which gfx950's
+ *               v_mfma_f32_32x32x2_f32 consumes a 16-byte-per-lane A fragment; C_in must be a multiple of 8)
+ * so that a device kernel documenting the same order can be compared bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ORC_ACT_NONE = 0, ORC_ACT_PRELU = 1, ORC_ACT_RELU = 2 };
+
+static inline int64_t chan_at(int64_t pos, int order) {
+    if (order == 0) return pos;
+    static const int p8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    return (pos & ~(int64_t)7) + p8[pos & 7];
+}
+
+/*
+ * x1 [n_in, c1] (row stride ld1 floats), optional x2 [n_in, c2] (row stride ld2): the input row is their concatenation.
+ * nbr [K, n_out] int32 (input row or -1); NULL means K == 1 and in(o) == o.
+ * w [K, c1+c2, c_out]; bias [c_out] or NULL.
+ * out_map NULL (row o -> o) or [n_out] (row o is written to out_map[o], skipped when negative).
+ * out row stride = ldo floats.
+ * act: 0 none, 1 PReLU(slope), 2 ReLU.  clip > 0 clamps to [-clip, clip] afterwards.
+ */
+void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *x2, int64_t c2, int64_t ld2,
+                         const int32_t *nbr, int64_t K, int64_t n_out,
+                         const float *w, const float *bias, int64_t c_out,
+                         const int32_t *out_map, float *out, int64_t ldo,
+                         int act, float slope, float clip, int order) {
+    const int64_t c_in = c1 + c2;
+#pragma omp parallel
+    {
+        float *acc = (float *)malloc(sizeof(float) * (size_t)c_out);
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t o = 0; o < n_out; ++o) {
+            int64_t dst = out_map ? out_map[o] : o;
+            if (dst < 0) continue;
+            for (int64_t j = 0; j < c_out; ++j) acc[j] = 0.0f;
+            for (int64_t k = 0; k < K; ++k) {
+                int64_t r = nbr ? nbr[k * n_out + o] : o;
+                if (r < 0) continue;
+                const float *wk = w + k * c_in * c_out;
+                for (int64_t pos = 0; pos < c_in; ++pos) {
+                    int64_t c = chan_at(pos, order);
+                    float xv = c < c1 ? x1[r * ld1 + c] : x2[r * ld2 + (c - c1)];
+                    const float *wr = wk + c * c_out;
+                    for (int64_t j = 0; j < c_out; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+                }
+            }
+            float *orow = out + dst * ldo;
+            for (int64_t j = 0; j < c_out; ++j) {
+                float v = acc[j];
+                if (bias) v = v + bias[j];
+                if (act == ORC_ACT_PRELU) v = v < 0.0f ? v * slope : v;
+                else if (act == ORC_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+                if (clip > 0.0f) v = v < -clip ? -clip : (v > clip ? clip : v);
+                orow[j] = v;
+            }
+        }
+        free(acc);
+    }
+}
