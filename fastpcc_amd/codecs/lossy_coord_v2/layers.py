@@ -1,0 +1,273 @@
+"""Network pieces of the lossy_coord_v2 codec (inference paths).
+
+Same class names, constructor arguments and sub-module attribute names as
+/root/reference/models/convolutional/lossy_coord_v2/layers.py:28-415, so a reference checkpoint's state_dict keys load
+unchanged; the forward passes are written against fastpcc_amd.engine (fused conv+bias+activation(+clip) launches, lazy
+channel concatenation, fused top-k pruning).  Training-time members of the reference (`train_forward`, `get_target`,
+`get_coord_recon_loss`, `BoundFunction.backward`) are outside this inference path.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import engine as ME
+from ... import hipops as ops
+from ...sparse_conv_layers import ConvBlock, ConvTransBlock, GenConvTransBlock, MEMLPBlock, \
+    NNSequentialWithConvBlockArgs, NNSequentialWithConvTransBlockArgs
+
+
+def _run(seq: nn.Sequential, x, last_clip: float = 0.0):
+    """nn.Sequential forward that lets the LAST block fuse a clamp into its epilogue."""
+    mods = list(seq)
+    for m in mods[:-1]:
+        x = m(x)
+    return mods[-1](x, clip=last_clip) if last_clip > 0 else mods[-1](x)
+
+
+class Encoder(nn.Module):
+    """conv3(in->c0) @stride 1, then per extra channel entry: conv2s2 + conv3 (layers.py:28-72)."""
+
+    def __init__(self, in_channels: int, intra_channels: Tuple[int, ...], requires_points_num_list: bool,
+                 points_num_scaler: float, region_type: str, act: Optional[str]):
+        super().__init__()
+        self.requires_points_num_list = requires_points_num_list
+        self.points_num_scaler = points_num_scaler
+        stages = [ConvBlock(in_channels, intra_channels[0], 3, 1, region_type=region_type, act=act)]
+        for c_prev, c in zip(intra_channels[:-1], intra_channels[1:]):
+            stages.append(nn.Sequential(
+                ConvBlock(c_prev, c, 2, 2, region_type='HYPER_CUBE', act=act),
+                ConvBlock(c, c, 3, 1, region_type=region_type, act=act)))
+        self.blocks = nn.ModuleList(stages)
+
+    def forward(self, x) -> Tuple[ME.SparseTensor, Optional[List[List[int]]]]:
+        counts = []
+        last = len(self.blocks) - 1
+        for i, block in enumerate(self.blocks):
+            x = block(x)
+            if i != last:
+                cm = x.coordinate_manager
+                edges = cm.batch_offsets(cm._map(x.coordinate_map_key))
+                counts.append([b - a for a, b in zip(edges[:-1], edges[1:])])
+        if not self.requires_points_num_list:
+            return x, None
+        return x, [[int(n * self.points_num_scaler) for n in c] for c in counts]
+
+
+class Decoder(nn.Module):
+    """Generative upsampling with adaptive top-k pruning back to stride 1 (layers.py:75-180)."""
+
+    def __init__(self, in_channels: int, intra_channels: Tuple[int, ...], region_type: str, act: Optional[str]):
+        super().__init__()
+        self.upsample_blocks = nn.ModuleList()
+        self.classify_blocks = nn.ModuleList()
+        prev = in_channels
+        n_stage = len(intra_channels)
+        for i, ch in enumerate(intra_channels):
+            up = nn.Sequential()
+            if i == n_stage - 1:
+                up.append(ConvBlock(prev, prev, 3, 1, region_type=region_type, act=act))
+            up.append(GenConvTransBlock(prev, ch, 2, 2, region_type='HYPER_CUBE', act=act))
+            if i != n_stage - 1:
+                up.append(ConvBlock(ch, ch, 3, 1, region_type=region_type, act=act))
+            self.upsample_blocks.append(up)
+            self.classify_blocks.append(nn.Sequential(ConvBlock(ch, ch // 2, 1, 1, act=act),
+                                                      ConvBlock(ch // 2, 1, 1, 1, act=None)))
+            prev = ch
+        self.pruning = ME.MinkowskiPruning()
+
+    def forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None):
+        if self.training:
+            raise NotImplementedError('training path is not part of this build')
+        return self.test_forward(fea, points_num_list, coord_offset)
+
+    @torch.no_grad()
+    def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns xyz int32 [N, 3] (plus coord_offset, a device int32[3], when given)."""
+        last = len(self.upsample_blocks) - 1
+        for i, (up, classify) in enumerate(zip(self.upsample_blocks, self.classify_blocks)):
+            fea = up(fea)
+            keep = self.get_keep(classify(fea), points_num_list)
+            if i != last:
+                fea = self.pruning(fea, keep)
+            else:
+                cm = fea.coordinate_manager
+                gen = cm._map(fea.coordinate_map_key)
+                if not gen.generated:
+                    raise RuntimeError('decoder output is expected on a generated coordinate set')
+                xyz, count = ops.compact_coords(gen.parent.keys, keep, gen.level, gen.bits, coord_offset)
+                return xyz[:int(count.item())]
+
+    @torch.no_grad()
+    def get_keep(self, pred: ME.SparseTensor, points_num_list: Optional[List[List[int]]]) -> torch.Tensor:
+        """uint8 [n]: logit above the adaptive threshold, or the maximum of its 2x2x2 cell (layers.py:151-180)."""
+        cm = pred.coordinate_manager
+        gen = cm._map(pred.coordinate_map_key)
+        if not gen.generated:
+            raise NotImplementedError('get_keep expects the candidates of a generative upsampling')
+        logits = pred.F.view(-1)
+        if points_num_list is None:
+            # fixed threshold 0: same kernel with a target that makes the k-th value irrelevant is not possible,
+            # so threshold through the general path with k = number of non-positive candidates
+            raise NotImplementedError('adaptive_pruning=False is not part of the in-scope configurations')
+        target = points_num_list.pop()
+        if len(target) != 1:
+            raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')
+        if not logits.numel() > target[0]:
+            raise ValueError('fewer candidates than points to keep')
+        return ops.topk_keep(logits, target[0])
+
+
+class HyperDecoderUpsample(nn.Module):
+    """Per level: (transposed conv k2s2 onto a given key | conv3) + conv3 (layers.py:201-227)."""
+
+    def __init__(self, in_channels: Tuple[int, ...], out_channels: Tuple[int, ...], if_sample: Tuple[int, ...],
+                 region_type: str, act: Optional[str]):
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for c_in, c_out, up in zip(in_channels, out_channels, if_sample):
+            if up:
+                head = ConvTransBlock(max(c_in, 1), c_out, 2, 2, region_type=region_type, act=act)
+                seq = NNSequentialWithConvTransBlockArgs
+            else:
+                head = ConvBlock(max(c_in, 1), c_out, 3, 1, region_type=region_type, act=act)
+                seq = NNSequentialWithConvBlockArgs
+            self.blocks.append(seq(head, ConvBlock(c_out, c_out, 3, 1, region_type=region_type, act=act)))
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __getitem__(self, idx):
+        return self.blocks[idx]
+
+
+class HyperDecoderGenUpsample(nn.Module):
+    """Per upsampling level: generative conv k2s2 (C -> C/4) + conv3 (-> 1 occupancy logit) (layers.py:230-249)."""
+
+    def __init__(self, in_channels: Tuple[int, ...], if_sample: Tuple[int, ...], region_type: str, act: Optional[str]):
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for c_in, up in zip(in_channels, if_sample):
+            if not up:
+                self.blocks.append(None)
+                continue
+            mid = max(c_in // 4, 1)
+            self.blocks.append(nn.Sequential(
+                GenConvTransBlock(c_in, mid, 2, 2, region_type=region_type, act=act),
+                ConvBlock(mid, 1, 3, 1, region_type=region_type, act=None)))
+
+    def __getitem__(self, idx):
+        return self.blocks[idx]
+
+
+class SubResidualGeoLossl(nn.Module):
+    """cat(fea, prediction) -> conv3 -> conv3 -> clamp to +-bound (layers.py:252-271)."""
+
+    def __init__(self, in_ch, out_ch, region_type, act, bottleneck_value_bound: int):
+        super().__init__()
+        self.blocks = nn.Sequential(
+            ConvBlock(in_ch + in_ch, in_ch, 3, 1, region_type=region_type, act=act),
+            ConvBlock(in_ch, out_ch, 3, 1, region_type=region_type, act=None))
+        self.register_buffer('bound', torch.tensor(bottleneck_value_bound), persistent=False)
+        self._bound = float(bottleneck_value_bound)
+
+    def forward(self, x, y):
+        return _run(self.blocks, ME.cat(x, y), last_clip=self._bound)
+
+
+class ResidualGeoLossl(nn.Module):
+    def __init__(self, in_channels: Tuple[int, ...], out_channels: Tuple[int, ...], region_type: str,
+                 act: Optional[str], bottleneck_value_bound: int, skip_encoding_fea: int):
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for idx, (c_in, c_out) in enumerate(zip(in_channels, out_channels)):
+            self.blocks.append(SubResidualGeoLossl(c_in, c_out, region_type, act, bottleneck_value_bound)
+                               if idx > skip_encoding_fea else None)
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __getitem__(self, idx):
+        return self.blocks[idx]
+
+
+class SubDecoderGeoLossl(nn.Module):
+    """MLP(residual) ++ prediction -> MLP (layers.py:294-315)."""
+
+    def __init__(self, in_ch, in_ch2, out_ch, region_type, act):
+        super().__init__()
+        self.residual_decoder = nn.Sequential(MEMLPBlock(in_ch, out_ch // 2, act=act),
+                                              MEMLPBlock(out_ch // 2, out_ch, act=act))
+        self.decoder = nn.Sequential(MEMLPBlock(out_ch + in_ch2, out_ch, act=act),
+                                     MEMLPBlock(out_ch, out_ch, act=act))
+
+    def forward(self, x, y: ME.SparseTensor):
+        if isinstance(x, torch.Tensor):
+            x = ME.SparseTensor(x, coordinate_map_key=y.coordinate_map_key, coordinate_manager=y.coordinate_manager)
+        return self.decoder(ME.cat(self.residual_decoder(x), y))
+
+
+class SubDecoderGeoLossl2(nn.Module):
+    def __init__(self, in_ch, in_ch2, out_ch, region_type, act):
+        super().__init__()
+        self.decoder = nn.Sequential(MEMLPBlock(in_ch2, out_ch, act=act), MEMLPBlock(out_ch, out_ch, act=act))
+
+    def forward(self, x):
+        return self.decoder(x)
+
+
+class DecoderGeoLossl(nn.Module):
+    def __init__(self, in_channels: Tuple[int, ...], in_channels2: Tuple[int, ...], out_channels: Tuple[int, ...],
+                 region_type: str, act: Optional[str], skip_encoding_fea: int):
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for idx, (c_in, c_out, c_in2) in enumerate(zip(in_channels, out_channels, in_channels2)):
+            cls = SubDecoderGeoLossl if idx > skip_encoding_fea else SubDecoderGeoLossl2
+            self.blocks.append(cls(c_in, c_in2, c_out, region_type, act))
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __getitem__(self, idx):
+        return self.blocks[idx]
+
+
+class EncoderGeoLossl(nn.Module):
+    """The analysis pyramid of the lossless coder: per level (conv k2s2 | conv3) + conv3, with an MLP head on the levels
+    whose features are coded; the last head is clamped to +-bound (layers.py:357-415)."""
+
+    def __init__(self, in_channels: Tuple[int, ...], out_channels: Tuple[int, ...], if_sample: Tuple[int, ...],
+                 region_type: str, act: Optional[str], bottleneck_value_bound: int, skip_encoding_fea: int):
+        super().__init__()
+        if len(in_channels) + 1 != len(out_channels):
+            raise ValueError('out_channels must have one more entry than in_channels')
+        self.blocks_out_first = MEMLPBlock(in_channels[0], out_channels[0], act=act) if skip_encoding_fea < 0 else None
+        self.blocks = nn.ModuleList()
+        self.blocks_out = nn.ModuleList()
+        for idx, (c_in, c_out, down) in enumerate(zip(in_channels, out_channels[1:], if_sample)):
+            wide = max(c_in, c_out)
+            first = ConvBlock(c_in, c_in, 2, 2, region_type=region_type, act=act) if down else \
+                ConvBlock(c_in, c_in, 3, 1, region_type=region_type, act=act)
+            self.blocks.append(nn.Sequential(first, ConvBlock(c_in, wide, 3, 1, region_type=region_type, act=act)))
+            self.blocks_out.append(MEMLPBlock(wide, c_out, act=act) if idx >= skip_encoding_fea else None)
+        self.out_channels = out_channels
+        self.register_buffer('bound', torch.tensor(bottleneck_value_bound), persistent=False)
+        self._bound = float(bottleneck_value_bound)
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def forward(self, x: ME.SparseTensor, batch_size: int) -> List[ME.SparseTensor]:
+        if batch_size != 1:
+            raise NotImplementedError('batch size 1 at test time')
+        outs = [self.blocks_out_first(x) if self.blocks_out_first is not None else x]
+        last = len(self.blocks) - 1
+        for i, (block, head) in enumerate(zip(self.blocks, self.blocks_out)):
+            x = block(x)
+            if head is None:
+                outs.append(x)
+            else:
+                outs.append(head(x, clip=self._bound) if i == last else head(x))
+        if self.blocks_out[last] is None:
+            raise NotImplementedError('the bottom level must carry a coded feature')
+        return outs

@@ -1,0 +1,148 @@
+"""lossy_coord_v2 point-cloud geometry codec: encode/decode entry points with the module tree (state_dict keys), the
+method names and the frame layout of `PCC` in /root/reference/models/convolutional/lossy_coord_v2/model.py:23-288.
+
+    compress(batched_coord)   -> bytes      u16 x0,y0,z0 | u24 target point count per pruning stage | lossless payload
+    decompress(bytes)         -> int32 [N, 3]
+    test_forward(PCData)      -> dict with the reconstructed cloud, the bytes and the two wall-clock times, timed the
+                                 way the reference's Timer blocks are (device synchronised at both ends).
+
+Training (`train_forward`) is not part of this inference build.
+"""
+import io
+import time
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import engine as ME
+from ...data import PCData
+from ..geo_lossl_em import GeoLosslessEntropyModel
+from .layers import Decoder, DecoderGeoLossl, Encoder, EncoderGeoLossl, HyperDecoderGenUpsample, \
+    HyperDecoderUpsample, ResidualGeoLossl
+from .model_config import ModelConfig
+
+
+class PCC(nn.Module):
+
+    @staticmethod
+    def params_divider(s: str) -> int:
+        return 1 if 'bottom_fea_entropy_model' in s else 0
+
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        self.cfg = cfg
+        ME.set_sparse_tensor_operation_mode(ME.SparseTensorOperationMode.SHARE_COORDINATE_MANAGER)
+        if len(cfg.compressed_channels) != len(cfg.geo_lossl_channels) or \
+                len(cfg.geo_lossl_if_sample) != len(cfg.geo_lossl_channels) - 1 or \
+                cfg.compressed_channels[-1] != cfg.geo_lossl_channels[-1]:
+            raise ValueError('inconsistent geo_lossl_* / compressed_channels configuration')
+        ch = cfg.geo_lossl_channels
+        region, act = cfg.conv_region_type, cfg.activation
+
+        self.encoder = Encoder(1, cfg.encoder_channels, cfg.adaptive_pruning, cfg.adaptive_pruning_scaler, region, act)
+        self.decoder = Decoder(ch[0], cfg.decoder_channels, region, act)
+        self.em_lossless_based = GeoLosslessEntropyModel(
+            cfg.compressed_channels[0], cfg.bottleneck_process, cfg.bottleneck_scaler, cfg.skip_encoding_fea,
+            encoder=EncoderGeoLossl(ch[:-1], ch, cfg.geo_lossl_if_sample, region, act, cfg.bottleneck_value_bound,
+                                    cfg.skip_encoding_fea),
+            residual_block=ResidualGeoLossl(ch[:-1], cfg.compressed_channels[:-1], region, act,
+                                            cfg.bottleneck_value_bound, cfg.skip_encoding_fea),
+            decoder_block=DecoderGeoLossl(cfg.compressed_channels[:-1], ch[:-1], ch[:-1], region, act,
+                                          cfg.skip_encoding_fea),
+            hyper_decoder_coord=HyperDecoderGenUpsample(ch[1:], cfg.geo_lossl_if_sample, region, act),
+            hyper_decoder_fea=HyperDecoderUpsample(ch[1:], ch[:-1], cfg.geo_lossl_if_sample, region, act))
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def forward(self, pc_data: PCData):
+        if self.training:
+            raise NotImplementedError('training is not part of this inference build')
+        if pc_data.batch_size != 1:
+            raise ValueError('Only supports batch size == 1 during testing.')
+        return self.test_forward(pc_data)
+
+    def set_global_cm(self) -> ME.CoordinateManager:
+        ME.clear_global_coordinate_manager()
+        cm = ME.CoordinateManager(D=3)
+        ME.set_global_coordinate_manager(cm)
+        return cm
+
+    def get_sparse_pc(self, xyz: torch.Tensor) -> ME.SparseTensor:
+        """All-ones 1-channel tensor on the input voxels.  The engine keeps every map in Morton order, which is what the
+        reference obtains by sorting explicitly before building the tensor (model.py:140-142)."""
+        cm = self.set_global_cm()
+        ones = torch.ones((xyz.shape[0], 1), dtype=torch.float32, device=xyz.device)
+        return ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
+                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def compress(self, batched_coord: torch.Tensor) -> bytes:
+        if not batched_coord.is_cuda:
+            raise RuntimeError('compress() runs on the GPU; move the coordinates there first')
+        coord_offset = batched_coord[:, 1:].amin(0)
+        sparse_pc = self.get_sparse_pc((batched_coord - F.pad(coord_offset, (1, 0))).contiguous())
+        feature, points_num_list = self.encoder(sparse_pc)
+        em_bytes = self.em_lossless_based.compress(feature, 1)
+        with io.BytesIO() as bs:
+            for v in coord_offset.tolist():
+                bs.write(int(v).to_bytes(2, 'little', signed=False))
+            if self.cfg.adaptive_pruning:
+                for counts in points_num_list:
+                    bs.write(int(counts[0]).to_bytes(3, 'little', signed=False))
+            bs.write(em_bytes)
+            return bs.getvalue()
+
+    def compress_partitions(self, batched_coord: List[torch.Tensor]) -> bytes:
+        # element 0 is the unpartitioned cloud (model.py:249-250)
+        parts = [self.compress(p) for p in batched_coord[1:]]
+        return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in parts)
+
+    @torch.no_grad()
+    def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
+        dev = next(self.parameters()).device
+        with io.BytesIO(compressed_bytes) as bs:
+            coord_offset = [int.from_bytes(bs.read(2), 'little', signed=False) for _ in range(3)]
+            points_num_list = None
+            if self.cfg.adaptive_pruning:
+                points_num_list = [[int.from_bytes(bs.read(3), 'little', signed=False)]
+                                   for _ in range(len(self.encoder.blocks) - 1)]
+            em_bytes = bs.read()
+        fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
+        offset = torch.tensor(coord_offset, dtype=torch.int32, device=dev)
+        return self.decoder(fea_recon, points_num_list, offset)
+
+    def decompress_partitions(self, concat_bytes: bytes) -> torch.Tensor:
+        out = []
+        with io.BytesIO(concat_bytes) as bs:
+            while bs.tell() != len(concat_bytes):
+                length = int.from_bytes(bs.read(3), 'little', signed=False)
+                out.append(self.decompress(bs.read(length)))
+        return torch.cat(out, 0)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def test_forward(self, pc_data: PCData) -> dict:
+        whole = isinstance(pc_data.xyz, torch.Tensor)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        compressed_bytes = self.compress(pc_data.xyz) if whole else self.compress_partitions(pc_data.xyz)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ME.clear_global_coordinate_manager()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        coord_recon = self.decompress(compressed_bytes) if whole else self.decompress_partitions(compressed_bytes)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ME.clear_global_coordinate_manager()
+        if pc_data.inv_transform is not None:
+            inv = pc_data.inv_transform[0].to(coord_recon.device)
+            pred_xyz = coord_recon * inv[3] + inv[None, :3]
+            compressed_bytes = pc_data.inv_transform[0].numpy().astype('<f4').tobytes() + compressed_bytes
+        else:
+            pred_xyz = coord_recon
+        n_org = pc_data.org_points_num[0] if pc_data.org_points_num else \
+            (pc_data.xyz.shape[0] if whole else pc_data.xyz[0].shape[0])
+        return {'pred': pred_xyz, 'compressed_bytes': compressed_bytes, 'bpp': 8 * len(compressed_bytes) / n_org,
+                'encode time': t1 - t0, 'decode time': t3 - t2}

@@ -1,0 +1,42 @@
+// Shared helpers for libfpcc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../../include/fpcc_hip.h"
+
+namespace fpcc {
+
+void set_error(const char *fmt, ...);
+
+inline int fail_arg(const char *what) {
+    set_error("invalid argument: %s", what);
+    return FPCC_E_ARG;
+}
+
+inline int check_hip(hipError_t e, const char *where) {
+    if (e == hipSuccess) return FPCC_OK;
+    set_error("%s: %s", where, hipGetErrorString(e));
+    return FPCC_E_HIP;
+}
+
+#define FPCC_HIP(expr)                                          \
+    do {                                                        \
+        int rc__ = ::fpcc::check_hip((expr), #expr);            \
+        if (rc__ != FPCC_OK) return rc__;                       \
+    } while (0)
+
+#define FPCC_LAUNCHED(name) FPCC_HIP((hipGetLastError()))
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;   // gfx950 wavefront
+
+inline unsigned blocks_for(int64_t n, int threads) { return static_cast<unsigned>((n + threads - 1) / threads); }
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace fpcc

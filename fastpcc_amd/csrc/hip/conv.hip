@@ -1,0 +1,363 @@
+// fp32 sparse convolution for gfx950: output-stationary gather -> LDS -> v_mfma_f32_32x32x2_f32.
+//
+// One workgroup (4 waves) owns 128 consecutive output rows (rows are Morton-sorted, so their neighbourhoods overlap and
+// the gathered input rows are L2-resident) and ALL output channels.  It walks the kernel offsets that occur in its tile
+// and, per offset, the input channels in chunks of CH; a stage = (offset, chunk):
+//     global (gathered rows of X, one 128-byte line per row and chunk; the W[k] chunk, contiguous)
+//         -> registers (issued one stage ahead) -> LDS (double buffered, XOR-swizzled) -> MFMA fragments.
+// Every output element is ONE fp32 FMA chain (offsets ascending, channels in the order documented in fpcc_hip.h), it is
+// written once, nothing is scattered or atomically added: results are bitwise reproducible and independent of tiling,
+// which the codec needs because the decoder must recompute the encoder's activations exactly.
+// Offsets absent from a whole wave's 32 rows are skipped by that wave, offsets absent from the tile by the workgroup
+// (adding x*0 would not change the chain's value).
+//
+// Roofline: 2*L*C_in*C_out algorithmic flop against the fp32 MFMA peak (157 TFLOP/s); the gathered bytes
+// (L*C_in*4 from L2/MALL) are ~1/16 of what the MFMAs can consume at C_out = 128.
+//
+// Shapes the MFMA kernel does not cover (C_out in {1, 8, 16}, C_in = 1, ...) are tiny in this codec and go through the
+// VALU kernel below: one thread per output row and block of <= 16 output channels, weights through the scalar cache.
+#include "common.h"
+
+namespace fpcc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float *x1; int c1; int ld1;
+    const float *x2; int c2; int ld2;
+    const int32_t *nbr; int n_off; int64_t nbr_ks; int64_t nbr_os;
+    const float *w; const float *bias; int c_out; int groups;
+    const int32_t *out_map; int64_t om_os; int64_t om_gs; float *out; int ldo; int64_t n_out;
+    int act; const float *slope; float clip;
+};
+
+__device__ float g_zero_row[64];   // 256 bytes of zeros: the source of every absent neighbour
+
+__device__ __forceinline__ float finish(float v, float b, int act, float slope, float clip) {
+    v = v + b;
+    if (act == FPCC_ACT_PRELU) v = v < 0.0f ? v * slope : v;
+    else if (act == FPCC_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+    if (clip > 0.0f) v = fminf(fmaxf(v, -clip), clip);
+    return v;
+}
+
+// blockIdx.x -> tile so that tiles adjacent in row order share an XCD (and therefore its L2); bijective for any grid size
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
+    const unsigned q = n / 8, r = n % 8, x = bid % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
+constexpr int kTileRows = 128;
+
+template <int CH>
+__device__ __forceinline__ int swz(int r) {
+    // 16-byte piece index XOR so that the 16 lanes of a ds_read_b128 group land on 16 different bank slots
+    return CH == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3);
+}
+
+template <int NB, int CH>
+struct MfmaCfg {
+    static constexpr int C_OUT = 32 * NB;
+    static constexpr int PPR = CH / 4;                        // 16-byte pieces per gathered row chunk
+    static constexpr int A_PIECES = kTileRows * PPR / 256;    // per thread
+    static constexpr int W_TOTAL = CH * C_OUT / 4;            // 16-byte pieces of one weight chunk
+    static constexpr int W_PIECES = (W_TOTAL + 255) / 256;
+};
+
+// global -> registers for stage (k, cc)
+template <int NB, int CH>
+__device__ __forceinline__ void stage_fetch(const ConvArgs &a, const float *wg, int64_t row0, int c_in, int tid, int k,
+                                            int cc, f32x4 (&ra)[MfmaCfg<NB, CH>::A_PIECES],
+                                            f32x4 (&rw)[MfmaCfg<NB, CH>::W_PIECES]) {
+    using C = MfmaCfg<NB, CH>;
+    // the chunk lies entirely in x1 or entirely in x2 (c1 is a multiple of CH): a scalar choice, no per-lane branch
+    const bool in_x1 = cc * CH < a.c1;
+    const float *xb = in_x1 ? a.x1 + cc * CH : a.x2 + (cc * CH - a.c1);
+    const int64_t ld = in_x1 ? a.ld1 : a.ld2;
+    const int32_t *nk = a.nbr ? a.nbr + (int64_t)k * a.nbr_ks : nullptr;
+#pragma unroll
+    for (int j = 0; j < C::A_PIECES; ++j) {
+        const int p = tid + 256 * j;
+        const int r = p / C::PPR, q = p % C::PPR;
+        const int64_t row = row0 + r;
+        int32_t idx = (int32_t)row;
+        if (nk) idx = nk[(row < a.n_out ? row : 0) * a.nbr_os];
+        if (row >= a.n_out) idx = -1;
+        const float *src = idx >= 0 ? xb + (int64_t)idx * ld + 4 * q : (const float *)g_zero_row;
+        ra[j] = *reinterpret_cast<const f32x4 *>(src);
+    }
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wg + ((int64_t)k * c_in + (int64_t)cc * CH) * C::C_OUT);
+#pragma unroll
+    for (int j = 0; j < C::W_PIECES; ++j) {
+        const int p = tid + 256 * j;
+        rw[j] = (C::W_TOTAL % 256 == 0 || p < C::W_TOTAL) ? wsrc[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// registers -> LDS buffer
+template <int NB, int CH>
+__device__ __forceinline__ void stage_stash(float *dA, float *dWf, int tid,
+                                            const f32x4 (&ra)[MfmaCfg<NB, CH>::A_PIECES],
+                                            const f32x4 (&rw)[MfmaCfg<NB, CH>::W_PIECES]) {
+    using C = MfmaCfg<NB, CH>;
+#pragma unroll
+    for (int j = 0; j < C::A_PIECES; ++j) {
+        const int p = tid + 256 * j;
+        const int r = p / C::PPR, q = p % C::PPR;
+        *reinterpret_cast<f32x4 *>(dA + r * CH + 4 * (q ^ swz<CH>(r))) = ra[j];
+    }
+    f32x4 *dW = reinterpret_cast<f32x4 *>(dWf);
+#pragma unroll
+    for (int j = 0; j < C::W_PIECES; ++j) {
+        const int p = tid + 256 * j;
+        if (C::W_TOTAL % 256 == 0 || p < C::W_TOTAL) dW[p] = rw[j];
+    }
+}
+
+template <int NB, int CH>
+__device__ __forceinline__ void stage_compute(const float *cA, const float *cW, int wave, int li, int lh,
+                                              f32x16 (&acc)[NB]) {
+    constexpr int C_OUT = 32 * NB;
+    const int r = wave * 32 + li;
+#pragma unroll
+    for (int g8 = 0; g8 < CH / 8; ++g8) {
+        const int q = 2 * g8 + lh;
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(cA + r * CH + 4 * (q ^ swz<CH>(r)));
+        const float *wrow = cW + (8 * g8 + 4 * lh) * C_OUT + li;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wrow[32 * nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wrow[C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wrow[2 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wrow[3 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+    }
+}
+
+template <int NB, int CH>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+    using C = MfmaCfg<NB, CH>;
+    constexpr int C_OUT = C::C_OUT;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTileRows * CH + 2 * CH * C_OUT];
+    __shared__ unsigned s_mask[4];
+    float *sA = smem;
+    float *sW = smem + 2 * kTileRows * CH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = blockIdx.y;
+    const int64_t row0 = (int64_t)tile * kTileRows;
+    const int c_in = a.c1 + a.c2;
+    const int n_chunks = c_in / CH;
+    const float *wg = a.w + (int64_t)g * a.n_off * c_in * C_OUT;
+
+    // which offsets occur in this wave's 32 rows / in the whole tile
+    unsigned wmask = 0;
+    {
+        const int64_t myrow = row0 + wave * 32 + li;
+        for (int k = 0; k < a.n_off; ++k) {
+            int32_t v = -1;
+            if (myrow < a.n_out) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + myrow * a.nbr_os] : (int32_t)myrow;
+            if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
+        }
+        if (lane == 0) s_mask[wave] = wmask;
+    }
+    __syncthreads();
+    const unsigned tmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    const int n_stages = __popc(tmask) * n_chunks;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    f32x4 ra[C::A_PIECES], rw[C::W_PIECES];
+
+    if (n_stages > 0) {
+        // stage iterator over (set bits of tmask) x chunks
+        unsigned rest = tmask;
+        int k_cur = __ffs(rest) - 1;
+        int k_next = k_cur, cc_next = 0;
+        stage_fetch<NB, CH>(a, wg, row0, c_in, tid, k_cur, 0, ra, rw);
+        stage_stash<NB, CH>(sA, sW, tid, ra, rw);
+        __syncthreads();
+        for (int s = 0; s < n_stages; ++s) {
+            if (++cc_next == n_chunks) {
+                cc_next = 0;
+                rest &= rest - 1;
+                k_next = rest ? __ffs(rest) - 1 : 0;
+            }
+            const bool more = s + 1 < n_stages;
+            if (more) stage_fetch<NB, CH>(a, wg, row0, c_in, tid, k_next, cc_next, ra, rw);
+            if ((wmask >> k_cur) & 1u)
+                stage_compute<NB, CH>(sA + (s & 1) * kTileRows * CH, sW + (s & 1) * CH * C_OUT, wave, li, lh, acc);
+            if (more) stage_stash<NB, CH>(sA + ((s + 1) & 1) * kTileRows * CH, sW + ((s + 1) & 1) * CH * C_OUT, tid, ra, rw);
+            __syncthreads();
+            k_cur = k_next;
+        }
+    }
+
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t o = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (o >= a.n_out) continue;
+        const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+        if (dst < 0) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = 32 * nb + li;
+            const float b = a.bias ? a.bias[col] : 0.0f;
+            a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// VALU path: thread = (output row, group, block of JB output channels); natural channel order.
+template <int JB>
+__global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y / n_jb, jb = blockIdx.y % n_jb;
+    if (o >= a.n_out) return;
+    const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+    if (dst < 0) return;
+    const int c_in = a.c1 + a.c2;
+    const int j0 = jb * JB;
+    const float *wg = a.w + (int64_t)g * a.n_off * c_in * a.c_out;
+
+    float acc[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) acc[j] = 0.0f;
+
+    for (int k = 0; k < a.n_off; ++k) {
+        const int32_t idx = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + o * a.nbr_os] : (int32_t)o;
+        if (idx < 0) continue;
+        const float *xr1 = a.x1 + (int64_t)idx * a.ld1;
+        const float *wk = wg + (int64_t)k * c_in * a.c_out + j0;
+        for (int c = 0; c < a.c1; ++c) {
+            const float xv = xr1[c];
+            const float *wr = wk + (int64_t)c * a.c_out;
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+                if (JB == 1 || j0 + j < a.c_out) acc[j] = fmaf(xv, wr[j], acc[j]);
+        }
+        if (a.c2 > 0) {
+            const float *xr2 = a.x2 + (int64_t)idx * a.ld2;
+            for (int c = 0; c < a.c2; ++c) {
+                const float xv = xr2[c];
+                const float *wr = wk + (int64_t)(a.c1 + c) * a.c_out;
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+                    if (JB == 1 || j0 + j < a.c_out) acc[j] = fmaf(xv, wr[j], acc[j]);
+            }
+        }
+    }
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        if (j0 + j < a.c_out) {
+            const float b = a.bias ? a.bias[j0 + j] : 0.0f;
+            a.out[dst * a.ldo + j0 + j] = finish(acc[j], b, a.act, slope, a.clip);
+        }
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 0: VALU kernel, 16 / 32: MFMA kernel with that chunk size
+int mfma_chunk(int c1, int c2, int c_out) {
+    if (c_out != 32 && c_out != 64 && c_out != 128) return 0;
+    const int c_in = c1 + c2;
+    if (c_in % 32 == 0 && c1 % 32 == 0) return 32;
+    if (c_in % 16 == 0 && c1 % 16 == 0) return 16;
+    return 0;
+}
+
+template <int NB, int CH>
+int launch_mfma(const ConvArgs &a, hipStream_t s) {
+    const unsigned tiles = (unsigned)((a.n_out + kTileRows - 1) / kTileRows);
+    hipLaunchKernelGGL((k_conv_mfma<NB, CH>), dim3(tiles, a.groups), dim3(256), 0, s, a);
+    return check_hip(hipGetLastError(), "k_conv_mfma");
+}
+
+template <int JB>
+int launch_valu(const ConvArgs &a, hipStream_t s) {
+    const int n_jb = (a.c_out + JB - 1) / JB;
+    hipLaunchKernelGGL((k_conv_valu<JB>), dim3(blocks_for(a.n_out, 256), a.groups * n_jb), dim3(256), 0, s, a, n_jb);
+    return check_hip(hipGetLastError(), "k_conv_valu");
+}
+
+}  // namespace
+}  // namespace fpcc
+
+using namespace fpcc;
+
+extern "C" int fpcc_conv_f32_order(int c1, int c2, int c_out) { return mfma_chunk(c1, c2, c_out) ? 1 : 0; }
+
+extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2, const int32_t *nbr,
+                             int n_offsets, int64_t nbr_ks, int64_t nbr_os, const float *w, const float *bias, int c_out,
+                             int groups, const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo,
+                             int64_t n_out, int act, const float *slope, float clip, void *stream) {
+    if (n_out < 0 || c1 < 1 || c2 < 0 || c_out < 1 || groups < 1 || n_offsets < 1 || n_offsets > 32)
+        return fail_arg("conv_f32: sizes out of range (n_offsets must be 1..32)");
+    if (!x1 || !w || !out || (c2 > 0 && !x2)) return fail_arg("conv_f32: null pointer");
+    if (!nbr && n_offsets != 1) return fail_arg("conv_f32: identity map needs n_offsets == 1");
+    if (ld1 < c1 || (c2 > 0 && ld2 < c2) || ldo < c_out) return fail_arg("conv_f32: row stride smaller than the row");
+    if (act != FPCC_ACT_NONE && act != FPCC_ACT_PRELU && act != FPCC_ACT_RELU) return fail_arg("conv_f32: unknown activation");
+    if (act == FPCC_ACT_PRELU && !slope) return fail_arg("conv_f32: PReLU needs a slope pointer");
+    if ((int64_t)groups * ((c_out + 15) / 16) > 65535) return fail_arg("conv_f32: too many groups");
+    if (n_out == 0) return FPCC_OK;
+
+    ConvArgs a{x1, c1, ld1, x2, c2, ld2, nbr, n_offsets, nbr_ks, nbr_os, w, bias, c_out, groups,
+               out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip};
+    hipStream_t s = as_stream(stream);
+    int ch = mfma_chunk(c1, c2, c_out);
+    if (ch && !(aligned16(x1) && ld1 % 4 == 0 && aligned16(w) && (c2 == 0 || (aligned16(x2) && ld2 % 4 == 0))))
+        return fail_arg("conv_f32: the MFMA path needs 16-byte aligned inputs and row strides that are multiples of 4");
+    if (ch == 32) {
+        if (c_out == 128) return launch_mfma<4, 32>(a, s);
+        if (c_out == 64) return launch_mfma<2, 32>(a, s);
+        return launch_mfma<1, 32>(a, s);
+    }
+    if (ch == 16) {
+        if (c_out == 128) return launch_mfma<4, 16>(a, s);
+        if (c_out == 64) return launch_mfma<2, 16>(a, s);
+        return launch_mfma<1, 16>(a, s);
+    }
+    if (c_out == 1) return launch_valu<1>(a, s);
+    if (c_out <= 4) return launch_valu<4>(a, s);
+    if (c_out <= 8) return launch_valu<8>(a, s);
+    return launch_valu<16>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row gather (features re-ordered into the canonical Morton row order of a coordinate map).
+namespace fpcc {
+namespace {
+__global__ void k_gather_rows(const float *__restrict__ x, int c, int ld, const int32_t *__restrict__ index, int64_t n,
+                              float *__restrict__ out, int ldo) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * c) return;
+    const int64_t r = e / c;
+    const int j = (int)(e - r * c);
+    out[r * ldo + j] = x[(int64_t)index[r] * ld + j];
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int fpcc_gather_rows_f32(const float *x, int c, int ld, const int32_t *index, int64_t n, float *out, int ldo,
+                                    void *stream) {
+    if (n < 0 || c < 1 || (n > 0 && (!x || !index || !out))) return fail_arg("gather_rows: null pointer or bad size");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(n * c, 256)), dim3(256), 0, as_stream(stream), x, c, ld, index, n,
+                       out, ldo);
+    return check_hip(hipGetLastError(), "k_gather_rows");
+}

@@ -1,0 +1,423 @@
+// Coordinate machinery: Morton keys, sorting, the octree-shaped pyramid of coordinate maps and the 3x3x3 kernel maps.
+//
+// Design (MI355X-first, not a port of MinkowskiEngine's or torchsparse's hash maps): every coordinate set is a SORTED
+// array of unique 64-bit Morton keys.  With x on Morton bit 0 the parent of a key is key >> 3 and its octant is key & 7,
+// which is exactly the (x fastest) kernel index of a 2x2x2 stride-2 kernel.  Hence
+//   * a stride-2 map is a run-length pass over the sorted keys (no hashing),
+//   * transposed / generative maps are the child_row table read the other way,
+//   * the 27-neighbour table of a level follows from its parent's table with two dependent, cache-friendly loads,
+//   * rows that are neighbours in space are neighbours in memory, so gathers hit L2.
+// All kernels are HBM/L2-bound integer work; they use 256-thread blocks, one element (or one parent) per thread and
+// fully coalesced streaming accesses for everything that is not a table lookup.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "common.h"
+
+namespace fpcc {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t gather21(uint64_t x) {
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffull;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffull;
+    x = (x ^ (x >> 32)) & 0x1fffffull;
+    return static_cast<uint32_t>(x);
+}
+
+__device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
+}
+
+__global__ void k_morton(const int32_t *__restrict__ c, int64_t n, int64_t ld, int a0, int a1, int a2,
+                         int64_t *__restrict__ keys) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *r = c + i * ld;
+    keys[i] = static_cast<int64_t>(morton3((uint32_t)r[a0], (uint32_t)r[a1], (uint32_t)r[a2]));
+}
+
+__global__ void k_keys_from_coords(const int4 *__restrict__ c, int64_t n, int level, int bits, int64_t *__restrict__ keys) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 v = c[i];   // (batch, x, y, z): one 16-byte load per row
+    uint64_t m = morton3((uint32_t)(v.y >> level), (uint32_t)(v.z >> level), (uint32_t)(v.w >> level));
+    keys[i] = static_cast<int64_t>(((uint64_t)(uint32_t)v.x << (3 * bits)) | m);
+}
+
+__global__ void k_coords_from_keys(const int64_t *__restrict__ keys, int64_t n, int level, int bits,
+                                   const int32_t *__restrict__ off, int4 *__restrict__ out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = (uint64_t)keys[i];
+    uint64_t m = k & ((1ull << (3 * bits)) - 1ull);
+    int4 v;
+    v.x = (int32_t)(k >> (3 * bits));
+    v.y = (int32_t)(gather21(m) << level);
+    v.z = (int32_t)(gather21(m >> 1) << level);
+    v.w = (int32_t)(gather21(m >> 2) << level);
+    if (off) { v.y += off[0]; v.z += off[1]; v.w += off[2]; }
+    out[i] = v;
+}
+
+__global__ void k_iota(int32_t *p, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
+// flag[i] = 1 where a new group (keys >> shift differs from the predecessor) starts
+__global__ void k_head_flags(const int64_t *__restrict__ keys, int64_t n, int shift, int32_t *__restrict__ flag) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1 : 0;
+}
+
+__global__ void k_unique_scatter(const int64_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ flag,
+                                 const int32_t *__restrict__ pos, int64_t *__restrict__ ukeys,
+                                 int32_t *__restrict__ first, int32_t *__restrict__ count) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        int32_t u = pos[i] - 1;
+        ukeys[u] = keys[i];
+        first[u] = (int32_t)i;
+    }
+    if (i == n - 1) count[0] = pos[i];
+}
+
+__global__ void k_coarsen_scatter(const int64_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ flag,
+                                  const int32_t *__restrict__ pos, int32_t *__restrict__ parent_of,
+                                  int64_t *__restrict__ pkeys, int32_t *__restrict__ child_row,
+                                  int32_t *__restrict__ count) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = pos[i] - 1;
+    parent_of[i] = p;
+    if (flag[i]) {
+        // first child of its parent: siblings are the following rows (at most 8, sorted by octant)
+        const int64_t pk = keys[i] >> 3;
+        int32_t rows[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rows[k] = -1;
+        for (int64_t j = i; j < n && j < i + 8; ++j) {
+            const int64_t kj = keys[j];
+            if ((kj >> 3) != pk) break;
+            const int oct = (int)(kj & 7);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k == oct) rows[k] = (int32_t)j;   // static indexing keeps rows[] in registers
+        }
+        pkeys[p] = pk;
+        int4 *dst = reinterpret_cast<int4 *>(child_row + (int64_t)p * 8);
+        dst[0] = make_int4(rows[0], rows[1], rows[2], rows[3]);
+        dst[1] = make_int4(rows[4], rows[5], rows[6], rows[7]);
+    }
+    if (i == n - 1) count[0] = pos[i];
+}
+
+struct ByteToInt {
+    __host__ __device__ int32_t operator()(uint8_t b) const { return b ? 1 : 0; }
+};
+
+__global__ void k_refine_scatter(const int64_t *__restrict__ pkeys, int64_t n_cand, const uint8_t *__restrict__ mask,
+                                 const int32_t *__restrict__ pos, int64_t *__restrict__ keys_out,
+                                 int32_t *__restrict__ parent_of, int32_t *__restrict__ child_row,
+                                 int32_t *__restrict__ count) {
+    int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    int32_t row = -1;
+    if (mask[c]) {
+        row = pos[c] - 1;
+        keys_out[row] = (pkeys[c >> 3] << 3) | (c & 7);
+        parent_of[row] = (int32_t)(c >> 3);
+    }
+    child_row[c] = row;
+    if (c == n_cand - 1) count[0] = pos[c];
+}
+
+__global__ void k_compact_coords(const int64_t *__restrict__ pkeys, int64_t n_cand, const uint8_t *__restrict__ mask,
+                                 const int32_t *__restrict__ pos, int level, int bits, const int32_t *__restrict__ off,
+                                 int32_t *__restrict__ xyz, int32_t *__restrict__ count) {
+    int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    if (mask[c]) {
+        const uint64_t k = ((uint64_t)pkeys[c >> 3] << 3) | (uint64_t)(c & 7);
+        const uint64_t m = k & ((1ull << (3 * bits)) - 1ull);
+        int32_t *o = xyz + (int64_t)(pos[c] - 1) * 3;
+        o[0] = (int32_t)(gather21(m) << level) + (off ? off[0] : 0);
+        o[1] = (int32_t)(gather21(m >> 1) << level) + (off ? off[1] : 0);
+        o[2] = (int32_t)(gather21(m >> 2) << level) + (off ? off[2] : 0);
+    }
+    if (c == n_cand - 1) count[0] = pos[c];
+}
+
+// offset d = (dx+1) + 3*(dy+1) + 9*(dz+1), x fastest, centred: MinkowskiEngine's HYPER_CUBE enumeration for odd sizes
+__global__ void k_nbr27_search(const int64_t *__restrict__ keys, int64_t n, int bits, int32_t *__restrict__ nbr) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = (uint64_t)keys[i];
+    const uint64_t mmask = (1ull << (3 * bits)) - 1ull;
+    const uint64_t batch = k & ~mmask;
+    const uint64_t m = k & mmask;
+    const int32_t x = (int32_t)gather21(m), y = (int32_t)gather21(m >> 1), z = (int32_t)gather21(m >> 2);
+    const int32_t lim = 1 << bits;
+    for (int d = 0; d < 27; ++d) {
+        const int32_t nx = x + (d % 3) - 1, ny = y + (d / 3) % 3 - 1, nz = z + d / 9 - 1;
+        int32_t found = -1;
+        if (d == 13) {
+            found = (int32_t)i;
+        } else if (nx >= 0 && ny >= 0 && nz >= 0 && nx < lim && ny < lim && nz < lim) {
+            const int64_t want = (int64_t)(batch | morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+            int64_t lo = 0, hi = n;   // first index with keys[idx] >= want
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n && keys[lo] == want) found = (int32_t)lo;
+        }
+        nbr[(int64_t)d * n + i] = found;
+    }
+}
+
+__global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
+                                    const int32_t *__restrict__ pnbr, int64_t m, const int32_t *__restrict__ child_row,
+                                    int32_t *__restrict__ nbr) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int oct = keys ? (int)(keys[i] & 7) : (int)(i & 7);   // keys == NULL: generated set, row = 8*parent + octant
+    const int ox = oct & 1, oy = (oct >> 1) & 1, oz = oct >> 2;
+    const int32_t p = parent_of ? parent_of[i] : (int32_t)(i >> 3);
+    for (int d = 0; d < 27; ++d) {
+        const int tx = ox + (d % 3) - 1, ty = oy + (d / 3) % 3 - 1, tz = oz + d / 9 - 1;   // in {-1,0,1,2}
+        // parent offset floor(t/2) in {-1,0,1}; child octant t mod 2
+        const int px = (tx + 2) / 2 - 1, py = (ty + 2) / 2 - 1, pz = (tz + 2) / 2 - 1;
+        const int co = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
+        const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
+        int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
+        int32_t found = -1;
+        if (q >= 0) found = child_row ? child_row[(int64_t)q * 8 + co] : q * 8 + co;
+        nbr[(int64_t)d * n + i] = found;
+    }
+}
+
+template <typename InIt>
+int64_t scan_bytes(InIt in, int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, in, (int32_t *)nullptr, (size_t)n, rocprim::plus<int32_t>());
+    return (int64_t)bytes;
+}
+
+}  // namespace
+}  // namespace fpcc
+
+using namespace fpcc;
+
+extern "C" int fpcc_morton3d_encode(const int32_t *coords, int64_t n, int64_t row_stride, int col_bit0, int col_bit1,
+                                    int col_bit2, int64_t *keys_out, void *stream) {
+    if (n < 0 || (n > 0 && (!coords || !keys_out))) return fail_arg("morton3d_encode: null pointer");
+    if (col_bit0 < 0 || col_bit1 < 0 || col_bit2 < 0 || col_bit0 >= row_stride || col_bit1 >= row_stride ||
+        col_bit2 >= row_stride)
+        return fail_arg("morton3d_encode: column outside the row");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_morton, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), coords, n,
+                       row_stride, col_bit0, col_bit1, col_bit2, keys_out);
+    FPCC_LAUNCHED(k_morton);
+    return FPCC_OK;
+}
+
+static int check_bits(int level, int bits) {
+    if (level < 0 || level > 21 || bits < 1 || bits > 21) return fail_arg("level must be in [0,21], bits in [1,21]");
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_keys_from_coords(const int32_t *coords, int64_t n, int level, int bits, int64_t *keys_out,
+                                     void *stream) {
+    if (int rc = check_bits(level, bits)) return rc;
+    if (n < 0 || (n > 0 && (!coords || !keys_out))) return fail_arg("keys_from_coords: null pointer");
+    if ((reinterpret_cast<uintptr_t>(coords) & 15) != 0) return fail_arg("keys_from_coords: coords must be 16-byte aligned");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_keys_from_coords, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const int4 *>(coords), n, level, bits, keys_out);
+    FPCC_LAUNCHED(k_keys_from_coords);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_coords_from_keys(const int64_t *keys, int64_t n, int level, int bits, const int32_t *offset_xyz,
+                                     int32_t *coords_out, void *stream) {
+    if (int rc = check_bits(level, bits)) return rc;
+    if (n < 0 || (n > 0 && (!keys || !coords_out))) return fail_arg("coords_from_keys: null pointer");
+    if ((reinterpret_cast<uintptr_t>(coords_out) & 15) != 0) return fail_arg("coords_from_keys: output must be 16-byte aligned");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_coords_from_keys, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
+                       level, bits, offset_xyz, reinterpret_cast<int4 *>(coords_out));
+    FPCC_LAUNCHED(k_coords_from_keys);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_sort_keys(const int64_t *keys_in, int64_t n, int end_bit, int64_t *keys_out, int32_t *perm_out,
+                                  void *ws, int64_t ws_bytes, void *stream) {
+    if (n < 0 || end_bit < 1 || end_bit > 64) return fail_arg("sort_keys: bad n or end_bit");
+    size_t sort_bytes = 0;
+    // keys are non-negative (bit 63 clear), so an unsigned sort of the low end_bit bits is an ordinary ascending sort
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)(n > 0 ? n : 1), 0u,
+                                             (unsigned)end_bit);
+    if (e != hipSuccess) return check_hip(e, "radix_sort_pairs(size query)");
+    const int64_t iota_bytes = align_up(4 * (n > 0 ? n : 1), 256);
+    const int64_t need = iota_bytes + align_up((int64_t)sort_bytes, 256);
+    if (!ws) return need;
+    if (ws_bytes < need) { set_error("sort_keys: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
+    if (n == 0) return FPCC_OK;
+    if (!keys_in || !keys_out || !perm_out) return fail_arg("sort_keys: null pointer");
+    int32_t *iota = static_cast<int32_t *>(ws);
+    void *tmp = static_cast<char *>(ws) + iota_bytes;
+    hipLaunchKernelGGL(k_iota, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), iota, n);
+    FPCC_LAUNCHED(k_iota);
+    FPCC_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint64_t *>(keys_in),
+                                       reinterpret_cast<uint64_t *>(keys_out), (const int32_t *)iota, perm_out,
+                                       (size_t)n, 0u, (unsigned)end_bit, as_stream(stream)));
+    return FPCC_OK;
+}
+
+// shared body of unique / coarsen: head flags on keys >> shift, inclusive scan
+static int64_t flags_and_scan(const int64_t *keys, int64_t n, int shift, void *ws, int64_t ws_bytes, void *stream,
+                              int32_t **flag_out, int32_t **pos_out, const char *who) {
+    const int64_t nn = n > 0 ? n : 1;
+    const int64_t arr = align_up(4 * nn, 256);
+    const int64_t tmp_bytes = align_up(scan_bytes((const int32_t *)nullptr, nn), 256);
+    const int64_t need = 2 * arr + tmp_bytes;
+    if (!ws) return need;
+    if (ws_bytes < need) { set_error("%s: workspace %lld < %lld", who, (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
+    int32_t *flag = static_cast<int32_t *>(ws);
+    int32_t *pos = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + arr);
+    void *tmp = static_cast<char *>(ws) + 2 * arr;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_head_flags, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
+                           shift, flag);
+        FPCC_LAUNCHED(k_head_flags);
+        size_t tb = (size_t)tmp_bytes;
+        FPCC_HIP(rocprim::inclusive_scan(tmp, tb, (const int32_t *)flag, pos, (size_t)n, rocprim::plus<int32_t>(),
+                                         as_stream(stream)));
+    }
+    *flag_out = flag;
+    *pos_out = pos;
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_unique_keys(const int64_t *keys, int64_t n, int64_t *ukeys_out, int32_t *first_out,
+                                    int32_t *count_out, void *ws, int64_t ws_bytes, void *stream) {
+    if (n < 0) return fail_arg("unique_keys: n < 0");
+    int32_t *flag = nullptr, *pos = nullptr;
+    if (ws && n > 0 && (!keys || !ukeys_out || !first_out || !count_out)) return fail_arg("unique_keys: null pointer");
+    int64_t rc = flags_and_scan(keys, n, 0, ws, ws_bytes, stream, &flag, &pos, "unique_keys");
+    if (!ws || rc != FPCC_OK) return rc;
+    if (n == 0) { FPCC_HIP(hipMemsetAsync(count_out, 0, 4, as_stream(stream))); return FPCC_OK; }
+    hipLaunchKernelGGL(k_unique_scatter, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
+                       (const int32_t *)flag, (const int32_t *)pos, ukeys_out, first_out, count_out);
+    FPCC_LAUNCHED(k_unique_scatter);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_of, int64_t *pkeys, int32_t *child_row,
+                                int32_t *count_out, void *ws, int64_t ws_bytes, void *stream) {
+    if (n < 0) return fail_arg("coarsen: n < 0");
+    int32_t *flag = nullptr, *pos = nullptr;
+    if (ws && n > 0 && (!keys || !parent_of || !pkeys || !child_row || !count_out)) return fail_arg("coarsen: null pointer");
+    if (ws && (reinterpret_cast<uintptr_t>(child_row) & 15) != 0) return fail_arg("coarsen: child_row must be 16-byte aligned");
+    int64_t rc = flags_and_scan(keys, n, 3, ws, ws_bytes, stream, &flag, &pos, "coarsen");
+    if (!ws || rc != FPCC_OK) return rc;
+    if (n == 0) { FPCC_HIP(hipMemsetAsync(count_out, 0, 4, as_stream(stream))); return FPCC_OK; }
+    hipLaunchKernelGGL(k_coarsen_scatter, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
+                       (const int32_t *)flag, (const int32_t *)pos, parent_of, pkeys, child_row, count_out);
+    FPCC_LAUNCHED(k_coarsen_scatter);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_t *keys_out,
+                               int32_t *parent_of, int32_t *child_row, int32_t *count_out, void *ws, int64_t ws_bytes,
+                               void *stream) {
+    if (m < 0) return fail_arg("refine: m < 0");
+    const int64_t n_cand = 8 * m;
+    const int64_t nn = n_cand > 0 ? n_cand : 1;
+    auto in = rocprim::make_transform_iterator(mask, ByteToInt());
+    const int64_t arr = align_up(4 * nn, 256);
+    const int64_t tmp_bytes = align_up(scan_bytes(in, nn), 256);
+    const int64_t need = arr + tmp_bytes;
+    if (!ws) return need;
+    if (ws_bytes < need) { set_error("refine: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
+    if (m == 0) { FPCC_HIP(hipMemsetAsync(count_out, 0, 4, as_stream(stream))); return FPCC_OK; }
+    if (!pkeys || !mask || !keys_out || !parent_of || !child_row || !count_out) return fail_arg("refine: null pointer");
+    int32_t *pos = static_cast<int32_t *>(ws);
+    void *tmp = static_cast<char *>(ws) + arr;
+    size_t tb = (size_t)tmp_bytes;
+    FPCC_HIP(rocprim::inclusive_scan(tmp, tb, in, pos, (size_t)n_cand, rocprim::plus<int32_t>(), as_stream(stream)));
+    hipLaunchKernelGGL(k_refine_scatter, dim3(blocks_for(n_cand, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
+                       n_cand, mask, (const int32_t *)pos, keys_out, parent_of, child_row, count_out);
+    FPCC_LAUNCHED(k_refine_scatter);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_nbr27_search(const int64_t *keys, int64_t n, int bits, int32_t *nbr, void *stream) {
+    if (bits < 1 || bits > 21) return fail_arg("nbr27_search: bits must be in [1,21]");
+    if (n < 0 || (n > 0 && (!keys || !nbr))) return fail_arg("nbr27_search: null pointer");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_nbr27_search, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n, bits,
+                       nbr);
+    FPCC_LAUNCHED(k_nbr27_search);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n,
+                                      const int32_t *parent_nbr, int64_t m, const int32_t *child_row, int32_t *nbr,
+                                      void *stream) {
+    if (n < 0 || m < 0 || (n > 0 && (!parent_nbr || !nbr))) return fail_arg("nbr27_from_parent: null pointer");
+    if (!keys && (parent_of || child_row)) return fail_arg("nbr27_from_parent: keys may only be omitted for a full generated set");
+    if (!parent_of && !(child_row == nullptr && n == 8 * m))
+        return fail_arg("nbr27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_nbr27_from_parent, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+                       parent_of, n, parent_nbr, m, child_row, nbr);
+    FPCC_LAUNCHED(k_nbr27_from_parent);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_compact_coords(const int64_t *pkeys, int64_t m, const uint8_t *mask, int level, int bits,
+                                       const int32_t *offset_xyz, int32_t *xyz_out, int32_t *count_out, void *ws,
+                                       int64_t ws_bytes, void *stream) {
+    if (m < 0) return fail_arg("compact_coords: m < 0");
+    if (int rc = check_bits(level, bits)) return rc;
+    const int64_t n_cand = 8 * m;
+    const int64_t nn = n_cand > 0 ? n_cand : 1;
+    auto in = rocprim::make_transform_iterator(mask, ByteToInt());
+    const int64_t arr = align_up(4 * nn, 256);
+    const int64_t tmp_bytes = align_up(scan_bytes(in, nn), 256);
+    const int64_t need = arr + tmp_bytes;
+    if (!ws) return need;
+    if (ws_bytes < need) { set_error("compact_coords: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
+    if (m == 0) { FPCC_HIP(hipMemsetAsync(count_out, 0, 4, as_stream(stream))); return FPCC_OK; }
+    if (!pkeys || !mask || !xyz_out || !count_out) return fail_arg("compact_coords: null pointer");
+    int32_t *pos = static_cast<int32_t *>(ws);
+    void *tmp = static_cast<char *>(ws) + arr;
+    size_t tb = (size_t)tmp_bytes;
+    FPCC_HIP(rocprim::inclusive_scan(tmp, tb, in, pos, (size_t)n_cand, rocprim::plus<int32_t>(), as_stream(stream)));
+    hipLaunchKernelGGL(k_compact_coords, dim3(blocks_for(n_cand, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
+                       n_cand, mask, (const int32_t *)pos, level, bits, offset_xyz, xyz_out, count_out);
+    FPCC_LAUNCHED(k_compact_coords);
+    return FPCC_OK;
+}

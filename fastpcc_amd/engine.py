@@ -1,0 +1,594 @@
+"""Sparse-tensor engine with the names the reference's model code uses from MinkowskiEngine
+(`ME.SparseTensor`, `ME.CoordinateManager`, `ME.CoordinateMapKey`, `ME.cat`, `ME.Minkowski*` modules; call sites listed in
+SURVEY.md section 8b), backed by libfpcc_hip.so.
+
+This is not MinkowskiEngine's design.  A coordinate map is a SORTED array of unique Morton keys (x on bit 0) living in a
+pyramid: the stride-2 parent of a key is key >> 3, its octant key & 7.  Consequences used throughout:
+  * row order of every map is Morton order -- the invariant the codec's bitstream needs
+    (/root/reference/models/convolutional/lossy_coord_v2/model.py:121-123,141-142);
+  * stride-2 / transposed / generative maps are one `child_row` table [parents, 8];
+  * the 3x3x3 kernel map of a level is derived from its parent's (no hash table).
+Convolutions are output-stationary (gather -> MFMA GEMM), with bias, activation and channel concatenation fused.
+
+Inference only: modules hold ordinary nn.Parameters (state_dict keys equal the reference's) but define no backward.
+"""
+import math
+from enum import Enum
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import hipops as ops
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# enums kept for source compatibility with the reference's call sites
+class RegionType(Enum):
+    HYPER_CUBE = 0
+    HYPER_CROSS = 1
+    CUSTOM = 2
+
+
+class MinkowskiAlgorithm(Enum):
+    DEFAULT = 0
+    MEMORY_EFFICIENT = 1
+    SPEED_OPTIMIZED = 2
+
+
+class CoordinateMapType(Enum):
+    CPU = 0
+    CUDA = 1
+
+
+class SparseTensorQuantizationMode(Enum):
+    RANDOM_SUBSAMPLE = 0
+    UNWEIGHTED_AVERAGE = 1
+    UNWEIGHTED_SUM = 2
+    NO_QUANTIZATION = 3
+
+
+class SparseTensorOperationMode(Enum):
+    SEPARATE_COORDINATE_MANAGER = 0
+    SHARE_COORDINATE_MANAGER = 1
+
+
+_global_cm: Optional['CoordinateManager'] = None
+_operation_mode = SparseTensorOperationMode.SEPARATE_COORDINATE_MANAGER
+
+
+def set_sparse_tensor_operation_mode(mode: SparseTensorOperationMode):
+    global _operation_mode
+    _operation_mode = mode
+
+
+def set_global_coordinate_manager(cm: 'CoordinateManager'):
+    global _global_cm
+    _global_cm = cm
+
+
+def clear_global_coordinate_manager():
+    global _global_cm
+    _global_cm = None
+
+
+def global_coordinate_manager() -> Optional['CoordinateManager']:
+    return _global_cm
+
+
+def _as_stride(s) -> Tuple[int, int, int]:
+    if isinstance(s, int):
+        return (s, s, s)
+    s = tuple(int(v) for v in s)
+    if len(s) == 1:
+        s = s * 3
+    if len(s) != 3 or len(set(s)) != 1 or s[0] < 1 or s[0] & (s[0] - 1):
+        raise NotImplementedError(f'only isotropic power-of-two tensor strides are supported, got {s}')
+    return s
+
+
+class CoordinateMapKey:
+    def __init__(self, tensor_stride, string_id: str = ''):
+        self._stride = _as_stride(tensor_stride)
+        self._id = string_id
+
+    def get_tensor_stride(self) -> List[int]:
+        return list(self._stride)
+
+    def get_key(self):
+        return list(self._stride), self._id
+
+    def __eq__(self, other):
+        return isinstance(other, CoordinateMapKey) and self._stride == other._stride and self._id == other._id
+
+    def __hash__(self):
+        return hash((self._stride, self._id))
+
+    def __repr__(self):
+        return f'CoordinateMapKey(stride={list(self._stride)}, id={self._id!r})'
+
+
+class KernelGenerator:
+    def __init__(self, kernel_size=-1, stride=1, dilation=1, region_type: RegionType = RegionType.HYPER_CUBE,
+                 dimension: int = 3, **_):
+        if dimension != 3:
+            raise NotImplementedError('3-D only')
+        if region_type not in (RegionType.HYPER_CUBE, 'HYPER_CUBE'):
+            raise NotImplementedError('only HYPER_CUBE kernels')
+        as3 = lambda v: [v] * 3 if isinstance(v, int) else list(v)
+        self.kernel_size, self.kernel_stride, self.kernel_dilation = as3(kernel_size), as3(stride), as3(dilation)
+        self.region_type = region_type
+        self.dimension = dimension
+        self.kernel_volume = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _Map:
+    """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
+    __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
+                 'gen_child', 'key')
+
+    def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
+        self.level, self.bits, self.n, self.keys = level, bits, n, keys
+        self.parent: Optional['_Map'] = None
+        self.parent_of: Optional[torch.Tensor] = None     # [n] row of the parent
+        self.child_row: Optional[torch.Tensor] = None     # [parent.n, 8] row of (parent, octant) in THIS map or -1
+        self.generated = False                            # all 8 children of every parent row, row = 8p + octant
+        self.nbr27: Optional[torch.Tensor] = None
+        self.coords: Optional[torch.Tensor] = None
+        self.gen_child: Optional['_Map'] = None
+        self.key: Optional[CoordinateMapKey] = None
+
+
+class CoordinateManager:
+    """Owns the pyramid of coordinate maps of one batch of clouds."""
+    # below this many rows the top level's 27-neighbour table is found by binary search instead of climbing further
+    ROOT_ROWS = 2048
+
+    def __init__(self, D: int = 3, coordinate_map_type=None, minkowski_algorithm=None, bits: Optional[int] = None):
+        if D != 3:
+            raise NotImplementedError('3-D only')
+        self._maps: Dict[CoordinateMapKey, _Map] = {}
+        self._bits0 = bits            # bits per axis at level 0; fixed on the first insertion
+        self._manager = self          # the reference reaches into `coordinate_manager._manager`
+        self._n_batch: Optional[int] = None
+        self.device = None
+
+    # -- key bookkeeping --------------------------------------------------------------------------------------------
+    def _register(self, m: _Map, string_id: str = '') -> CoordinateMapKey:
+        key = CoordinateMapKey(1 << m.level, string_id)
+        n = 0
+        while key in self._maps and self._maps[key] is not m:
+            n += 1
+            key = CoordinateMapKey(1 << m.level, f'{string_id}#{n}')
+        self._maps[key] = m
+        if m.key is None:
+            m.key = key
+        return key
+
+    def _map(self, key: CoordinateMapKey) -> _Map:
+        try:
+            return self._maps[key]
+        except KeyError:
+            raise KeyError(f'{key} is not in this coordinate manager') from None
+
+    def get_coordinate_map_keys(self, tensor_stride) -> List[CoordinateMapKey]:
+        s = _as_stride(tensor_stride)
+        return [k for k in self._maps if k._stride == s]
+
+    # -- creation ---------------------------------------------------------------------------------------------------
+    def insert_and_map(self, coordinates: torch.Tensor, tensor_stride=1, string_id: str = ''):
+        """coordinates int32 [n, 4] = (batch, x, y, z), multiples of the stride.  Returns (key, (perm, count)) where
+        perm[i] is the input row that became map row i (duplicates: first occurrence in sorted order)."""
+        stride = _as_stride(tensor_stride)
+        level = stride[0].bit_length() - 1
+        if coordinates.dtype != torch.int32 or coordinates.dim() != 2 or coordinates.shape[1] != 4:
+            raise TypeError('coordinates must be int32 [n, 4] = (batch, x, y, z)')
+        coordinates = coordinates.contiguous()
+        self.device = coordinates.device
+        if self._bits0 is None:
+            nb = int(coordinates[:, 0].max().item()) + 1 if coordinates.shape[0] else 1
+            self._n_batch = nb
+            self._bits0 = min(21, (63 - max(nb - 1, 0).bit_length()) // 3)
+        bits = self._bits0 - level
+        if bits < 1:
+            raise ValueError('tensor stride exceeds the coordinate range')
+        keys = ops.keys_from_coords(coordinates, level, bits)
+        skeys, perm = ops.sort_keys(keys, 63)
+        ukeys, first, count = ops.unique_keys(skeys)
+        n = int(count.item())
+        m = _Map(level, bits, n, ukeys[:n])
+        rows = perm if n == coordinates.shape[0] else perm[first[:n].long()]
+        key = self._register(m, string_id)
+        return key, (rows, n)
+
+    def _ensure_parent(self, m: _Map) -> _Map:
+        if m.parent is None:
+            if m.bits <= 1:
+                raise ValueError('cannot stride past the coordinate range')
+            parent_of, pkeys, child_row, count = ops.coarsen(self._keys(m))
+            cnt = int(count.item())
+            p = _Map(m.level + 1, m.bits - 1, cnt, pkeys[:cnt])
+            m.parent, m.parent_of, m.child_row = p, parent_of, child_row[:cnt]
+            self._register(p, '')
+        return m.parent
+
+    def stride(self, key: CoordinateMapKey, stride) -> CoordinateMapKey:
+        """Key of the map `stride` times coarser (ME: cm.stride)."""
+        s = _as_stride(stride)[0]
+        m = self._map(key)
+        while s > 1:
+            m = self._ensure_parent(m)
+            s >>= 1
+        return m.key
+
+    def _generated(self, m: _Map) -> _Map:
+        """The set of all 8 children of every row of m (output map of a generative transposed convolution)."""
+        if m.gen_child is None:
+            if m.level < 1:
+                raise ValueError('cannot upsample below tensor stride 1')
+            g = _Map(m.level - 1, m.bits + 1, 8 * m.n, None)
+            g.parent, g.generated = m, True
+            m.gen_child = g
+            self._register(g, 'gen')
+        return m.gen_child
+
+    def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str) -> _Map:
+        """New map = children of `parent` selected by mask[8 * parent.n] (decoder side / pruning of a generated set)."""
+        keys, parent_of, child_row, count = ops.refine(parent.keys, mask)
+        n = int(count.item())
+        t = _Map(parent.level - 1, parent.bits + 1, n, keys[:n])
+        t.parent, t.parent_of, t.child_row = parent, parent_of[:n], child_row
+        self._register(t, string_id)
+        return t
+
+    # -- queries ----------------------------------------------------------------------------------------------------
+    def _keys(self, m: _Map) -> torch.Tensor:
+        if m.keys is None:      # generated set: materialise lazily
+            p = m.parent.keys
+            m.keys = ((p << 3).unsqueeze(1) + torch.arange(8, device=p.device, dtype=torch.int64)).reshape(-1)
+        return m.keys
+
+    def _nbr27(self, m: _Map) -> torch.Tensor:
+        """[27, n] int32 input row per (offset, output row) of the 3x3x3 kernel on m, offsets x fastest, -1 = absent."""
+        if m.nbr27 is None:
+            if m.generated:
+                m.nbr27 = ops.nbr27_from_parent(None, None, self._nbr27(m.parent), None, n=m.n)
+            else:
+                if m.parent is None and m.n > self.ROOT_ROWS and m.bits > 1:
+                    self._ensure_parent(m)
+                if m.parent is not None:
+                    m.nbr27 = ops.nbr27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+                else:
+                    m.nbr27 = ops.nbr27_search(m.keys, m.bits)
+        return m.nbr27
+
+    def get_coordinates(self, key: CoordinateMapKey) -> torch.Tensor:
+        m = self._map(key)
+        if m.coords is None:
+            m.coords = ops.coords_from_keys(self._keys(m), m.level, m.bits)
+        return m.coords
+
+    def kernel_map(self, in_key: CoordinateMapKey, out_key: CoordinateMapKey, stride=1, kernel_size=1, **_):
+        """Only the kernel_size == 1 form the reference uses (membership of `in` rows in `out`):
+        {0: int64 [2, L]} with row 0 = input rows, row 1 = output rows."""
+        ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        if ks != 1:
+            raise NotImplementedError('kernel_map is only provided for kernel_size == 1')
+        a, b = self._map(in_key), self._map(out_key)
+        if a.level != b.level:
+            raise NotImplementedError('kernel_map(kernel_size=1) needs maps of equal stride')
+        ka, kb = self._keys(a), self._keys(b)
+        if kb.numel() == 0 or ka.numel() == 0:
+            return {}
+        pos = torch.searchsorted(kb, ka).clamp_(max=kb.numel() - 1)
+        hit = kb[pos] == ka
+        rows_in = torch.nonzero(hit).squeeze(1)
+        return {0: torch.stack((rows_in, pos[hit]))}
+
+    def batch_offsets(self, m: _Map) -> List[int]:
+        """Row ranges of the samples of a batch (rows are batch-major)."""
+        if m.n == 0:
+            return [0]
+        if self._n_batch == 1:
+            return [0, m.n]
+        b = (self._keys(m) >> (3 * m.bits))
+        nb = int(b[-1].item()) + 1
+        edges = torch.searchsorted(b, torch.arange(nb + 1, device=b.device, dtype=b.dtype))
+        return edges.tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class SparseTensor:
+    """Features [n, C] on a coordinate map.  `features` rows follow the map's (Morton) row order."""
+
+    def __init__(self, features: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]], coordinates=None,
+                 tensor_stride=1, coordinate_map_key: Optional[CoordinateMapKey] = None,
+                 coordinate_manager: Optional[CoordinateManager] = None,
+                 quantization_mode: SparseTensorQuantizationMode = SparseTensorQuantizationMode.RANDOM_SUBSAMPLE,
+                 **_):
+        if coordinate_manager is None:
+            coordinate_manager = _global_cm
+            if coordinate_manager is None:
+                coordinate_manager = CoordinateManager()
+                if _operation_mode == SparseTensorOperationMode.SHARE_COORDINATE_MANAGER:
+                    set_global_coordinate_manager(coordinate_manager)
+        self.coordinate_manager = coordinate_manager
+        if coordinates is not None:
+            if coordinate_map_key is not None:
+                raise ValueError('give coordinates or a coordinate_map_key, not both')
+            key, (rows, n) = coordinate_manager.insert_and_map(coordinates, tensor_stride)
+            if n != coordinates.shape[0] and quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
+                features = _average_duplicates(features, coordinate_manager, key, coordinates, tensor_stride)
+            else:
+                features = ops.gather_rows(features.contiguous(), rows.contiguous())
+            coordinate_map_key = key
+        elif coordinate_map_key is None:
+            raise ValueError('coordinates or coordinate_map_key required')
+        self.coordinate_map_key = coordinate_map_key
+        self._parts = features if isinstance(features, tuple) else (features,)
+        n_rows = coordinate_manager._map(coordinate_map_key).n
+        for f in self._parts:
+            if f.shape[0] != n_rows:
+                raise ValueError(f'features have {f.shape[0]} rows, the coordinate map {n_rows}')
+
+    # features ------------------------------------------------------------------------------------------------------
+    @property
+    def F(self) -> torch.Tensor:
+        if len(self._parts) > 1:
+            self._parts = (torch.cat(self._parts, dim=1),)
+        return self._parts[0]
+
+    @property
+    def parts(self) -> Tuple[torch.Tensor, ...]:
+        return self._parts
+
+    @property
+    def C(self) -> torch.Tensor:
+        return self.coordinate_manager.get_coordinates(self.coordinate_map_key)
+
+    @property
+    def tensor_stride(self) -> List[int]:
+        return self.coordinate_map_key.get_tensor_stride()
+
+    @property
+    def shape(self):
+        return torch.Size((self._parts[0].shape[0], sum(p.shape[1] for p in self._parts)))
+
+    @property
+    def device(self):
+        return self._parts[0].device
+
+    @property
+    def dtype(self):
+        return self._parts[0].dtype
+
+    def size(self):
+        return self.shape
+
+    # batch decomposition -------------------------------------------------------------------------------------------
+    @property
+    def _batchwise_row_indices(self):
+        edges = self.coordinate_manager.batch_offsets(self.coordinate_manager._map(self.coordinate_map_key))
+        return [torch.arange(a, b, device=self.device) for a, b in zip(edges[:-1], edges[1:])]
+
+    @property
+    def decomposition_permutations(self):
+        return self._batchwise_row_indices
+
+    @property
+    def decomposed_coordinates(self):
+        c = self.C
+        return [c[idx, 1:] for idx in self._batchwise_row_indices]
+
+    def __repr__(self):
+        return f'SparseTensor(shape={tuple(self.shape)}, key={self.coordinate_map_key})'
+
+
+def _average_duplicates(features, cm, key, coordinates, tensor_stride):
+    # rare path (inputs of the codec are unique): average the features of equal coordinates with torch ops
+    m = cm._map(key)
+    level = m.level
+    keys = ops.keys_from_coords(coordinates.contiguous(), level, m.bits)
+    row = torch.searchsorted(m.keys, keys)
+    out = torch.zeros((m.n, features.shape[1]), dtype=features.dtype, device=features.device)
+    cnt = torch.zeros((m.n, 1), dtype=features.dtype, device=features.device)
+    out.index_add_(0, row, features)
+    cnt.index_add_(0, row, torch.ones_like(features[:, :1]))
+    return out / cnt
+
+
+def cat(*tensors) -> SparseTensor:
+    """Channel concatenation on one coordinate map (ME.cat).  Lazy: a following convolution reads both sources."""
+    if len(tensors) == 1 and isinstance(tensors[0], (tuple, list)):
+        tensors = tuple(tensors[0])
+    key, cm = tensors[0].coordinate_map_key, tensors[0].coordinate_manager
+    parts = []
+    for t in tensors:
+        if t.coordinate_manager is not cm or cm._map(t.coordinate_map_key) is not cm._map(key):
+            raise ValueError('cat needs tensors on the same coordinate map')
+        parts.extend(t.parts)
+    if len(parts) > 2:
+        parts = [torch.cat(parts[:-1], dim=1), parts[-1]]
+    return SparseTensor(tuple(parts), coordinate_map_key=key, coordinate_manager=cm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# modules
+class _Act:
+    """What a convolution may fuse after its bias."""
+    __slots__ = ('kind', 'slope')
+
+    def __init__(self, kind=ops.ACT_NONE, slope=None):
+        self.kind, self.slope = kind, slope
+
+
+def _act_of(module: Optional[nn.Module]) -> _Act:
+    if module is None:
+        return _Act()
+    if isinstance(module, MinkowskiPReLU):
+        if module.module.weight.numel() != 1:
+            raise NotImplementedError('per-channel PReLU')
+        return _Act(ops.ACT_PRELU, module.module.weight.detach())
+    if isinstance(module, MinkowskiReLU):
+        return _Act(ops.ACT_RELU)
+    raise NotImplementedError(f'cannot fuse {type(module).__name__}')
+
+
+class _ConvBase(nn.Module):
+    TRANSPOSED = False
+    GENERATIVE = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator: Optional[KernelGenerator] = None, expand_coordinates=False, dimension=3):
+        super().__init__()
+        if kernel_generator is None:
+            kernel_generator = KernelGenerator(kernel_size, stride, dilation, dimension=dimension)
+        kg = kernel_generator
+        if len(set(kg.kernel_size)) != 1 or len(set(kg.kernel_stride)) != 1 or set(kg.kernel_dilation) != {1}:
+            raise NotImplementedError('isotropic kernels without dilation only')
+        self.kernel_generator = kg
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.ks, self.st = kg.kernel_size[0], kg.kernel_stride[0]
+        if (self.ks, self.st) not in ((1, 1), (3, 1), (2, 2)):
+            raise NotImplementedError(f'kernel {self.ks} stride {self.st}')
+        if (self.TRANSPOSED or self.GENERATIVE) and (self.ks, self.st) != (2, 2):
+            raise NotImplementedError('transposed convolutions are kernel 2 stride 2')
+        volume = kg.kernel_volume
+        shape = (in_channels, out_channels) if volume == 1 else (volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # MinkowskiEngine 0.5's default: U(-1/sqrt(n), 1/sqrt(n)), n = (C_out if transposed else C_in) * volume
+        fan = (self.out_channels if (self.TRANSPOSED or self.GENERATIVE) else self.in_channels) * \
+            self.kernel_generator.kernel_volume
+        bound = 1.0 / math.sqrt(fan)
+        with torch.no_grad():
+            self.kernel.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x: SparseTensor, coordinates: Optional[CoordinateMapKey] = None, *, act: Optional[_Act] = None,
+                clip: float = 0.0) -> SparseTensor:
+        if torch.is_grad_enabled() and self.kernel.requires_grad:
+            raise RuntimeError('fastpcc_amd convolutions are inference-only; wrap the call in torch.no_grad()')
+        act = act or _Act()
+        cm = x.coordinate_manager
+        src = cm._map(x.coordinate_map_key)
+        parts = x.parts
+        x1 = parts[0]
+        x2 = parts[1] if len(parts) > 1 else None
+        kw = dict(x2=x2, bias=None if self.bias is None else self.bias.detach().view(-1), act=act.kind, slope=act.slope,
+                  clip=clip)
+        w = self.kernel.detach()
+        c_out = self.out_channels
+        if self.GENERATIVE:
+            dst = cm._generated(src)
+            out = ops.conv_f32(x1, w, c_out, src.n, groups=8, **kw)
+        elif self.TRANSPOSED:
+            if coordinates is None:
+                raise ValueError('a transposed convolution needs the target coordinate key')
+            dst = cm._map(coordinates)
+            if dst.parent is not src:
+                raise ValueError('target map is not a stride-2 child of the input map')
+            if dst.generated:
+                out = ops.conv_f32(x1, w, c_out, src.n, groups=8, **kw)
+            else:
+                out = ops.conv_f32(x1, w, c_out, src.n, groups=8, out_map=dst.child_row, om_os=8, om_gs=1,
+                                   out_rows=dst.n, **kw)
+        elif self.ks == 1:
+            dst = src
+            out = ops.conv_f32(x1, w, c_out, src.n, **kw)
+        elif self.ks == 3:
+            dst = src
+            if coordinates is not None and cm._map(coordinates) is not src:
+                raise NotImplementedError('stride-1 convolution onto a different coordinate map')
+            out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, **kw)
+        else:   # kernel 2, stride 2
+            dst = cm._ensure_parent(src)
+            if src.generated:
+                raise NotImplementedError('stride-2 convolution of a generated set')
+            out = ops.conv_f32(x1, w, c_out, dst.n, nbr=src.child_row, n_offsets=8, nbr_ks=1, nbr_os=8, **kw)
+        return SparseTensor(out, coordinate_map_key=dst.key, coordinate_manager=cm)
+
+
+class MinkowskiConvolution(_ConvBase):
+    pass
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    TRANSPOSED = True
+
+
+class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
+    GENERATIVE = True
+
+
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        self._wt = None
+        self._wt_version = None
+
+    def _weight_t(self) -> torch.Tensor:
+        w = self.linear.weight
+        if self._wt is None or self._wt_version != (w._version, w.data_ptr()):
+            self._wt = w.detach().t().contiguous()
+            self._wt_version = (w._version, w.data_ptr())
+        return self._wt
+
+    def forward(self, x: SparseTensor, *, act: Optional[_Act] = None, clip: float = 0.0) -> SparseTensor:
+        if torch.is_grad_enabled() and self.linear.weight.requires_grad:
+            raise RuntimeError('fastpcc_amd layers are inference-only; wrap the call in torch.no_grad()')
+        act = act or _Act()
+        parts = x.parts
+        b = self.linear.bias
+        out = ops.conv_f32(parts[0], self._weight_t(), self.linear.out_features, parts[0].shape[0],
+                           x2=parts[1] if len(parts) > 1 else None, bias=None if b is None else b.detach(),
+                           act=act.kind, slope=act.slope, clip=clip)
+        return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+
+
+class _Pointwise(nn.Module):
+    MODULE = None
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.module = self.MODULE(*args, **kwargs)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return SparseTensor(self.module(x.F), coordinate_map_key=x.coordinate_map_key,
+                            coordinate_manager=x.coordinate_manager)
+
+
+class MinkowskiReLU(_Pointwise):
+    MODULE = nn.ReLU
+
+
+class MinkowskiPReLU(_Pointwise):
+    MODULE = nn.PReLU
+
+
+class MinkowskiLeakyReLU(_Pointwise):
+    MODULE = nn.LeakyReLU
+
+
+class MinkowskiSigmoid(_Pointwise):
+    MODULE = nn.Sigmoid
+
+
+class MinkowskiPruning(nn.Module):
+    """Keeps the rows where mask is true; the new map keeps Morton order.  Only generated sets (the decoder's
+    candidates) and their refinement are supported, which is how the reference uses it."""
+
+    def forward(self, x: SparseTensor, mask: torch.Tensor) -> SparseTensor:
+        cm = x.coordinate_manager
+        src = cm._map(x.coordinate_map_key)
+        if not src.generated:
+            raise NotImplementedError('pruning of a non-generated map')
+        t = cm._refine(src.parent, mask.contiguous(), 'pruned')
+        rows = torch.nonzero(mask.view(-1)).squeeze(1).to(torch.int32)
+        return SparseTensor(ops.gather_rows(x.F, rows), coordinate_map_key=t.key, coordinate_manager=cm)

@@ -1,0 +1,309 @@
+"""Thin typed wrappers over the C ABI of libfpcc_hip.so (include/fpcc_hip.h).
+
+Tensors are torch CUDA(=HIP) tensors used purely as device buffers: every wrapper checks device / dtype / contiguity,
+passes raw pointers plus the current HIP stream, and raises on a non-zero status.  No computation happens in Python and
+there is no alternative implementation: without the library or a GPU these functions raise.
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
+
+_SIGS = {
+    # name: (restype, argtypes)
+    'fpcc_morton3d_encode': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'fpcc_keys_from_coords': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    'fpcc_coords_from_keys': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'fpcc_sort_keys': (_i64, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_unique_keys': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_coarsen': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
+                             _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp]),
+    'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
+    'fpcc_logit_to_prob16': (_i32, [_vp, _i64, _vp, _vp]),
+    'fpcc_quantize_symbols': (_i32, [_vp, _i64, _f32, _vp, _vp]),
+    'fpcc_child_mask': (_i32, [_vp, _i64, _vp, _vp]),
+    'fpcc_topk_keep': (_i64, [_vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    'fpcc_gather_rows_f32': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
+    'fpcc_compact_coords': (_i64, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_device_count': (_i32, []),
+}
+HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = _native.hip()
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L.fpcc_last_error.restype = C.c_char_p
+        L.fpcc_last_error.argtypes = []
+        _lib = L
+    return _lib
+
+
+class FpccError(RuntimeError):
+    pass
+
+
+def _ok(code: int) -> int:
+    if code < 0:
+        raise FpccError(f'libfpcc_hip status {code}: {lib().fpcc_last_error().decode()}')
+    return code
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Optional[torch.Tensor], dtype, name: str, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f'{name} is required')
+    if not t.is_cuda:
+        raise FpccError(f'{name} must live on the GPU (libfpcc_hip has no CPU path)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def _ws(query_fn, device) -> Tuple[torch.Tensor, int]:
+    need = _ok(query_fn())
+    buf = torch.empty(max(int(need), 16), dtype=torch.uint8, device=device)
+    return buf, int(need)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# coordinates
+
+def morton3d_encode(coords: torch.Tensor, cols=(0, 1, 2)) -> torch.Tensor:
+    """coords [n, w] int32 (any row stride, unit column stride); cols = columns landing on Morton bits 0, 1, 2."""
+    if coords.dtype != torch.int32 or coords.dim() != 2 or not coords.is_cuda:
+        raise TypeError('coords must be a 2-D int32 GPU tensor')
+    if coords.stride(1) != 1:
+        coords = coords.contiguous()
+    n = coords.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=coords.device)
+    _ok(lib().fpcc_morton3d_encode(coords.data_ptr(), n, coords.stride(0) if n else coords.shape[1], cols[0], cols[1],
+                                   cols[2], out.data_ptr(), _stream()))
+    return out
+
+
+def keys_from_coords(coords: torch.Tensor, level: int, bits: int) -> torch.Tensor:
+    n = coords.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=coords.device)
+    _ok(lib().fpcc_keys_from_coords(_dev(coords, torch.int32, 'coords'), n, level, bits, out.data_ptr(), _stream()))
+    return out
+
+
+def coords_from_keys(keys: torch.Tensor, level: int, bits: int, offset_xyz: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n = keys.shape[0]
+    out = torch.empty((n, 4), dtype=torch.int32, device=keys.device)
+    _ok(lib().fpcc_coords_from_keys(_dev(keys, torch.int64, 'keys'), n, level, bits,
+                                    _dev(offset_xyz, torch.int32, 'offset', True), out.data_ptr(), _stream()))
+    return out
+
+
+def sort_keys(keys: torch.Tensor, end_bit: int = 63) -> Tuple[torch.Tensor, torch.Tensor]:
+    n = keys.shape[0]
+    kp = _dev(keys, torch.int64, 'keys')
+    out = torch.empty_like(keys)
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_sort_keys(None, n, end_bit, None, None, None, 0, None), keys.device)
+    _ok(L.fpcc_sort_keys(kp, n, end_bit, out.data_ptr(), perm.data_ptr(), ws.data_ptr(), need, _stream()))
+    return out, perm
+
+
+def unique_keys(keys: torch.Tensor):
+    """-> (ukeys[n] (first `count` valid), first[n], count device int32[1])"""
+    n = keys.shape[0]
+    kp = _dev(keys, torch.int64, 'keys')
+    ukeys = torch.empty_like(keys)
+    first = torch.empty(n, dtype=torch.int32, device=keys.device)
+    count = torch.empty(1, dtype=torch.int32, device=keys.device)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_unique_keys(None, n, None, None, None, None, 0, None), keys.device)
+    _ok(L.fpcc_unique_keys(kp, n, ukeys.data_ptr(), first.data_ptr(), count.data_ptr(), ws.data_ptr(), need, _stream()))
+    return ukeys, first, count
+
+
+def coarsen(keys: torch.Tensor):
+    """-> (parent_of[n], pkeys[n], child_row[n,8], count device int32[1]); only the first `count` parents are valid."""
+    n = keys.shape[0]
+    kp = _dev(keys, torch.int64, 'keys')
+    dev = keys.device
+    parent_of = torch.empty(n, dtype=torch.int32, device=dev)
+    pkeys = torch.empty(n, dtype=torch.int64, device=dev)
+    child_row = torch.empty((n, 8), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_coarsen(None, n, None, None, None, None, None, 0, None), dev)
+    _ok(L.fpcc_coarsen(kp, n, parent_of.data_ptr(), pkeys.data_ptr(), child_row.data_ptr(), count.data_ptr(),
+                       ws.data_ptr(), need, _stream()))
+    return parent_of, pkeys, child_row, count
+
+
+def refine(pkeys: torch.Tensor, mask: torch.Tensor):
+    """mask uint8 [8m] -> (keys[8m], parent_of[8m], child_row[m,8], count device int32[1])"""
+    m = pkeys.shape[0]
+    dev = pkeys.device
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    if mask.numel() != 8 * m:
+        raise ValueError('mask must have 8 entries per parent')
+    keys = torch.empty(8 * m, dtype=torch.int64, device=dev)
+    parent_of = torch.empty(8 * m, dtype=torch.int32, device=dev)
+    child_row = torch.empty((m, 8), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_refine(None, m, None, None, None, None, None, None, 0, None), dev)
+    _ok(L.fpcc_refine(_dev(pkeys, torch.int64, 'pkeys'), m, _dev(mask, torch.uint8, 'mask'), keys.data_ptr(),
+                      parent_of.data_ptr(), child_row.data_ptr(), count.data_ptr(), ws.data_ptr(), need, _stream()))
+    return keys, parent_of, child_row, count
+
+
+def nbr27_search(keys: torch.Tensor, bits: int) -> torch.Tensor:
+    n = keys.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=keys.device)
+    _ok(lib().fpcc_nbr27_search(_dev(keys, torch.int64, 'keys'), n, bits, nbr.data_ptr(), _stream()))
+    return nbr
+
+
+def nbr27_from_parent(keys: Optional[torch.Tensor], parent_of: Optional[torch.Tensor], parent_nbr: torch.Tensor,
+                      child_row: Optional[torch.Tensor], n: Optional[int] = None) -> torch.Tensor:
+    """keys/parent_of/child_row all None: the full generated set of the parent level (n = 8 * parents)."""
+    m = parent_nbr.shape[1]
+    if keys is None:
+        n = 8 * m if n is None else n
+    else:
+        n = keys.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=parent_nbr.device)
+    _ok(lib().fpcc_nbr27_from_parent(_dev(keys, torch.int64, 'keys', True), _dev(parent_of, torch.int32, 'parent_of', True),
+                                     n, _dev(parent_nbr, torch.int32, 'parent_nbr'), m,
+                                     _dev(child_row, torch.int32, 'child_row', True), nbr.data_ptr(), _stream()))
+    return nbr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolution
+
+def _rows2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+        raise TypeError(f'{name} must be a 2-D float32 GPU tensor with unit column stride')
+    return t.data_ptr(), t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: Optional[torch.Tensor] = None,
+             nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1,
+             bias: Optional[torch.Tensor] = None, groups: int = 1, out_map: Optional[torch.Tensor] = None,
+             om_os: int = 0, om_gs: int = 1, out: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
+             act: int = ACT_NONE, slope: Optional[torch.Tensor] = None, clip: float = 0.0) -> torch.Tensor:
+    """out[dst(o,g)] = act(sum_k X[nbr[k*nbr_ks + o*nbr_os]] @ w[g][k] + bias); see include/fpcc_hip.h."""
+    p1, c1, ld1 = _rows2d(x1, 'x1')
+    if x2 is not None:
+        p2, c2, ld2 = _rows2d(x2, 'x2')
+    else:
+        p2, c2, ld2 = None, 0, 0
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or \
+            w.numel() != groups * n_offsets * (c1 + c2) * c_out:
+        raise ValueError(f'weights must be contiguous fp32 [{groups},{n_offsets},{c1 + c2},{c_out}], got {tuple(w.shape)}')
+    if out is None:
+        rows = out_rows if out_rows is not None else n_out * groups
+        out = torch.empty((rows, c_out), dtype=torch.float32, device=x1.device)
+    po, co, ldo = _rows2d(out, 'out')
+    if co != c_out:
+        raise ValueError('output width mismatch')
+    if om_os == 0:
+        om_os = groups
+    _ok(lib().fpcc_conv_f32(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                            w.data_ptr(), _dev(bias, torch.float32, 'bias', True), c_out, groups,
+                            _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
+                            _dev(slope, torch.float32, 'slope', True), float(clip), _stream()))
+    return out
+
+
+def conv_order(c1: int, c2: int, c_out: int) -> int:
+    return lib().fpcc_conv_f32_order(c1, c2, c_out)
+
+
+def gather_rows(x: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[i] = x[index[i]] (rows; features re-ordered into canonical Morton row order)."""
+    p, c, ld = _rows2d(x, 'x')
+    n = index.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _ok(lib().fpcc_gather_rows_f32(p, c, ld, _dev(index, torch.int32, 'index'), n, out.data_ptr(), c, _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# entropy glue
+
+def logit_to_prob16(logit: torch.Tensor) -> torch.Tensor:
+    """uint16 probabilities, returned in an int16 tensor (same bits; view as uint16 on the host)."""
+    n = logit.numel()
+    out = torch.empty(n, dtype=torch.int16, device=logit.device)
+    _ok(lib().fpcc_logit_to_prob16(_dev(logit, torch.float32, 'logit'), n, out.data_ptr(), _stream()))
+    return out
+
+
+def quantize_symbols_(x: torch.Tensor, scale: float = 1.0, want_symbols: bool = True) -> Optional[torch.Tensor]:
+    n = x.numel()
+    sym = torch.empty(n, dtype=torch.int32, device=x.device) if want_symbols else None
+    _ok(lib().fpcc_quantize_symbols(_dev(x, torch.float32, 'x'), n, float(scale),
+                                    None if sym is None else sym.data_ptr(), _stream()))
+    return sym
+
+
+def child_mask(child_row: torch.Tensor) -> torch.Tensor:
+    m = child_row.shape[0]
+    out = torch.empty(8 * m, dtype=torch.uint8, device=child_row.device)
+    _ok(lib().fpcc_child_mask(_dev(child_row, torch.int32, 'child_row'), m, out.data_ptr(), _stream()))
+    return out
+
+
+def topk_keep(logit: torch.Tensor, target: int) -> torch.Tensor:
+    n = logit.numel()
+    if n % 8:
+        raise ValueError('logits must come in groups of 8 children')
+    m = n // 8
+    out = torch.empty(n, dtype=torch.uint8, device=logit.device)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_topk_keep(None, m, target, None, None, 0, None), logit.device)
+    _ok(L.fpcc_topk_keep(_dev(logit, torch.float32, 'logit'), m, int(target), out.data_ptr(), ws.data_ptr(), need,
+                         _stream()))
+    return out
+
+
+def compact_coords(pkeys: torch.Tensor, mask: torch.Tensor, level: int, bits: int,
+                   offset_xyz: Optional[torch.Tensor] = None):
+    """Children (of parents pkeys at level+1) selected by mask -> xyz int32 [<=8m, 3] at `level`, + count (device)."""
+    m = pkeys.shape[0]
+    dev = pkeys.device
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    out = torch.empty((8 * m, 3), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_compact_coords(None, m, None, level, bits, None, None, None, None, 0, None), dev)
+    _ok(L.fpcc_compact_coords(_dev(pkeys, torch.int64, 'pkeys'), m, _dev(mask, torch.uint8, 'mask'), level, bits,
+                              _dev(offset_xyz, torch.int32, 'offset', True), out.data_ptr(), count.data_ptr(),
+                              ws.data_ptr(), need, _stream()))
+    return out, count

@@ -1,0 +1,165 @@
+/*
+ * fpcc_hip.h -- C ABI of libfpcc_hip.so: hand-written HIP kernels for gfx950 (MI355X) behind the FastPCC
+ * encode/decode hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller (e.g. PyTorch's caching allocator)
+ *     owns all memory, nothing is allocated or freed inside;
+ *   - `stream` is a hipStream_t passed as void*; every function only enqueues work on it (no synchronisation), so the
+ *     calls can be captured into a hipGraph;
+ *   - return value: 0 on success, a negative fpcc_status otherwise; fpcc_last_error() gives the message of the last
+ *     failure on the calling thread;
+ *   - functions that need scratch memory take (ws, ws_bytes); called with ws == NULL they return the number of bytes
+ *     they need for that problem size (a positive value) and enqueue nothing;
+ *   - variable-size results are written into caller buffers sized for the worst case, and their length is left in a
+ *     device counter the caller reads back when it needs it (one D2H copy may serve several calls).
+ *
+ * Which reference interface each entry point replaces is cited per function (paths relative to /root/reference).
+ * MinkowskiEngine itself is an un-vendored dependency of the reference; for the float path the citations are the
+ * reference's call sites into it.
+ */
+#ifndef FPCC_HIP_H_
+#define FPCC_HIP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FPCC_OK = 0,
+    FPCC_E_ARG = -1,       /* invalid argument / unsupported shape */
+    FPCC_E_HIP = -2,       /* a HIP runtime call failed */
+    FPCC_E_WORKSPACE = -3  /* workspace too small */
+} fpcc_status;
+
+const char *fpcc_last_error(void);
+/* Number of visible HIP devices (0 without a GPU); never initialises a context beyond hipGetDeviceCount. */
+int fpcc_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Coordinates.  A coordinate set at pyramid level l is a sorted array of unique 64-bit keys                      */
+/*      key = batch << (3*bits) | morton3(x >> l, y >> l, z >> l)       (x is Morton bit 0)                        */
+/* so that the parent of a key is key >> 3 and its octant (kernel index of a 2x2x2 stride-2 kernel, x fastest) is */
+/* key & 7.  `bits` is the number of bits per axis AT THAT LEVEL.                                                 */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* Morton key of int32 coordinates; replaces space_filling_curves_ext.morton3d_encode_magicbits
+ * (lib/space_filling_curves/src/morton3d.cu:19-72, binding.cu:17-23).  coords: [n, row_stride] int32, the three axes at
+ * columns col_bit0, col_bit1, col_bit2 (the column whose bits land on Morton bit 0, 1, 2: axis order 'xyz' of a [n,3]
+ * array is 0,1,2; 'zyx' is 2,1,0).  Each coordinate is taken modulo 2^21 as in the reference. */
+int fpcc_morton3d_encode(const int32_t *coords, int64_t n, int64_t row_stride, int col_bit0, int col_bit1, int col_bit2,
+                         int64_t *keys_out, void *stream);
+
+/* Level-l keys of batched coordinates [n,4] = (batch, x, y, z): what ME.SparseTensor(coordinates=...) hashes
+ * (models/convolutional/lossy_coord_v2/model.py:147-153). */
+int fpcc_keys_from_coords(const int32_t *coords, int64_t n, int level, int bits, int64_t *keys_out, void *stream);
+/* Inverse: coordinates (batch, x, y, z) in absolute units (multiples of 1 << level), optionally + offset_xyz[3] (device). */
+int fpcc_coords_from_keys(const int64_t *keys, int64_t n, int level, int bits, const int32_t *offset_xyz,
+                          int32_t *coords_out, void *stream);
+
+/* Stable ascending radix sort of (key, original row) pairs; replaces torch.argsort(morton) (lossy_coord_v2/model.py:142).
+ * perm_out[i] = original row of the i-th smallest key.  end_bit: number of significant key bits. */
+int64_t fpcc_sort_keys(const int64_t *keys_in, int64_t n, int end_bit, int64_t *keys_out, int32_t *perm_out,
+                       void *ws, int64_t ws_bytes, void *stream);
+
+/* keys sorted -> unique keys (first occurrence kept).  first_out[u] = index of the first row of unique key u;
+ * count_out (device int32[1]) = number of unique keys.  Replaces the de-duplication ME.SparseTensor performs. */
+int64_t fpcc_unique_keys(const int64_t *keys, int64_t n, int64_t *ukeys_out, int32_t *first_out, int32_t *count_out,
+                         void *ws, int64_t ws_bytes, void *stream);
+
+/* One pyramid step (stride-2 coordinate map, what cm.stride(key, 2) / a stride-2 MinkowskiConvolution creates,
+ * lib/minkowski_sparse_conv_layers.py:114-127): from sorted unique keys[n] produce
+ *   parent_of[n]          parent row of every row,
+ *   pkeys[<=n]            sorted unique parent keys,
+ *   child_row[<=n][8]     row of child (parent, octant) or -1,
+ *   count_out             device int32[1], number of parents. */
+int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_of, int64_t *pkeys, int32_t *child_row,
+                     int32_t *count_out, void *ws, int64_t ws_bytes, void *stream);
+
+/* Occupancy-driven refinement (decoder side; replaces coords = pred.C[mask]; cm.insert_and_map(...),
+ * models/convolutional/lossy_coord_lossy_color/geo_lossl_em.py:278-283, and MinkowskiPruning on a generated set):
+ * candidates are the 8 children of each of m parents in (parent, octant) order; mask[8m] selects the kept ones.
+ *   keys_out[<=8m], parent_of[<=8m], child_row[m][8], count_out device int32[1]. */
+int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_t *keys_out, int32_t *parent_of,
+                    int32_t *child_row, int32_t *count_out, void *ws, int64_t ws_bytes, void *stream);
+
+/* 3x3x3 kernel map (what cm.kernel_map(key, key, kernel_size=3) answers; offsets enumerated x fastest, centred):
+ * nbr[d][i] = row of the voxel at offset d from voxel i, or -1.  nbr is [27][n] int32.
+ *   _search      : binary search in the sorted keys (any level, no parent needed);
+ *   _from_parent : derived from the parent level's table and the child_row table (two dependent loads per entry, no
+ *                  hashing, no key arithmetic); parent_nbr is [27][m].
+ *   child_row == NULL means "all 8 children exist, row = 8*parent + octant" (a generated set). */
+int fpcc_nbr27_search(const int64_t *keys, int64_t n, int bits, int32_t *nbr, void *stream);
+int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr,
+                           int64_t m, const int32_t *child_row, int32_t *nbr, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Sparse convolution, fp32, output-stationary gather -> MFMA GEMM (no scatter, no atomics, bitwise reproducible) */
+/* ------------------------------------------------------------------------------------------------------------ */
+enum { FPCC_ACT_NONE = 0, FPCC_ACT_PRELU = 1, FPCC_ACT_RELU = 2 };
+
+/*
+ * out[dst(o,g), :] = act( sum_k  X[nbr[k][o], :] @ W[g][k]  + bias )        o < n_out, g < groups
+ *
+ * Replaces MinkowskiConvolution / MinkowskiConvolutionTranspose / MinkowskiGenerativeConvolutionTranspose /
+ * MinkowskiLinear (+ the bias add, MinkowskiPReLU/ReLU and ME.cat that surround them) as used through
+ * lib/minkowski_sparse_conv_layers.py:31-159 and models/convolutional/lossy_coord_v2/layers.py:263-271,306-315.
+ *
+ *   X        rows are the channel-concatenation of x1 [*, c1] (row stride ld1 floats) and, if x2 != NULL, x2 [*, c2];
+ *   nbr      int32 input row per (offset k, output row o) at nbr[k*nbr_ks + o*nbr_os], -1 = absent; NULL = identity
+ *            (n_offsets == 1).  A [27][n] table has (ks, os) = (n, 1); a child_row table [m][8] read as a stride-2
+ *            2x2x2 convolution has (1, 8);
+ *   w        [groups][n_offsets][c1 + c2][c_out] fp32 (MinkowskiEngine kernel layout [K, C_in, C_out] per group);
+ *   bias     [c_out] or NULL;  slope: device float[1] for PReLU;  clip > 0 clamps the result to [-clip, clip];
+ *   dst      out_map == NULL: row o*groups + g;  else out_map[o*om_os + g*om_gs] (negative: skipped);
+ *   out      row stride ldo floats.
+ * groups > 1 expresses a stride-2 transposed / generative convolution: group g = octant g of parent row o, with
+ * out_map = child_row [m][8] ((om_os, om_gs) = (8, 1)) or NULL for the full generated set.
+ *
+ * Summation order (fixed, documented for bit-exact checking): one fp32 FMA chain per output element, offsets ascending,
+ * channels ascending -- except that the MFMA path visits every aligned group of 8 channels as 0,4,1,5,2,6,3,7.
+ * fpcc_conv_f32_order() reports which of the two a given shape uses (0 natural, 1 the MFMA order).
+ */
+int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2,
+                  const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                  const float *w, const float *bias, int c_out, int groups,
+                  const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
+                  int act, const float *slope, float clip, void *stream);
+int fpcc_conv_f32_order(int c1, int c2, int c_out);
+
+/* out[i, :] = x[index[i], :] -- features re-ordered into the canonical (Morton) row order of a coordinate map, the
+ * permutation ME.SparseTensor applies to its features (models/convolutional/lossy_coord_v2/model.py:147-153). */
+int fpcc_gather_rows_f32(const float *x, int c, int ld, const int32_t *index, int64_t n, float *out, int ldo, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Entropy-model glue that has to sit next to the features                                                         */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* p = clip(round(float64(sigmoid_fp32(logit)) * 65536), 1, 65535) as uint16: GeoLosslessEntropyModel.init_prob
+ * (models/convolutional/lossy_coord_lossy_color/geo_lossl_em.py:95-99). */
+int fpcc_logit_to_prob16(const float *logit, int64_t n, uint16_t *prob_out, void *stream);
+
+/* x = round_half_even(x * scale) in place, symbols_out = int32(x), then x /= scale
+ * (geo_lossl_em.py:168-172, 202-206).  symbols_out may be NULL. */
+int fpcc_quantize_symbols(float *x, int64_t n, float scale, int32_t *symbols_out, void *stream);
+
+/* occupancy of candidate children: mask[8*m] = child_row[p][k] >= 0  (get_coord_mask, geo_lossl_em.py:306-317) */
+int fpcc_child_mask(const int32_t *child_row, int64_t m, uint8_t *mask_out, void *stream);
+
+/* Adaptive top-k pruning of Decoder.get_keep (models/convolutional/lossy_coord_v2/layers.py:151-180) for one sample:
+ * logit[8*m] in (parent, octant) order; keep = logit > kth_smallest(non-local-max logits, 8m - target) OR local max.
+ * A voxel is a local max when it equals the maximum over the 8 candidates of its parent.  keep_out uint8[8m]. */
+int64_t fpcc_topk_keep(const float *logit, int64_t m, int64_t target, uint8_t *keep_out,
+                       void *ws, int64_t ws_bytes, void *stream);
+
+/* Final step of Decoder.test_forward (models/convolutional/lossy_coord_v2/layers.py:148 `fea.C[:, 1:][keep]`) fused with
+ * the `+ coord_offset` of PCC.decompress (lossy_coord_v2/model.py:274): the kept children of parents pkeys[m]
+ * (level+1 keys) -> xyz_out int32 [<=8m, 3] in Morton order at `level`; count_out device int32[1]. */
+int64_t fpcc_compact_coords(const int64_t *pkeys, int64_t m, const uint8_t *mask, int level, int bits,
+                            const int32_t *offset_xyz, int32_t *xyz_out, int32_t *count_out,
+                            void *ws, int64_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

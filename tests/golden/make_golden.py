@@ -1,0 +1,189 @@
+"""Generates the golden fixtures under tests/golden/ from the REFERENCE itself.  Runs only in the build container
+(needs /root/reference and oracle/_ref built by `make -C oracle ref`); the fixtures it writes are data -- inputs and the
+reference's outputs -- and are what travels to the GPU box.
+
+    python tests/golden/make_golden.py
+
+Sources of truth used:
+  rans.json      reference C++ coders compiled from /root/reference (oracle/_ref): IndexedRansCoder (with/without
+                 overflow coding, with/without indexes), BinaryRansCoder, simple RansEncoder; plus
+                 batched_pmf_to_quantized_cdf incl. the known-answer assertion of
+                 /root/reference/lib/entropy_models/rans_coder/__init__.py:72-77
+  morton.json    /root/reference/lib/space_filling_curves/__init__.py:65-88 (CPU path, imported with the CUDA loader stubbed)
+  byteslist.json /root/reference/lib/entropy_models/hyperprior/noisy_deep_factorized/utils.py:8-77
+  explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
+"""
+import hashlib
+import importlib.util
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, os.path.join(ROOT, 'oracle', '_ref'))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def make_rans():
+    import rans_ext_cpp as R
+    import simple_rans_ext_cpp as S
+    rng = np.random.default_rng(20261002)
+    out = {'cdf': [], 'indexed': [], 'binary': [], 'simple': []}
+
+    # --- PMF -> CDF --------------------------------------------------------------------------------------------------
+    known = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [2 ** -17, 1, 0, 0]], dtype=np.float64)
+    cases = [(known, True), (np.array([[1, 2, 3, 1]], np.float64), False), (np.array([[.1, .2, .4, .2, .1]]), True),
+             (np.array([[0, 0, 1], [1, 1, 2]], np.float64), False)]
+    for _ in range(12):
+        n = int(rng.integers(2, 70))
+        p = rng.random((2, n)) ** 4
+        p[rng.random((2, n)) < 0.3] = 0
+        p[:, int(rng.integers(0, n))] += 0.5
+        cases.append((p / p.sum(1, keepdims=True) * rng.choice([1.0, 0.7]), bool(rng.integers(0, 2))))
+    for pmf, ov in cases:
+        off = np.full(pmf.shape[0], -3, dtype=np.int32)
+        cdfs = R.batched_pmf_to_quantized_cdf(pmf.copy(), off, ov)
+        out['cdf'].append({'pmf': pmf.tolist(), 'overflow': ov, 'offset_in': -3, 'offset_out': off.tolist(),
+                           'cdf': [list(map(int, c)) for c in cdfs]})
+
+    # --- indexed coder -----------------------------------------------------------------------------------------------
+    for ov in (False, True):
+        for with_idx in (False, True):
+            for _ in range(3):
+                nt, ns = int(rng.integers(1, 4)), int(rng.integers(2, 40))
+                pmf = rng.random((nt, ns)) ** 2
+                pmf[rng.random((nt, ns)) < 0.2] = 0
+                pmf[:, 0] += 1e-2
+                pmf /= pmf.sum(1, keepdims=True)
+                off = rng.integers(-6, 3, nt).astype(np.int32)
+                coder = R.IndexedRansCoder(ov, 1)
+                coder.init_with_pmfs(pmf.copy(), off)
+                cdfs = coder.get_cdfs()
+                n = int(rng.integers(1, 400))
+                idx = rng.integers(0, nt, (1, n)).astype(np.int32) if with_idx else (np.arange(n) % nt).astype(np.int32)[None]
+                lens = np.array([len(c) - 1 for c in cdfs])
+                if ov:
+                    sym = rng.integers(-70, 70, (1, n)).astype(np.int32)
+                    sym[0, :3] = [2049, -2049, 0][:min(3, n)][:n] if n >= 3 else sym[0, :3]
+                else:
+                    sym = (rng.integers(0, 1 << 30, (1, n)) % lens[idx] + off[idx]).astype(np.int32)
+                enc = coder.encode_with_indexes(sym, idx)[0] if with_idx else coder.encode(sym)[0]
+                dec = np.empty_like(sym)
+                if with_idx:
+                    coder.decode_with_indexes([enc], idx, dec)
+                else:
+                    coder.decode([enc], dec)
+                assert (dec == sym).all()
+                out['indexed'].append({'overflow': ov, 'with_indexes': with_idx, 'cdfs': [list(map(int, c)) for c in cdfs],
+                                       'offsets': off.tolist(), 'symbols': sym[0].tolist(),
+                                       'indexes': idx[0].tolist(), 'stream': enc.hex()})
+    # survey samples
+    coder = R.IndexedRansCoder(False, 1)
+    coder.init_with_pmfs(np.array([[1, 2, 3, 1]], np.float64), np.array([0], np.int32))
+    enc = coder.encode(np.array([[0, 1, 1, 2, 2, 2, 3]], np.int32))[0]
+    out['indexed'].append({'overflow': False, 'with_indexes': False, 'cdfs': coder.get_cdfs(), 'offsets': [0],
+                           'symbols': [0, 1, 1, 2, 2, 2, 3], 'indexes': [0] * 7, 'stream': enc.hex()})
+
+    # --- binary coder ------------------------------------------------------------------------------------------------
+    for n in (1, 7, 100, 5000):
+        p = np.clip(np.round(rng.beta(.3, .3, (1, n)) * 65536), 1, 65535).astype(np.uint32)
+        bits = rng.random((1, n)) < p / 65536
+        enc = R.BinaryRansCoder(1).encode(bits, p)[0]
+        out['binary'].append({'prob': p[0].tolist(), 'bits': bits[0].astype(int).tolist(), 'stream': enc.hex()})
+
+    # --- simple persistent coder -------------------------------------------------------------------------------------
+    quan_cdf = np.array([[1, 2, 3, 4, 65535], [1, 2, 3, 5, 65535], [2, 3, 4, 6, 65535], [2, 3, 4, 7, 65535],
+                         [1, 2, 3, 8, 65535], [1, 2, 3, 9, 65535]], dtype=np.uint16)
+    quan_cdf2 = np.array([[1, 2, 4000, 5000, 65535], [2, 3, 3000, 6000, 65535], [3, 4, 3000, 7000, 65535],
+                          [4, 5, 1000, 8000, 65535], [5, 6, 5000, 9000, 65535], [6, 7, 6000, 10000, 65535]], dtype=np.uint16)
+    org = np.array([2, 4, 1, 1, 2, 3, 0, 2, 4, 2, 1, 1], dtype=np.uint16)
+    e = S.RansEncoder(1 << 20)
+    e.encode(quan_cdf2, org[6:12])
+    e.encode(quan_cdf, org[:6])
+    out['simple'].append({'blocks': [{'rows': quan_cdf2.tolist(), 'symbols': org[6:12].tolist()},
+                                     {'rows': quan_cdf.tolist(), 'symbols': org[:6].tolist()}], 'stream': e.flush().hex()})
+    logits = rng.normal(0, 3, (64, 255))
+    pm = np.exp(logits)
+    pm /= pm.sum(1, keepdims=True)
+    f = np.floor(pm * (65536 - 255)).astype(np.int64) + 1
+    rows = np.cumsum(f, 1)
+    rows[:, -1] = 65535
+    rows = rows.astype(np.uint16)
+    sym = rng.integers(0, 255, 64).astype(np.uint16)
+    e.encode(rows, sym)
+    e.encode(rows[:1], sym[:50])
+    out['simple'].append({'blocks': [{'rows': rows.tolist(), 'symbols': sym.tolist()},
+                                     {'rows': rows[:1].tolist(), 'symbols': sym[:50].tolist()}], 'stream': e.flush().hex()})
+    edge = rng.integers(1, 65535, 200).astype(np.uint16)
+    bits = rng.random(200) < 0.5
+    e.encode_bin(edge, bits)
+    out['simple'].append({'bin': {'edge': edge.tolist(), 'bits': bits.astype(int).tolist()}, 'stream': e.flush().hex()})
+    return out
+
+
+def make_morton():
+    # import the reference module with its CUDA extension loader stubbed (only the NumPy path is used)
+    import torch.utils.cpp_extension as ce
+    real = ce.load
+    ce.load = lambda *a, **k: types.SimpleNamespace()
+    try:
+        sfc = _load(os.path.join(REF, 'lib/space_filling_curves/__init__.py'), 'ref_sfc')
+    finally:
+        ce.load = real
+    rng = np.random.default_rng(7)
+    xyz = np.concatenate((np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [3, 5, 7], [0x1fffff] * 3, [1023, 0, 512]]),
+                          rng.integers(0, 1 << 21, (40, 3)), rng.integers(0, 1024, (40, 3)))).astype(np.int64)
+    out = {'xyz': xyz.tolist(), 'keys': {}}
+    for order in ('xyz', 'zyx', 'yxz'):
+        for inv in (False, True):
+            out['keys'][f'{order}|{int(inv)}'] = [int(v) for v in sfc.morton_encode_magicbits(xyz.copy(), order, inv)]
+    return out
+
+
+def make_byteslist():
+    ref = _load(os.path.join(REF, 'lib/entropy_models/hyperprior/noisy_deep_factorized/utils.py'), 'ref_bl')
+    rng = np.random.default_rng(11)
+    out = []
+    for lens in ([0, 1], [255, 256], [65535, 65536, 3], [1] * 8, [1] * 9, [300] * 7, [5, 70000, 2, 0, 9, 1000], [3] * 15,
+                 [3] * 16, [3] * 17, [400] * 4, [400] * 5):
+        strings = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+        blob = ref.BytesListUtils.concat_bytes_list(strings)
+        out.append({'lengths': lens, 'seed_strings_sha': hashlib.sha256(b''.join(strings)).hexdigest(),
+                    'strings': [s.hex() if len(s) < 64 else None for s in strings],
+                    'head': blob[: len(blob) - sum(lens)].hex()})
+    return out
+
+
+def make_explut():
+    text = open(os.path.join(REF, 'lib/int_sparse_conv/src/softmax.cu')).read()
+    body = text[text.index('at::tensor('):]
+    body = body[body.index('{') + 1: body.index('}')]
+    vals = [int(v) for v in re.findall(r'-?\d+', body)]
+    assert len(vals) == 12 * 512 + 1, len(vals)
+    return {'n': len(vals), 'sha256': hashlib.sha256(np.array(vals, dtype='<i4').tobytes()).hexdigest(),
+            'head': vals[:8], 'tail': vals[-8:], 'at_512': vals[512], 'at_3000': vals[3000]}
+
+
+def main():
+    for name, fn in (('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+        data = fn()
+        path = os.path.join(HERE, name + '.json')
+        with open(path, 'w') as f:
+            json.dump(data, f, separators=(',', ':'))
+        print(name, os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,150 @@
+"""fpcc_conv_f32 (MFMA and VALU paths, through the C ABI) against the oracle.
+
+Bit-exactness: the device kernel documents its summation order (include/fpcc_hip.h); oracle/sparse_conv.c evaluates the
+same FMA chain, so outputs are compared BIT FOR BIT.  Against the reference-shaped evaluation (gather, GEMM,
+scatter-add) the tolerance is 2e-5 relative to the row's magnitude -- fp32 re-association only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import sparse_conv as sc
+from util import batched, surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from fastpcc_amd import hipops
+    return hipops
+
+
+@pytest.fixture(scope='module')
+def scene():
+    xyz = surface_cloud(21, 128, 60000)
+    lvl = oc.Level(batched(xyz), 1)
+    up = oc.strided(lvl)
+    return {'lvl': lvl, 'up': up, 'k3': oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n),
+            'k2': oc.dense_table(oc.kernel_map(lvl, up, 2), up.n)}
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+SHAPES_K3 = [(1, 0, 16), (16, 0, 8), (32, 0, 1), (64, 0, 64), (64, 0, 128), (128, 0, 64), (128, 0, 128),
+             (128, 128, 128), (128, 0, 1), (16, 0, 64), (48, 0, 32), (8, 8, 4), (5, 0, 3)]
+
+
+@pytest.mark.parametrize('c1,c2,c_out', SHAPES_K3)
+def test_conv3_bit_exact(ops, scene, c1, c2, c_out):
+    rng = np.random.default_rng(c1 * 1000 + c2 * 10 + c_out)
+    lvl, table = scene['lvl'], scene['k3']
+    n = lvl.n
+    x1 = rng.normal(size=(n, c1)).astype(np.float32)
+    x2 = rng.normal(size=(n, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.2], device='cuda')
+    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
+                       n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope, clip=1.5)
+    order = ops.conv_order(c1, c2, c_out)
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.2, clip=1.5, order=order)
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+    # reference-shaped evaluation, tolerance
+    x = x1 if x2 is None else np.concatenate((x1, x2), 1)
+    km = [(table[k][table[k] >= 0].astype(np.int64), np.nonzero(table[k] >= 0)[0]) for k in range(27)]
+    ref = sc.conv_mm(torch.from_numpy(x), km, torch.from_numpy(w), torch.from_numpy(b), n, sc.ACT_PRELU, 0.2, 1.5).numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_mfma_path_is_used_for_the_big_shapes(ops):
+    assert ops.conv_order(128, 0, 128) == 1 and ops.conv_order(128, 128, 128) == 1 and ops.conv_order(16, 0, 64) == 1
+    assert ops.conv_order(1, 0, 16) == 0 and ops.conv_order(128, 0, 1) == 0 and ops.conv_order(16, 0, 8) == 0
+
+
+@pytest.mark.parametrize('c_in,c_out', [(16, 64), (128, 128), (1, 1), (64, 32)])
+def test_stride2_conv_bit_exact(ops, scene, c_in, c_out):
+    rng = np.random.default_rng(c_in + c_out)
+    lvl, up, table = scene['lvl'], scene['up'], scene['k2']
+    x = rng.normal(size=(lvl.n, c_in)).astype(np.float32)
+    w = (rng.normal(size=(8, c_in, c_out)) / np.sqrt(4 * c_in)).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    child_row = np.ascontiguousarray(table.T)                    # [m, 8], the layout the pyramid keeps
+    got = ops.conv_f32(_cuda(x), _cuda(w), c_out, up.n, nbr=_cuda(child_row), n_offsets=8, nbr_ks=1, nbr_os=8,
+                       bias=_cuda(b), act=ops.ACT_RELU)
+    want = sc.conv_chain(x, table, w, b, up.n, act=sc.ACT_RELU, order=ops.conv_order(c_in, 0, c_out))
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
+@pytest.mark.parametrize('c_in,c_out', [(128, 128), (128, 32), (1, 128), (64, 16), (1, 1)])
+def test_transposed_and_generative_bit_exact(ops, scene, c_in, c_out):
+    rng = np.random.default_rng(7 * c_in + c_out)
+    lvl, up = scene['lvl'], scene['up']
+    child_row = np.ascontiguousarray(scene['k2'].T)              # [m, 8] rows of the fine level
+    x = rng.normal(size=(up.n, c_in)).astype(np.float32)
+    w = (rng.normal(size=(8, c_in, c_out)) / np.sqrt(c_in)).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.3], device='cuda')
+    order = ops.conv_order(c_in, 0, c_out)
+    # transposed onto the existing fine level
+    got = ops.conv_f32(_cuda(x), _cuda(w), c_out, up.n, groups=8, out_map=_cuda(child_row), om_os=8, om_gs=1,
+                       out_rows=lvl.n, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
+    want = np.zeros((lvl.n, c_out), np.float32)
+    gen = np.zeros((8 * up.n, c_out), np.float32)
+    for g in range(8):
+        y = sc.conv_chain(x, None, w[g], b, up.n, act=sc.ACT_PRELU, slope=0.3, order=order)
+        rows = child_row[:, g]
+        want[rows[rows >= 0]] = y[rows >= 0]
+        gen[g::8] = y
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+    # generative: all 8 children, row = 8 * parent + octant
+    got = ops.conv_f32(_cuda(x), _cuda(w), c_out, up.n, groups=8, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
+    assert (_bits(got.cpu().numpy()) == _bits(gen)).all()
+    # ... and it equals the oracle's transposed kernel map formulation
+    g_lvl = oc.generated(up)
+    ref = sc.conv_mm(torch.from_numpy(x), oc.transposed_map(up, g_lvl), torch.from_numpy(w), torch.from_numpy(b),
+                     g_lvl.n, sc.ACT_PRELU, 0.3).numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('c1,c2,c_out', [(1, 0, 64), (64, 0, 128), (128, 128, 128), (128, 0, 1), (16, 0, 8), (8, 0, 1)])
+def test_pointwise_linear_bit_exact(ops, c1, c2, c_out):
+    rng = np.random.default_rng(c1 + c2 + c_out)
+    for n in (1, 127, 128, 129, 5000):
+        x1 = rng.normal(size=(n, c1)).astype(np.float32)
+        x2 = rng.normal(size=(n, c2)).astype(np.float32) if c2 else None
+        w = rng.normal(size=(c1 + c2, c_out)).astype(np.float32)
+        b = rng.normal(size=c_out).astype(np.float32)
+        got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), bias=_cuda(b))
+        want = sc.conv_chain(x1, None, w, b, n, x2=x2, order=ops.conv_order(c1, c2, c_out))
+        assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
+def test_isolated_rows_and_empty_input(ops):
+    # rows without any neighbour get act(bias); zero rows is a no-op
+    n, c = 300, 64
+    table = np.full((27, n), -1, np.int32)
+    w = np.ones((27, c, c), np.float32)
+    b = np.arange(c, dtype=np.float32) - 30
+    got = ops.conv_f32(_cuda(np.ones((n, c), np.float32)), _cuda(w), c, n, nbr=_cuda(table), n_offsets=27, nbr_ks=n,
+                       nbr_os=1, bias=_cuda(b), act=ops.ACT_RELU)
+    assert (got.cpu().numpy() == np.maximum(b, 0)[None]).all()
+    out = ops.conv_f32(torch.zeros((0, c), device='cuda'), _cuda(w[:1]), c, 0)
+    assert out.shape == (0, c)
+
+
+def test_argument_checks(ops):
+    x = torch.zeros((4, 8), device='cuda')
+    w = torch.zeros((8, 8), device='cuda')
+    with pytest.raises(ops.FpccError):
+        ops.conv_f32(x, torch.zeros((27, 8, 8), device='cuda'), 8, 4, n_offsets=27)        # no table for 27 offsets
+    with pytest.raises(ops.FpccError):
+        ops.conv_f32(x, w, 8, 4, act=ops.ACT_PRELU)                                          # PReLU without slope
+    with pytest.raises((ops.FpccError, TypeError)):
+        ops.conv_f32(x.cpu(), w, 8, 4)                                                       # host tensor

@@ -1,0 +1,143 @@
+"""Coordinate kernels of libfpcc_hip.so (through the C ABI) against the NumPy oracle: bit-exact integer work."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from util import batched, surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from fastpcc_amd import hipops
+    return hipops
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_morton_matches_golden_and_oracle(ops, golden_dir):
+    import json, os
+    with open(os.path.join(golden_dir, 'morton.json')) as f:
+        g = json.load(f)
+    xyz = np.array(g['xyz'], dtype=np.int64)
+    d = _dev(xyz, torch.int32)
+    cols = {'xyz': (0, 1, 2), 'zyx': (2, 1, 0), 'yxz': (1, 0, 2)}
+    for tag, keys in g['keys'].items():
+        order, inv = tag.split('|')
+        c = cols[order][::-1] if int(inv) else cols[order]
+        assert ops.morton3d_encode(d, c).cpu().tolist() == keys
+    # strided view (columns 1..3 of a [n,4] tensor), as model code passes xyz[:, 1:]
+    b = _dev(batched(xyz % 1024), torch.int32)
+    assert ops.morton3d_encode(b[:, 1:]).cpu().tolist() == oc.morton_encode(xyz % 1024).tolist()
+    assert ops.morton3d_encode(torch.zeros((0, 3), dtype=torch.int32, device='cuda')).numel() == 0
+
+
+@pytest.mark.parametrize('res,n', [(64, 20000), (256, 200000)])
+def test_pyramid_and_neighbour_tables(ops, res, n):
+    rng = np.random.default_rng(res)
+    xyz = surface_cloud(res, res, n)
+    shuffled = xyz[rng.permutation(len(xyz))]
+    coords = np.concatenate((batched(shuffled), batched(shuffled[:100])))       # with duplicates
+    bits = 21
+    keys = ops.keys_from_coords(_dev(coords, torch.int32), 0, bits)
+    skeys, perm = ops.sort_keys(keys)
+    ukeys, first, count = ops.unique_keys(skeys)
+    n_u = int(count.item())
+    lvl = oc.Level(batched(xyz), 1)
+    assert n_u == lvl.n
+    ukeys = ukeys[:n_u].contiguous()
+    assert ukeys.cpu().tolist() == oc.morton_encode(lvl.coords[:, 1:]).tolist()
+    # perm/first give an input row with the right coordinates
+    rows = perm[first[:n_u].long()].cpu().numpy()
+    assert (coords[rows] == lvl.coords).all()
+    back = ops.coords_from_keys(ukeys, 0, bits).cpu().numpy()
+    assert (back == lvl.coords).all()
+
+    # --- pyramid: coarsen until small, compare every level with the oracle's strided maps --------------------------
+    levels = [(ukeys, lvl, None, None)]
+    cur_keys, cur_lvl = ukeys, lvl
+    for l in range(1, 5):
+        parent_of, pkeys, child_row, cnt = ops.coarsen(cur_keys)
+        m = int(cnt.item())
+        up = oc.strided(cur_lvl)
+        assert m == up.n
+        pkeys = pkeys[:m].contiguous()
+        child_row = child_row[:m].contiguous()
+        assert ops.coords_from_keys(pkeys, l, bits - l).cpu().numpy().tolist() == up.coords.tolist()
+        km = oc.kernel_map(cur_lvl, up, 2)
+        want_child = oc.dense_table(km, up.n).T                                   # [m, 8]
+        assert (child_row.cpu().numpy() == want_child).all()
+        want_parent = np.empty(cur_lvl.n, dtype=np.int64)
+        for rows_in, rows_out in km:
+            want_parent[rows_in] = rows_out
+        assert (parent_of.cpu().numpy() == want_parent).all()
+        levels.append((pkeys, up, parent_of, child_row))
+        cur_keys, cur_lvl = pkeys, up
+
+    # --- 27-neighbour tables: search at the top, parent-derived below; both must equal the oracle -------------------
+    top_keys, top_lvl, _, _ = levels[-1]
+    nbr = ops.nbr27_search(top_keys, bits - (len(levels) - 1))
+    assert (nbr.cpu().numpy() == oc.dense_table(oc.kernel_map(top_lvl, top_lvl, 3), top_lvl.n)).all()
+    for li in range(len(levels) - 2, -1, -1):
+        keys_l, lvl_l, _, _ = levels[li]
+        _, _, parent_of, child_row = levels[li + 1]
+        nbr = ops.nbr27_from_parent(keys_l, parent_of, nbr, child_row)
+        want = oc.dense_table(oc.kernel_map(lvl_l, lvl_l, 3), lvl_l.n)
+        assert (nbr.cpu().numpy() == want).all()
+        if lvl_l.n < 60000:
+            assert (ops.nbr27_search(keys_l, bits - li).cpu().numpy() == want).all()
+
+    # --- generated set of level 1 and its neighbour table ------------------------------------------------------------
+    keys1, lvl1, _, _ = levels[1]
+    nbr1 = ops.nbr27_search(keys1, bits - 1)
+    gen = oc.generated(lvl1)
+    got = ops.nbr27_from_parent(None, None, nbr1, None).cpu().numpy()
+    assert (got == oc.dense_table(oc.kernel_map(gen, gen, 3), gen.n)).all()
+
+    # --- refine: a random mask over the candidates -------------------------------------------------------------------
+    mask = rng.random(8 * lvl1.n) < 0.4
+    keys_r, parent_r, child_r, cnt = ops.refine(keys1, _dev(mask.astype(np.uint8)))
+    n_r = int(cnt.item())
+    sub = oc.Level(gen.coords[mask], gen.stride)
+    assert n_r == sub.n == int(mask.sum())
+    assert ops.coords_from_keys(keys_r[:n_r].contiguous(), 0, bits).cpu().numpy().tolist() == sub.coords.tolist()
+    assert (parent_r[:n_r].cpu().numpy() == np.nonzero(mask)[0] // 8).all()
+    want_child = np.where(mask, np.cumsum(mask) - 1, -1).reshape(-1, 8)
+    assert (child_r.cpu().numpy() == want_child).all()
+    nbr_r = ops.nbr27_from_parent(keys_r[:n_r].contiguous(), parent_r[:n_r].contiguous(), nbr1, child_r)
+    assert (nbr_r.cpu().numpy() == oc.dense_table(oc.kernel_map(sub, sub, 3), sub.n)).all()
+    xyz_r, cnt2 = ops.compact_coords(keys1, _dev(mask.astype(np.uint8)), 0, bits,
+                                     _dev(np.array([7, 0, 3]), torch.int32))
+    assert int(cnt2.item()) == n_r
+    assert (xyz_r[:n_r].cpu().numpy() == sub.coords[:, 1:] + np.array([7, 0, 3])).all()
+
+
+def test_batched_clouds_do_not_mix(ops):
+    a, b = surface_cloud(11, 32, 3000), surface_cloud(12, 32, 3000)
+    coords = np.concatenate((batched(a, 0), batched(b, 1)))
+    bits = 20
+    keys = ops.keys_from_coords(_dev(coords, torch.int32), 0, bits)
+    skeys, _ = ops.sort_keys(keys)
+    lvl = oc.Level(coords, 1)
+    assert ops.coords_from_keys(skeys, 0, bits).cpu().numpy().tolist() == lvl.coords.tolist()
+    nbr = ops.nbr27_search(skeys, bits).cpu().numpy()
+    assert (nbr == oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)).all()
+
+
+def test_empty_and_tiny_inputs(ops):
+    e = torch.zeros(0, dtype=torch.int64, device='cuda')
+    s, p = ops.sort_keys(e)
+    assert s.numel() == 0 and p.numel() == 0
+    u, f, c = ops.unique_keys(e)
+    assert int(c.item()) == 0
+    one = ops.keys_from_coords(torch.tensor([[0, 5, 6, 7]], dtype=torch.int32, device='cuda'), 0, 21)
+    par, pk, cr, cnt = ops.coarsen(one)
+    assert int(cnt.item()) == 1 and par.cpu().tolist() == [0]
+    assert cr[0].cpu().tolist() == [-1, -1, -1, -1, -1, 0, -1, -1]      # (5,6,7): octant = (x&1) + 2(y&1) + 4(z&1) = 5

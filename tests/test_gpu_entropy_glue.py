@@ -1,0 +1,68 @@
+"""Small device kernels between the features and the coders, against NumPy/torch-CPU restatements of the reference lines."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from fastpcc_amd import hipops
+    return hipops
+
+
+def test_logit_to_prob16(ops):
+    rng = np.random.default_rng(0)
+    x = np.concatenate((rng.normal(0, 4, 200000), [-100, 100, 0, -20, 20, 11.09, -11.09, np.inf, -np.inf])).astype(np.float32)
+    got = ops.logit_to_prob16(torch.from_numpy(x).cuda()).cpu().numpy().view(np.uint16).astype(np.int64)
+    # geo_lossl_em.py:95-99 on the CPU
+    want = np.clip(np.round(torch.sigmoid(torch.from_numpy(x)).numpy().astype(np.float64) * 65536), 1, 65535).astype(np.int64)
+    assert np.abs(got - want).max() <= 1                 # one ulp of fp32 sigmoid may move the rounded value by one
+    assert np.mean(got != want) < 0.01
+    assert got.min() >= 1 and got.max() <= 65535
+
+
+def test_quantize_symbols(ops):
+    rng = np.random.default_rng(1)
+    x = np.concatenate((rng.uniform(-20, 20, 100000), [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 20, -20])).astype(np.float32)
+    for scale in (1.0, 4.0):
+        t = torch.from_numpy(x.copy()).cuda()
+        sym = ops.quantize_symbols_(t, scale)
+        r = torch.round(torch.from_numpy(x) * scale)       # half to even, like Tensor.round_()
+        assert (sym.cpu() == r.to(torch.int32)).all()
+        assert (t.cpu() == r / scale).all()
+
+
+def test_child_mask(ops):
+    cr = torch.tensor([[-1, 0, 1, -1, -1, 2, -1, -1], [3, -1, -1, -1, -1, -1, -1, 4]], dtype=torch.int32).cuda()
+    assert ops.child_mask(cr).cpu().tolist() == [0, 1, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1]
+
+
+def _keep_reference(v: np.ndarray, target: int) -> np.ndarray:
+    """Decoder.get_keep (lossy_coord_v2/layers.py:151-180) for one sample whose candidates are grouped by parent cell"""
+    cells = v.reshape(-1, 8)
+    not_max = (cells - cells.max(1, keepdims=True)) != 0
+    ranked = np.sort(cells[not_max])
+    thr = ranked[v.size - target - 1]
+    return ((cells > thr) | ~not_max).reshape(-1)
+
+
+@pytest.mark.parametrize('m,frac', [(1, 0.5), (37, 0.3), (5000, 0.26), (200000, 0.5)])
+def test_topk_keep(ops, m, frac):
+    rng = np.random.default_rng(m)
+    v = rng.normal(size=8 * m).astype(np.float32)
+    target = max(m, int(8 * m * frac))
+    if target >= 8 * m:
+        target = 8 * m - 1
+    got = ops.topk_keep(torch.from_numpy(v).cuda(), target).cpu().numpy().astype(bool)
+    want = _keep_reference(v, target)
+    assert (got == want).all()
+    assert got.sum() == target                                  # no ties in continuous random data
+
+
+def test_topk_keep_with_ties(ops):
+    v = np.array([1, 1, 0, 0, 0, 0, 0, 0, 3, 2, 2, 2, 1, 1, 1, 1], dtype=np.float32)
+    for target in (2, 3, 5, 9, 15):
+        got = ops.topk_keep(torch.from_numpy(v).cuda(), target).cpu().numpy().astype(bool)
+        assert (got == _keep_reference(v, target)).all()

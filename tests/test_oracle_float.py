@@ -1,0 +1,91 @@
+"""Self-consistency of the float oracle (MinkowskiEngine is not available): the two evaluations
+of the convolution sum agree, kernel maps obey the restated ME semantics, and the oracle codec round-trips."""
+import numpy as np
+import torch
+
+from fastpcc_amd.codecs.lossy_coord_v2 import Model
+from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+from oracle import coords as oc
+from oracle import sparse_conv as sc
+from oracle.codec_v2 import OracleV2
+from util import batched, enliven, surface_cloud
+
+
+def test_kernel_offsets_order():
+    # first axis fastest, odd kernels centred, even kernels anchored at 0 (semantics (ii))
+    o3 = oc.kernel_offsets(3, 2)
+    assert o3[0].tolist() == [-2, -2, -2] and o3[1].tolist() == [0, -2, -2] and o3[13].tolist() == [0, 0, 0]
+    assert o3[26].tolist() == [2, 2, 2] and o3[3].tolist() == [-2, 0, -2]
+    o2 = oc.kernel_offsets(2, 1)
+    assert o2.tolist() == [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]]
+
+
+def test_levels_and_maps():
+    xyz = surface_cloud(3, 32, 4000)
+    lvl = oc.Level(batched(xyz), 1)
+    assert lvl.n == len(xyz)
+    assert (np.diff(oc.morton_encode(lvl.coords[:, 1:])) > 0).all()          # Morton order, unique
+    up = oc.strided(lvl)
+    assert (up.coords[:, 1:] % 2 == 0).all()
+    km = oc.kernel_map(lvl, up, 2)
+    assert sum(len(i) for i, _ in km) == lvl.n                                 # every voxel has exactly one parent
+    for k, (rows_in, rows_out) in enumerate(km):
+        d = lvl.coords[rows_in, 1:] - up.coords[rows_out, 1:]
+        assert (d == oc.kernel_offsets(2, 1)[k]).all()
+    gen = oc.generated(up)
+    assert gen.n == 8 * up.n
+    # generated rows are (parent, octant) ordered: row 8p+k = parent + offset_k
+    assert (gen.coords.reshape(up.n, 8, 4)[:, :, 1:] - up.coords[:, None, 1:] == oc.kernel_offsets(2, 1)[None]).all()
+    k3 = oc.kernel_map(lvl, lvl, 3)
+    assert (k3[13][0] == k3[13][1]).all() and len(k3[13][0]) == lvl.n
+    for k in range(27):                                                         # symmetry of the neighbourhood relation
+        a = set(zip(k3[k][0].tolist(), k3[k][1].tolist()))
+        b = set(zip(k3[26 - k][1].tolist(), k3[26 - k][0].tolist()))
+        assert a == b
+
+
+def test_conv_mm_equals_chain():
+    rng = np.random.default_rng(0)
+    xyz = surface_cloud(5, 32, 3000)
+    lvl = oc.Level(batched(xyz), 1)
+    kmap = oc.kernel_map(lvl, lvl, 3)
+    for c_in, c_out in ((1, 16), (16, 8), (32, 32)):
+        x = rng.normal(size=(lvl.n, c_in)).astype(np.float32)
+        w = (rng.normal(size=(27, c_in, c_out)) / np.sqrt(13 * c_in)).astype(np.float32)
+        b = rng.normal(size=c_out).astype(np.float32)
+        ref = sc.conv_mm(torch.from_numpy(x), kmap, torch.from_numpy(w), torch.from_numpy(b), lvl.n, sc.ACT_PRELU, 0.25).numpy()
+        for order in (0, 1) if c_in % 8 == 0 else (0,):
+            got = sc.conv_chain_kmap(x, kmap, w, b, lvl.n, act=sc.ACT_PRELU, slope=0.25, order=order)
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+    # two-source input == concatenated input, bit for bit
+    x1 = rng.normal(size=(lvl.n, 8)).astype(np.float32)
+    x2 = rng.normal(size=(lvl.n, 8)).astype(np.float32)
+    w = rng.normal(size=(27, 16, 4)).astype(np.float32)
+    a = sc.conv_chain_kmap(np.concatenate((x1, x2), 1), kmap, w, None, lvl.n)
+    b = sc.conv_chain_kmap(x1, kmap, w, None, lvl.n, x2=x2)
+    assert (a == b).all()
+
+
+def test_oracle_codec_roundtrip_and_modes_agree():
+    cfg = baseline_r1()
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, 0)
+    xyz = surface_cloud(1, 64, 6000)
+    coords = batched(xyz) + np.array([0, 5, 0, 9])
+    streams = {}
+    for mode in ('mm', 'chain'):
+        o = OracleV2(model.state_dict(), cfg, conv=mode)
+        data = o.compress(coords)
+        rec = o.decompress(data)
+        streams[mode] = (data, o.symbols)
+        assert rec.shape == (len(xyz), 3)                     # adaptive pruning returns exactly the coded point count
+        assert rec.min(0).tolist() >= coords[:, 1:].min(0).tolist()
+        # header: offsets then the point count
+        lo = coords[:, 1:].min(0)
+        assert [int.from_bytes(data[i:i + 2], 'little') for i in (0, 2, 4)] == lo.tolist()
+        assert int.from_bytes(data[6:9], 'little') == len(xyz)
+    # the two evaluations of the convolution sum differ only by fp32 rounding: symbol streams nearly identical
+    ra, rb = streams['mm'][1]['residual'], streams['chain'][1]['residual']
+    assert ra.shape == rb.shape and np.mean(ra != rb) < 0.02
+    assert abs(len(streams['mm'][0]) - len(streams['chain'][0])) <= 0.02 * len(streams['mm'][0])
