@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encode+decode throughput of lossy_coord_v2/baseline_r1 on a 1M-voxel synthetic frame.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = compress(frame) + decompress(bytes) of one frame resident in HBM, each closed by a device synchronise, exactly
+how the reference times 'encode time' / 'decode time' (models/convolutional/lossy_coord_v2/model.py:196-205).
+Frames are independent, so N GPUs run N replicas on N different frames (weak scaling, no data-path collective; SURVEY.md
+section 8e).  Weights: seeded random initialisation of the architecture (no checkpoints exist here); data: seeded
+synthetic voxel surface (fastpcc_amd/synthetic.py).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+MFMA_PEAK_TFLOPS = 157.3       # fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--resolution', type=int, default=1024, help='1024 -> ~1M voxels (cfg#2)')
+    ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
+    ap.add_argument('--cpu-resolution', type=int, default=256, help='resolution of the bounded CPU sample')
+    return ap.parse_args()
+
+
+def conv_flops(info, counts_cache):
+    """algorithmic flop of one conv launch: 2 * L * C_in * C_out with L = rulebook pairs actually present"""
+    import torch
+    if info['nbr'] is None:
+        pairs = info['n_out'] * info['groups']
+    else:
+        key = (info['nbr'].data_ptr(), info['n_offsets'], info['n_out'])
+        if key not in counts_cache:
+            t = info['nbr']
+            counts_cache[key] = int((t >= 0).sum().item()) if t.numel() else 0
+        pairs = counts_cache[key]
+    return 2.0 * pairs * info['c_in'] * info['c_out']
+
+
+def cpu_baseline(cfg, weights, resolution):
+    """the CPU oracle (plain C restatement, OpenMP over output rows) timed on a bounded sample of the same workload"""
+    import numpy as np
+    import oracle
+    from oracle.codec_v2 import OracleV2
+    from fastpcc_amd import hipops
+    from fastpcc_amd.synthetic import batched, body_cloud
+    oracle.build()
+    xyz = body_cloud(resolution, 1.0)
+    coords = batched(xyz).astype(np.int64)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=hipops.conv_order)
+    o.compress(batched(xyz[: min(len(xyz), 2000)]).astype(np.int64))      # warm-up (library load, thread pool)
+    t0 = time.perf_counter()
+    data = o.compress(coords)
+    t1 = time.perf_counter()
+    rec = o.decompress(data)
+    t2 = time.perf_counter()
+    assert rec.shape[0] == len(xyz)
+    return {'value': round(len(xyz) / (t2 - t0) / 1e6, 5), 'unit': 'Mpoints/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'same generator at {resolution}^3: {len(xyz)} voxels, 1 encode + 1 decode, '
+                      f'enc {t1 - t0:.2f}s dec {t2 - t1:.2f}s, oracle/sparse_conv.c with OpenMP'}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://')
+
+    from util import enliven
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+    from fastpcc_amd.synthetic import SCALE, batched, body_cloud
+    from fastpcc_amd import engine as ME
+
+    cfg = baseline_r1()
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, 0)
+    weights = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+
+    # every rank codes its own frame (different seed), all ~1M voxels
+    xyz = body_cloud(args.resolution, SCALE.get(args.resolution, 1.0), seed=2 + rank)
+    frame = torch.from_numpy(batched(xyz)).cuda()
+    n_points = frame.shape[0]
+
+    def step():
+        data = model.compress(frame)
+        torch.cuda.synchronize()
+        ME.clear_global_coordinate_manager()
+        rec = model.decompress(data)
+        torch.cuda.synchronize()
+        ME.clear_global_coordinate_manager()
+        return data, rec
+
+    for _ in range(args.warmup):
+        data, rec = step()
+    assert rec.shape[0] == n_points
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    hipops.CONV_TRACE = []
+    t_enc = t_dec = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a = time.perf_counter()
+        data = model.compress(frame)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        ME.clear_global_coordinate_manager()
+        rec = model.decompress(data)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        ME.clear_global_coordinate_manager()
+        t_enc += b - a
+        t_dec += c - b
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trace, hipops.CONV_TRACE = hipops.CONV_TRACE, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    pts = torch.tensor([float(n_points)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t.item())
+    total_points = float(pts.item()) * args.steps
+
+    if rank == 0:
+        # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
+        cache = {}
+        flops = ms = 0.0
+        n_launch = 0
+        ms_valu = 0.0
+        for ev0, ev1, info in trace:
+            dt = ev0.elapsed_time(ev1)
+            if info['mfma']:
+                flops += conv_flops(info, cache)
+                ms += dt
+                n_launch += 1
+            else:
+                ms_valu += dt
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            'metric': 'encode+decode Mpoints/sec, lossy_coord_v2 baseline_r1',
+            'value': round(total_points / elapsed_max / 1e6, 4),
+            'unit': 'Mpoints/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed_max / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'lossy_coord_v2/baseline_r1 inference, {n_points}-voxel {args.resolution}^3 '
+                                   f'body-surface frame per GPU (cfg#2), seeded random-init weights',
+                       'parallelism': f'replicas x{world} (independent frames)' if world > 1 else 'single GPU',
+                       'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
+                       'bytes': len(data), 'bpp': round(8 * len(data) / n_points, 4)},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'k_conv_mfma (fp32 gather->MFMA sparse convolution)',
+                         'launches_per_step': n_launch // max(args.steps, 1),
+                         'kernel_ms_per_step': round(ms / args.steps, 3),
+                         'algorithmic_gflop_per_step': round(flops / args.steps / 1e9, 2),
+                         'other_conv_ms_per_step': round(ms_valu / args.steps, 3)},
+        }
+        if args.cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(cfg, weights, args.cpu_resolution)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

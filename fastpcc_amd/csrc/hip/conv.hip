@@ -308,6 +308,7 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
                              int64_t n_out, int act, const float *slope, float clip, void *stream) {
     if (n_out < 0 || c1 < 1 || c2 < 0 || c_out < 1 || groups < 1 || n_offsets < 1 || n_offsets > 32)
         return fail_arg("conv_f32: sizes out of range (n_offsets must be 1..32)");
+    if (n_out == 0) return FPCC_OK;
     if (!x1 || !w || !out || (c2 > 0 && !x2)) return fail_arg("conv_f32: null pointer");
     if (!nbr && n_offsets != 1) return fail_arg("conv_f32: identity map needs n_offsets == 1");
     if (ld1 < c1 || (c2 > 0 && ld2 < c2) || ldo < c_out) return fail_arg("conv_f32: row stride smaller than the row");

@@ -211,6 +211,11 @@ def _rows2d(t: torch.Tensor, name: str):
     return t.data_ptr(), t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
 
 
+# When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
+# bench.py to time the dominant kernel inside the timed region (events only, no synchronisation).
+CONV_TRACE = None
+
+
 def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: Optional[torch.Tensor] = None,
              nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1,
              bias: Optional[torch.Tensor] = None, groups: int = 1, out_map: Optional[torch.Tensor] = None,
@@ -233,10 +238,20 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         raise ValueError('output width mismatch')
     if om_os == 0:
         om_os = groups
+    trace = CONV_TRACE
+    if trace is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _ok(lib().fpcc_conv_f32(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
                             w.data_ptr(), _dev(bias, torch.float32, 'bias', True), c_out, groups,
                             _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
                             _dev(slope, torch.float32, 'slope', True), float(clip), _stream()))
+    if trace is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out)), 'c_in': c1 + c2, 'c_out': c_out,
+                                 'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
+                                 'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
     return out
 
 

@@ -1,0 +1,54 @@
+"""Seeded synthetic voxel clouds for benchmarks and tests (no datasets are available): SURVEY.md section 8d.
+
+`body_cloud` is the stand-in for an 8iVFB frame (cfg#2): a closed, one-voxel-thick surface made of a torso, a head and
+two limbs (ellipsoids), voxelised by dense parametric sampling; `scale` is tuned so that the named resolutions give the
+named voxel counts."""
+from typing import Tuple
+
+import numpy as np
+
+# (centre, radii) in units of the resolution
+_BODY = (
+    ((0.50, 0.50, 0.45), (0.16, 0.10, 0.26)),    # torso
+    ((0.50, 0.50, 0.80), (0.075, 0.08, 0.09)),   # head
+    ((0.36, 0.50, 0.30), (0.05, 0.055, 0.28)),   # limb
+    ((0.64, 0.50, 0.30), (0.05, 0.055, 0.28)),   # limb
+)
+
+
+def _ellipsoid_surface(rng, centre, radii, n):
+    # area-uniform enough for voxelisation: sample the sphere, stretch, oversample
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return centre + d * radii
+
+
+def body_cloud(resolution: int = 1024, scale: float = 1.0, seed: int = 2, samples_per_voxel: float = 7.0) -> np.ndarray:
+    """unique int32 voxels [n, 3] of the union surface, inside [0, resolution)^3"""
+    rng = np.random.default_rng(seed)
+    parts = []
+    ells = [(np.array(c) * resolution, np.array(r) * resolution * scale) for c, r in _BODY]
+    for centre, radii in ells:
+        a, b, c = radii
+        area = 4 * np.pi * (((a * b) ** 1.6 + (a * c) ** 1.6 + (b * c) ** 1.6) / 3) ** (1 / 1.6)
+        pts = _ellipsoid_surface(rng, centre, radii, int(area * samples_per_voxel))
+        keep = np.ones(len(pts), bool)
+        for c2, r2 in ells:                       # drop what lies strictly inside another part: union surface
+            if c2 is centre:
+                continue
+            keep &= (((pts - c2) / r2) ** 2).sum(1) >= 1.0
+        parts.append(pts[keep])
+    p = np.round(np.concatenate(parts)).astype(np.int32)
+    p = p[((p >= 0) & (p < resolution)).all(1)]
+    # unique via a packed key (faster than np.unique(axis=0))
+    key = (p[:, 0].astype(np.int64) << 42) | (p[:, 1].astype(np.int64) << 21) | p[:, 2].astype(np.int64)
+    key = np.unique(key)
+    return np.stack(((key >> 42), (key >> 21) & 0x1fffff, key & 0x1fffff), 1).astype(np.int32)
+
+
+# scale factors calibrated so that body_cloud(res, SCALE[res]) has the voxel count BASELINE.json names (+-1 %)
+SCALE = {1024: 1.25, 2048: 0.735}      # 997 645 voxels at 10 bit (cfg#2), 1 997 208 at 11 bit (cfg#4)
+
+
+def batched(xyz: np.ndarray, batch: int = 0) -> np.ndarray:
+    return np.concatenate((np.full((len(xyz), 1), batch, dtype=np.int32), xyz.astype(np.int32)), 1)

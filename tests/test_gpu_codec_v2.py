@@ -84,6 +84,7 @@ def test_layer_activations_bit_exact(setup):
     cfg, model, weights, ops = setup
     from fastpcc_amd import engine as ME
     xyz, coords = _cloud(2, 64, 12000)
+    coords[:, 1:] -= coords[:, 1:].min(0)                # compress() codes coordinates relative to their minimum
     dev = torch.from_numpy(coords).to(torch.int32).cuda()
     o = OracleV2(weights, cfg, conv='chain', order_fn=ops.conv_order)
     o.keep_trace = True
