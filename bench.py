@@ -32,6 +32,7 @@ def parse():
     ap.add_argument('--resolution', type=int, default=1024, help='1024 -> ~1M voxels (cfg#2)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
     ap.add_argument('--cpu-resolution', type=int, default=256, help='resolution of the bounded CPU sample')
+    ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
 
 
@@ -167,6 +168,17 @@ def main():
             else:
                 ms_valu += dt
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if args.dump_trace:
+            per_step = len(trace) // args.steps
+            with open(args.dump_trace, 'w') as f:
+                f.write('kind c_in c_out n_out n_off groups ms algo_gflop algo_tflops dense_tflops\n')
+                for ev0, ev1, info in trace[-per_step:]:
+                    dt = ev0.elapsed_time(ev1)
+                    fl = conv_flops(info, cache)
+                    dense = 2.0 * info['n_out'] * info['groups'] * info['n_offsets'] * info['c_in'] * info['c_out']
+                    f.write(f"{'mfma' if info['mfma'] else 'valu'} {info['c_in']} {info['c_out']} {info['n_out']} "
+                            f"{info['n_offsets']} {info['groups']} {dt:.4f} {fl / 1e9:.3f} {fl / dt / 1e9:.2f} "
+                            f"{dense / dt / 1e9:.2f}\n")
         out = {
             'metric': 'encode+decode Mpoints/sec, lossy_coord_v2 baseline_r1',
             'value': round(total_points / elapsed_max / 1e6, 4),
