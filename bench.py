@@ -55,12 +55,12 @@ def cpu_baseline(cfg, weights, resolution):
     import numpy as np
     import oracle
     from oracle.codec_v2 import OracleV2
-    from fastpcc_amd import hipops
+    from fastpcc_amd.engine import summation_order as ME_order
     from fastpcc_amd.synthetic import batched, body_cloud
     oracle.build()
     xyz = body_cloud(resolution, 1.0)
     coords = batched(xyz).astype(np.int64)
-    o = OracleV2(weights, cfg, conv='chain', order_fn=hipops.conv_order)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     o.compress(batched(xyz[: min(len(xyz), 2000)]).astype(np.int64))      # warm-up (library load, thread pool)
     t0 = time.perf_counter()
     data = o.compress(coords)

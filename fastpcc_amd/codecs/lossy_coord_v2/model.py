@@ -81,7 +81,7 @@ class PCC(nn.Module):
     def compress(self, batched_coord: torch.Tensor) -> bytes:
         if not batched_coord.is_cuda:
             raise RuntimeError('compress() runs on the GPU; move the coordinates there first')
-        coord_offset = batched_coord[:, 1:].amin(0)
+        coord_offset = batched_coord.amin(0)[1:]        # reduce the contiguous [n, 4] tensor, then drop the batch column
         sparse_pc = self.get_sparse_pc((batched_coord - F.pad(coord_offset, (1, 0))).contiguous())
         feature, points_num_list = self.encoder(sparse_pc)
         em_bytes = self.em_lossless_based.compress(feature, 1)

@@ -49,132 +49,147 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
 }
 
-constexpr int kTileRows = 128;
-
 template <int CH>
 __device__ __forceinline__ int swz(int r) {
     // 16-byte piece index XOR so that the 16 lanes of a ds_read_b128 group land on 16 different bank slots
     return CH == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3);
 }
 
-template <int NB, int CH>
+constexpr int kMaxOffsets = 27;   // the MFMA kernel keeps the tile's neighbour indices in LDS: [27][rows]
+
+// Tile geometry.  A workgroup of WM x WN waves owns TM = 32*WM output rows and all 32*NBT output columns; wave (wr, wc)
+// computes rows [32*wr, 32*wr+32) x column blocks [wc*NBW, (wc+1)*NBW).  Large maps use 128-row tiles (4x1 waves);
+// small maps use 64- or 32-row tiles with the waves spread over the columns instead, so that a level with a few
+// thousand rows still fills the 256 CUs and its chain of (offset, chunk) stages is 4x shorter per wave.
+template <int NBT, int CH, int WM, int WN>
 struct MfmaCfg {
-    static constexpr int C_OUT = 32 * NB;
-    static constexpr int PPR = CH / 4;                        // 16-byte pieces per gathered row chunk
-    static constexpr int A_PIECES = kTileRows * PPR / 256;    // per thread
-    static constexpr int W_TOTAL = CH * C_OUT / 4;            // 16-byte pieces of one weight chunk
-    static constexpr int W_PIECES = (W_TOTAL + 255) / 256;
+    static constexpr int C_OUT = 32 * NBT;
+    static constexpr int TM = 32 * WM;
+    static constexpr int NBW = NBT / WN;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int PPR = CH / 4;                               // 16-byte pieces per gathered row chunk
+    static constexpr int A_TOTAL = TM * PPR;
+    static constexpr int A_PIECES = (A_TOTAL + THREADS - 1) / THREADS;
+    static constexpr int W_TOTAL = CH * C_OUT / 4;                   // 16-byte pieces of one weight chunk
+    static constexpr int W_PIECES = (W_TOTAL + THREADS - 1) / THREADS;
+    static_assert(NBT % WN == 0, "column blocks must divide over the waves");
 };
 
 // global -> registers for stage (k, cc)
-template <int NB, int CH>
-__device__ __forceinline__ void stage_fetch(const ConvArgs &a, const float *wg, int64_t row0, int c_in, int tid, int k,
-                                            int cc, f32x4 (&ra)[MfmaCfg<NB, CH>::A_PIECES],
-                                            f32x4 (&rw)[MfmaCfg<NB, CH>::W_PIECES]) {
-    using C = MfmaCfg<NB, CH>;
+template <typename C, int CH>
+__device__ __forceinline__ void stage_fetch(const ConvArgs &a, const float *wg, const int32_t *s_nbr, int c_in, int tid,
+                                            int k, int cc, f32x4 (&ra)[C::A_PIECES], f32x4 (&rw)[C::W_PIECES]) {
     // the chunk lies entirely in x1 or entirely in x2 (c1 is a multiple of CH): a scalar choice, no per-lane branch
     const bool in_x1 = cc * CH < a.c1;
     const float *xb = in_x1 ? a.x1 + cc * CH : a.x2 + (cc * CH - a.c1);
     const int64_t ld = in_x1 ? a.ld1 : a.ld2;
-    const int32_t *nk = a.nbr ? a.nbr + (int64_t)k * a.nbr_ks : nullptr;
 #pragma unroll
     for (int j = 0; j < C::A_PIECES; ++j) {
-        const int p = tid + 256 * j;
-        const int r = p / C::PPR, q = p % C::PPR;
-        const int64_t row = row0 + r;
-        int32_t idx = (int32_t)row;
-        if (nk) idx = nk[(row < a.n_out ? row : 0) * a.nbr_os];
-        if (row >= a.n_out) idx = -1;
-        const float *src = idx >= 0 ? xb + (int64_t)idx * ld + 4 * q : (const float *)g_zero_row;
-        ra[j] = *reinterpret_cast<const f32x4 *>(src);
+        const int p = tid + C::THREADS * j;
+        if (C::A_TOTAL % C::THREADS == 0 || p < C::A_TOTAL) {
+            const int r = p / C::PPR, q = p % C::PPR;
+            const int32_t idx = s_nbr[k * C::TM + r];
+            const float *src = idx >= 0 ? xb + (int64_t)idx * ld + 4 * q : (const float *)g_zero_row;
+            ra[j] = *reinterpret_cast<const f32x4 *>(src);
+        }
     }
     const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wg + ((int64_t)k * c_in + (int64_t)cc * CH) * C::C_OUT);
 #pragma unroll
     for (int j = 0; j < C::W_PIECES; ++j) {
-        const int p = tid + 256 * j;
-        rw[j] = (C::W_TOTAL % 256 == 0 || p < C::W_TOTAL) ? wsrc[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int p = tid + C::THREADS * j;
+        if (C::W_TOTAL % C::THREADS == 0 || p < C::W_TOTAL) rw[j] = wsrc[p];
     }
 }
 
 // registers -> LDS buffer
-template <int NB, int CH>
-__device__ __forceinline__ void stage_stash(float *dA, float *dWf, int tid,
-                                            const f32x4 (&ra)[MfmaCfg<NB, CH>::A_PIECES],
-                                            const f32x4 (&rw)[MfmaCfg<NB, CH>::W_PIECES]) {
-    using C = MfmaCfg<NB, CH>;
+template <typename C, int CH>
+__device__ __forceinline__ void stage_stash(float *dA, float *dWf, int tid, const f32x4 (&ra)[C::A_PIECES],
+                                            const f32x4 (&rw)[C::W_PIECES]) {
 #pragma unroll
     for (int j = 0; j < C::A_PIECES; ++j) {
-        const int p = tid + 256 * j;
-        const int r = p / C::PPR, q = p % C::PPR;
-        *reinterpret_cast<f32x4 *>(dA + r * CH + 4 * (q ^ swz<CH>(r))) = ra[j];
+        const int p = tid + C::THREADS * j;
+        if (C::A_TOTAL % C::THREADS == 0 || p < C::A_TOTAL) {
+            const int r = p / C::PPR, q = p % C::PPR;
+            *reinterpret_cast<f32x4 *>(dA + r * CH + 4 * (q ^ swz<CH>(r))) = ra[j];
+        }
     }
     f32x4 *dW = reinterpret_cast<f32x4 *>(dWf);
 #pragma unroll
     for (int j = 0; j < C::W_PIECES; ++j) {
-        const int p = tid + 256 * j;
-        if (C::W_TOTAL % 256 == 0 || p < C::W_TOTAL) dW[p] = rw[j];
+        const int p = tid + C::THREADS * j;
+        if (C::W_TOTAL % C::THREADS == 0 || p < C::W_TOTAL) dW[p] = rw[j];
     }
 }
 
-template <int NB, int CH>
-__device__ __forceinline__ void stage_compute(const float *cA, const float *cW, int wave, int li, int lh,
-                                              f32x16 (&acc)[NB]) {
-    constexpr int C_OUT = 32 * NB;
-    const int r = wave * 32 + li;
+template <typename C, int CH>
+__device__ __forceinline__ void stage_compute(const float *cA, const float *cW, int wr, int wc, int li, int lh,
+                                              f32x16 (&acc)[C::NBW]) {
+    constexpr int C_OUT = C::C_OUT;
+    constexpr int NBW = C::NBW;
+    const int r = wr * 32 + li;
 #pragma unroll
     for (int g8 = 0; g8 < CH / 8; ++g8) {
         const int q = 2 * g8 + lh;
         const f32x4 av = *reinterpret_cast<const f32x4 *>(cA + r * CH + 4 * (q ^ swz<CH>(r)));
-        const float *wrow = cW + (8 * g8 + 4 * lh) * C_OUT + li;
+        const float *wrow = cW + (8 * g8 + 4 * lh) * C_OUT + 32 * wc * NBW + li;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wrow[32 * nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wrow[32 * nb], acc[nb], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wrow[C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wrow[C_OUT + 32 * nb], acc[nb], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wrow[2 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wrow[2 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wrow[3 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wrow[3 * C_OUT + 32 * nb], acc[nb], 0, 0, 0);
     }
 }
 
-template <int NB, int CH>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
-    using C = MfmaCfg<NB, CH>;
+template <int NBT, int CH, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(ConvArgs a) {
+    using C = MfmaCfg<NBT, CH, WM, WN>;
     constexpr int C_OUT = C::C_OUT;
+    constexpr int TM = C::TM;
+    constexpr int NBW = C::NBW;
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * kTileRows * CH + 2 * CH * C_OUT];
-    __shared__ unsigned s_mask[4];
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * CH + 2 * CH * C_OUT];
+    __shared__ int32_t s_nbr[kMaxOffsets * TM];
+    __shared__ unsigned s_mask[WM];
     float *sA = smem;
-    float *sW = smem + 2 * kTileRows * CH;
+    float *sW = smem + 2 * TM * CH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WM, wc = wave / WM;
     const int li = lane & 31, lh = lane >> 5;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int g = blockIdx.y;
-    const int64_t row0 = (int64_t)tile * kTileRows;
+    const int64_t row0 = (int64_t)tile * TM;
     const int c_in = a.c1 + a.c2;
     const int n_chunks = c_in / CH;
     const float *wg = a.w + (int64_t)g * a.n_off * c_in * C_OUT;
 
-    // which offsets occur in this wave's 32 rows / in the whole tile
-    unsigned wmask = 0;
-    {
-        const int64_t myrow = row0 + wave * 32 + li;
-        for (int k = 0; k < a.n_off; ++k) {
-            int32_t v = -1;
-            if (myrow < a.n_out) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + myrow * a.nbr_os] : (int32_t)myrow;
-            if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
-        }
-        if (lane == 0) s_mask[wave] = wmask;
+    // the tile's neighbour table -> LDS (rows past the end count as absent)
+    for (int e = tid; e < a.n_off * TM; e += C::THREADS) {
+        const int k = e / TM, r = e % TM;
+        const int64_t row = row0 + r;
+        int32_t v = -1;
+        if (row < a.n_out) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + row * a.nbr_os] : (int32_t)row;
+        s_nbr[e] = v;
     }
     __syncthreads();
-    const unsigned tmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    // which offsets occur in this wave's 32 rows / in the whole tile
+    unsigned wmask = 0;
+    for (int k = 0; k < a.n_off; ++k)
+        if (__ballot(s_nbr[k * TM + wr * 32 + li] >= 0) != 0ull) wmask |= 1u << k;
+    if (lane == 0 && wc == 0) s_mask[wr] = wmask;
+    __syncthreads();
+    unsigned tmask = 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) tmask |= s_mask[i];
     const int n_stages = __popc(tmask) * n_chunks;
 
-    f32x16 acc[NB];
+    f32x16 acc[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 
@@ -185,8 +200,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
         unsigned rest = tmask;
         int k_cur = __ffs(rest) - 1;
         int k_next = k_cur, cc_next = 0;
-        stage_fetch<NB, CH>(a, wg, row0, c_in, tid, k_cur, 0, ra, rw);
-        stage_stash<NB, CH>(sA, sW, tid, ra, rw);
+        stage_fetch<C, CH>(a, wg, s_nbr, c_in, tid, k_cur, 0, ra, rw);
+        stage_stash<C, CH>(sA, sW, tid, ra, rw);
         __syncthreads();
         for (int s = 0; s < n_stages; ++s) {
             if (++cc_next == n_chunks) {
@@ -195,10 +210,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
                 k_next = rest ? __ffs(rest) - 1 : 0;
             }
             const bool more = s + 1 < n_stages;
-            if (more) stage_fetch<NB, CH>(a, wg, row0, c_in, tid, k_next, cc_next, ra, rw);
+            if (more) stage_fetch<C, CH>(a, wg, s_nbr, c_in, tid, k_next, cc_next, ra, rw);
             if ((wmask >> k_cur) & 1u)
-                stage_compute<NB, CH>(sA + (s & 1) * kTileRows * CH, sW + (s & 1) * CH * C_OUT, wave, li, lh, acc);
-            if (more) stage_stash<NB, CH>(sA + ((s + 1) & 1) * kTileRows * CH, sW + ((s + 1) & 1) * CH * C_OUT, tid, ra, rw);
+                stage_compute<C, CH>(sA + (s & 1) * TM * CH, sW + (s & 1) * CH * C_OUT, wr, wc, li, lh, acc);
+            if (more) stage_stash<C, CH>(sA + ((s + 1) & 1) * TM * CH, sW + ((s + 1) & 1) * CH * C_OUT, tid, ra, rw);
             __syncthreads();
             k_cur = k_next;
         }
@@ -207,13 +222,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int64_t o = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        const int64_t o = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
         if (o >= a.n_out) continue;
         const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
         if (dst < 0) continue;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = 32 * nb + li;
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int col = 32 * (wc * NBW + nb) + li;
             const float b = a.bias ? a.bias[col] : 0.0f;
             a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
         }
@@ -281,11 +296,22 @@ int mfma_chunk(int c1, int c2, int c_out) {
     return 0;
 }
 
-template <int NB, int CH>
-int launch_mfma(const ConvArgs &a, hipStream_t s) {
-    const unsigned tiles = (unsigned)((a.n_out + kTileRows - 1) / kTileRows);
-    hipLaunchKernelGGL((k_conv_mfma<NB, CH>), dim3(tiles, a.groups), dim3(256), 0, s, a);
+template <int NBT, int CH, int WM, int WN>
+int launch_mfma_cfg(const ConvArgs &a, hipStream_t s) {
+    constexpr int TM = 32 * WM;
+    const unsigned tiles = (unsigned)((a.n_out + TM - 1) / TM);
+    hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN>), dim3(tiles, a.groups), dim3(64 * WM * WN), 0, s, a);
     return check_hip(hipGetLastError(), "k_conv_mfma");
+}
+
+// pick the tile height so that the launch has at least ~2 workgroups per CU when the map allows it
+template <int NBT, int CH>
+int launch_mfma(const ConvArgs &a, hipStream_t s) {
+    const int64_t work = a.n_out * a.groups;
+    constexpr int WNS = NBT >= 2 ? 2 : 1;       // 64-row tile: 2 x WNS waves
+    if (work >= 128 * 1024) return launch_mfma_cfg<NBT, CH, 4, 1>(a, s);
+    if (work >= 64 * 512) return launch_mfma_cfg<NBT, CH, 2, WNS>(a, s);
+    return launch_mfma_cfg<NBT, CH, 1, NBT>(a, s);
 }
 
 template <int JB>
@@ -321,6 +347,7 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
                out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip};
     hipStream_t s = as_stream(stream);
     int ch = mfma_chunk(c1, c2, c_out);
+    if (ch && n_offsets > kMaxOffsets) return fail_arg("conv_f32: the MFMA path supports at most 27 kernel offsets");
     if (ch && !(aligned16(x1) && ld1 % 4 == 0 && aligned16(w) && (c2 == 0 || (aligned16(x2) && ld2 % 4 == 0))))
         return fail_arg("conv_f32: the MFMA path needs 16-byte aligned inputs and row strides that are multiples of 4");
     if (ch == 32) {
@@ -361,4 +388,43 @@ extern "C" int fpcc_gather_rows_f32(const float *x, int c, int ld, const int32_t
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(n * c, 256)), dim3(256), 0, as_stream(stream), x, c, ld, index, n,
                        out, ldo);
     return check_hip(hipGetLastError(), "k_gather_rows");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second half of a single-output-channel 3x3x3 convolution.  With C_out == 1 the convolution is
+//      out[o] = sum_k < X[nbr_k(o), :], w_k >  =  sum_k Y[nbr_k(o), k],      Y = X @ [w_0 | w_1 | ... | w_26]
+// so the dot products run once per INPUT row on the MFMA kernel (a pointwise GEMM with 27 -> 32 output columns) and this
+// kernel only gathers 27 scalars per output row: 27 x 4 B instead of 27 x C_in x 4 B of gather traffic.
+// Summation order ("order 2" of fpcc_hip.h): per offset the dot product is its own FMA chain from zero, the offsets'
+// partial sums are added in ascending offset order, then the bias -- which is the order of a per-offset
+// gather-GEMM-scatter-add evaluation.
+namespace fpcc {
+namespace {
+__global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ y, int ldy, const int32_t *__restrict__ nbr,
+                                                    int n_off, int64_t nbr_ks, int64_t nbr_os, int64_t n,
+                                                    const float *__restrict__ bias, int act,
+                                                    const float *__restrict__ slope, float clip, float *__restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    float acc = 0.0f;
+    for (int k = 0; k < n_off; ++k) {
+        const int32_t idx = nbr[(int64_t)k * nbr_ks + o * nbr_os];
+        if (idx >= 0) acc = acc + y[(int64_t)idx * ldy + k];
+    }
+    const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
+    out[o] = finish(acc, bias ? bias[0] : 0.0f, act, sl, clip);
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int fpcc_gather_sum_f32(const float *y, int ldy, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
+                                   int64_t nbr_os, int64_t n, const float *bias, int act, const float *slope, float clip,
+                                   float *out, void *stream) {
+    if (n < 0 || n_offsets < 1 || ldy < n_offsets) return fail_arg("gather_sum: bad sizes");
+    if (n == 0) return FPCC_OK;
+    if (!y || !nbr || !out) return fail_arg("gather_sum: null pointer");
+    if (act == FPCC_ACT_PRELU && !slope) return fail_arg("gather_sum: PReLU needs a slope pointer");
+    hipLaunchKernelGGL(k_gather_sum, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), y, ldy, nbr, n_offsets,
+                       nbr_ks, nbr_os, n, bias, act, slope, clip, out);
+    return check_hip(hipGetLastError(), "k_gather_sum");
 }

@@ -126,10 +126,29 @@ int64_t indexed_encode(const int32_t *sym, const int32_t *index, int64_t n, cons
     return w.finish();
 }
 
+// One table, no escape symbols, many symbols: resolve the 16-bit slot through a 64 Ki-entry lookup table instead of a
+// binary search per symbol (the decoder's critical path: the next state depends on the decoded symbol).
+int64_t single_table_decode(const uint8_t *stream, int64_t stream_len, int64_t n, const uint32_t *c, int32_t bins,
+                            int32_t offset, int32_t *out) {
+    std::vector<uint16_t> slot_to_bin(kProbOne);
+    for (int32_t b = 0; b < bins; ++b)
+        for (uint32_t s = c[b]; s < c[b + 1]; ++s) slot_to_bin[s] = static_cast<uint16_t>(b);
+    FrontReader r(stream, stream_len);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t v = slot_to_bin[r.peek<kProbBits>()];
+        r.take<kProbBits>(c[v], c[v + 1] - c[v]);
+        out[i] = static_cast<int32_t>(v) + offset;
+    }
+    return FPCC_HOST_OK;
+}
+
 template <bool ESCAPE>
 int64_t indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t *index, int64_t n, const Tables &t,
                        int32_t *out) {
     if (stream_len < 4) return FPCC_HOST_E_ARG;
+    if (!ESCAPE && t.count == 1 && n >= 8192 && t.len[0] - 1 <= 65535)
+        return single_table_decode(stream, stream_len, n, t.cdf + t.start[0], static_cast<int32_t>(t.len[0]) - 1,
+                                   t.offsets[0], out);
     FrontReader r(stream, stream_len);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t ti = index ? index[i] : i % t.count;

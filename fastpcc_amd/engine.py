@@ -435,6 +435,27 @@ def _act_of(module: Optional[nn.Module]) -> _Act:
     raise NotImplementedError(f'cannot fuse {type(module).__name__}')
 
 
+def _packed_gen_ok(c_in: int, c_out: int) -> bool:
+    """a generative transposed convolution whose 8 octant kernels fit one (or two) MFMA GEMMs of 8*C_out columns"""
+    return c_in % 16 == 0 and 8 * c_out in (32, 64, 128, 256)
+
+
+def _split_k3_ok(c_in: int, c2: int, c_out: int) -> bool:
+    """a 3x3x3 convolution with one output channel: dot products per input row on the MFMA kernel + scalar gather"""
+    return c_out == 1 and c2 == 0 and c_in % 16 == 0
+
+
+def summation_order(kind: str, c1: int, c2: int, c_out: int) -> int:
+    """Which documented fp32 summation order (include/fpcc_hip.h) a layer of this shape is evaluated in:
+    0 natural chain, 1 MFMA chain (0,4,1,5,2,6,3,7 inside groups of 8 channels), 2 per-offset chains then offset sum.
+    kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen' | 'mlp'.  Tests hand this to the oracle to compare bit for bit."""
+    if kind == 'gen' and c2 == 0 and _packed_gen_ok(c1, c_out):
+        return 1
+    if kind == 'k3' and _split_k3_ok(c1, c2, c_out):
+        return 2
+    return ops.conv_order(c1, c2, c_out)
+
+
 class _ConvBase(nn.Module):
     TRANSPOSED = False
     GENERATIVE = False
@@ -458,7 +479,28 @@ class _ConvBase(nn.Module):
         shape = (in_channels, out_channels) if volume == 1 else (volume, in_channels, out_channels)
         self.kernel = nn.Parameter(torch.empty(shape))
         self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self._packed = None           # derived weight layouts, rebuilt when the parameters change
+        self._packed_tag = None
         self.reset_parameters()
+
+    def _derived(self):
+        """weight layouts derived from `kernel`/`bias` for the fused evaluations below (cached)"""
+        tag = (self.kernel._version, self.kernel.data_ptr(), None if self.bias is None else self.bias._version)
+        if self._packed_tag != tag:
+            k = self.kernel.detach()
+            b = None if self.bias is None else self.bias.detach().view(-1)
+            d = {}
+            if self.GENERATIVE and _packed_gen_ok(self.in_channels, self.out_channels):
+                w_all = k.permute(1, 0, 2).reshape(self.in_channels, 8 * self.out_channels).contiguous()
+                d['gen_w'] = [w_all] if w_all.shape[1] <= 128 else [w_all[:, :128].contiguous(), w_all[:, 128:].contiguous()]
+                b_all = None if b is None else b.repeat(8)
+                d['gen_b'] = [b_all] if (b_all is None or b_all.numel() <= 128) else [b_all[:128].contiguous(), b_all[128:].contiguous()]
+            if not (self.GENERATIVE or self.TRANSPOSED) and self.ks == 3 and _split_k3_ok(self.in_channels, 0, self.out_channels):
+                wt = torch.zeros((self.in_channels, 32), dtype=k.dtype, device=k.device)
+                wt[:, :27] = k[:, :, 0].t()
+                d['k3_w'] = wt
+            self._packed, self._packed_tag = d, tag
+        return self._packed
 
     def reset_parameters(self):
         # MinkowskiEngine 0.5's default: U(-1/sqrt(n), 1/sqrt(n)), n = (C_out if transposed else C_in) * volume
@@ -486,7 +528,21 @@ class _ConvBase(nn.Module):
         c_out = self.out_channels
         if self.GENERATIVE:
             dst = cm._generated(src)
-            out = ops.conv_f32(x1, w, c_out, src.n, groups=8, **kw)
+            d = self._derived()
+            if x2 is None and 'gen_w' in d:
+                # all 8 octant kernels side by side: one dense GEMM [n, C_in] @ [C_in, 8*C_out]; its row-major output IS
+                # the generated tensor [8n, C_out] (row 8*parent + octant)
+                halves = d['gen_w']
+                wide = 8 * c_out
+                out = torch.empty((src.n, wide), dtype=torch.float32, device=x1.device)
+                for h, wh in enumerate(halves):
+                    cols = wh.shape[1]
+                    bh = d['gen_b'][h] if d['gen_b'][0] is not None else None
+                    ops.conv_f32(x1, wh, cols, src.n, bias=bh, act=act.kind, slope=act.slope, clip=clip,
+                                 out=out[:, h * 128: h * 128 + cols])
+                out = out.view(8 * src.n, c_out)
+            else:
+                out = ops.conv_f32(x1, w, c_out, src.n, groups=8, **kw)
         elif self.TRANSPOSED:
             if coordinates is None:
                 raise ValueError('a transposed convolution needs the target coordinate key')
@@ -505,7 +561,13 @@ class _ConvBase(nn.Module):
             dst = src
             if coordinates is not None and cm._map(coordinates) is not src:
                 raise NotImplementedError('stride-1 convolution onto a different coordinate map')
-            out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, **kw)
+            d = self._derived()
+            if x2 is None and 'k3_w' in d:
+                y = ops.conv_f32(x1, d['k3_w'], 32, src.n)       # per input row: its dot product with every offset's kernel
+                out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
+                                     slope=act.slope, clip=clip)
+            else:
+                out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, **kw)
         else:   # kernel 2, stride 2
             dst = cm._ensure_parent(src)
             if src.generated:

@@ -29,6 +29,7 @@ _SIGS = {
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
+    'fpcc_gather_sum_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _f32, _vp, _vp]),
     'fpcc_logit_to_prob16': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_quantize_symbols': (_i32, [_vp, _i64, _f32, _vp, _vp]),
     'fpcc_child_mask': (_i32, [_vp, _i64, _vp, _vp]),
@@ -257,6 +258,18 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
 
 def conv_order(c1: int, c2: int, c_out: int) -> int:
     return lib().fpcc_conv_f32_order(c1, c2, c_out)
+
+
+def gather_sum(y: torch.Tensor, nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, *,
+               bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: Optional[torch.Tensor] = None,
+               clip: float = 0.0) -> torch.Tensor:
+    """out[o] = act(sum_k y[nbr[k*ks + o*os]][k] + bias): second half of a one-output-channel 3x3x3 convolution"""
+    py, cy, ldy = _rows2d(y, 'y')
+    out = torch.empty((n, 1), dtype=torch.float32, device=y.device)
+    _ok(lib().fpcc_gather_sum_f32(py, ldy, _dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n,
+                                  _dev(bias, torch.float32, 'bias', True), act,
+                                  _dev(slope, torch.float32, 'slope', True), float(clip), out.data_ptr(), _stream()))
+    return out
 
 
 def gather_rows(x: torch.Tensor, index: torch.Tensor) -> torch.Tensor:

@@ -127,6 +127,14 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
                   int act, const float *slope, float clip, void *stream);
 int fpcc_conv_f32_order(int c1, int c2, int c_out);
 
+/* out[o] = act( sum_k y[nbr[k*nbr_ks + o*nbr_os]][k] + bias[0] ): the gather half of a 3x3x3 convolution with ONE output
+ * channel, whose per-offset dot products y = X @ [w_0 | ... | w_26] (padded to 32 columns) were computed per input row
+ * by fpcc_conv_f32.  Together they replace MinkowskiConvolution(C, 1, kernel_size=3) (occupancy / residual heads,
+ * models/convolutional/lossy_coord_v2/layers.py:241-242,258).  Summation order 2: per-offset FMA chains from zero, partial
+ * sums added in ascending offset order, then the bias. */
+int fpcc_gather_sum_f32(const float *y, int ldy, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                        int64_t n, const float *bias, int act, const float *slope, float clip, float *out, void *stream);
+
 /* out[i, :] = x[index[i], :] -- features re-ordered into the canonical (Morton) row order of a coordinate map, the
  * permutation ME.SparseTensor applies to its features (models/convolutional/lossy_coord_v2/model.py:147-153). */
 int fpcc_gather_rows_f32(const float *x, int c, int ld, const int32_t *index, int64_t n, float *out, int ldo, void *stream);

@@ -14,7 +14,7 @@ coding oracle/rans.py.  Parity: the rANS and framing parts are PINNED (golden ve
 network part is UNPINNED against MinkowskiEngine -- what is checked is GPU == this oracle.
 
 `conv='mm'` evaluates convolutions the reference-shaped way (gather, GEMM, scatter-add); `conv='chain'` uses the
-fixed-order FMA chain with `order_fn(c1, c2, c_out) -> 0|1` choosing the channel order per layer shape (see
+fixed-order FMA chain with `order_fn(kind, c1, c2, c_out) -> 0|1|2` choosing the summation order per layer (see
 oracle/sparse_conv.c), which makes the activations comparable bit for bit with a device kernel of the same order.
 """
 import io
@@ -71,11 +71,11 @@ class Feature:
 
 class OracleV2:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg, conv: str = 'mm',
-                 order_fn: Optional[Callable[[int, int, int], int]] = None):
+                 order_fn: Optional[Callable[[str, int, int, int], int]] = None):
         self.P = {k: v.detach().cpu().float() for k, v in weights.items()}
         self.cfg = cfg
         self.conv = conv
-        self.order_fn = order_fn or (lambda c1, c2, c_out: 0)
+        self.order_fn = order_fn or (lambda kind, c1, c2, c_out: 0)
         self._kmaps = {}
         self.trace: Dict[str, np.ndarray] = {}     # activations by layer prefix (filled when keep_trace)
         self.keep_trace = False
@@ -86,7 +86,7 @@ class OracleV2:
             return sc.ACT_PRELU, float(self.P[key].reshape(-1)[0])
         return sc.ACT_NONE, 0.0
 
-    def _apply(self, name, x1, x2, kmap, n_out, w, b, act, slope, clip):
+    def _apply(self, name, kind, x1, x2, kmap, n_out, w, b, act, slope, clip):
         c1 = x1.shape[1]
         c2 = 0 if x2 is None else x2.shape[1]
         c_out = w.shape[-1]
@@ -97,7 +97,7 @@ class OracleV2:
             table = oc.dense_table(kmap, n_out)
             out = torch.from_numpy(sc.conv_chain(x1.numpy(), table, w.numpy(), None if b is None else b.numpy(), n_out,
                                                  x2=None if x2 is None else x2.numpy(), act=act, slope=slope,
-                                                 clip=clip, order=self.order_fn(c1, c2, c_out)))
+                                                 clip=clip, order=self.order_fn(kind, c1, c2, c_out)))
         if self.keep_trace:
             self.trace[name] = out.numpy().copy()
         return out
@@ -141,7 +141,7 @@ class OracleV2:
             kmap = self._kmap(src, dst, 'k2s2T')
         else:
             raise ValueError(kind)
-        out = self._apply(prefix, x.f, None if x2 is None else x2.f, kmap, dst.n, w, b, act, slope, clip)
+        out = self._apply(prefix, kind, x.f, None if x2 is None else x2.f, kmap, dst.n, w, b, act, slope, clip)
         return Feature(out, dst)
 
     def _strided(self, src: oc.Level) -> oc.Level:
@@ -156,7 +156,7 @@ class OracleV2:
         act, slope = self._slope(prefix + '.act.module.weight')
         n = x.level.n
         kmap = [(np.arange(n), np.arange(n))]
-        out = self._apply(prefix, x.f, None if x2 is None else x2.f, kmap, n, w.reshape(1, *w.shape), b, act, slope, clip)
+        out = self._apply(prefix, 'mlp', x.f, None if x2 is None else x2.f, kmap, n, w.reshape(1, *w.shape), b, act, slope, clip)
         return Feature(out, x.level)
 
     # ---- networks ------------------------------------------------------------------------------------------------

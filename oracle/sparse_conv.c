@@ -20,6 +20,9 @@
  *      order 0: natural 0,1,2,...
  *      order 1: inside every aligned group of 8 channels: 0,4,1,5,2,6,3,7  (the order in which gfx950's
  *               v_mfma_f32_32x32x2_f32 consumes a 16-byte-per-lane A fragment; C_in must be a multiple of 8)
+ *      order 2: per kernel offset its own chain (channels as in order 1) starting from zero; the offsets' partial
+ *               sums are then added in ascending offset order -- the association of a per-offset
+ *               gather-GEMM-scatter-add evaluation (and of MinkowskiEngine's own loop over kernel offsets)
  * so that a device kernel documenting the same order can be compared bit for bit.
  */
 #include <math.h>
@@ -30,7 +33,7 @@
 enum { ORC_ACT_NONE = 0, ORC_ACT_PRELU = 1, ORC_ACT_RELU = 2 };
 
 static inline int64_t chan_at(int64_t pos, int order) {
-    if (order == 0) return pos;
+    if (order == 0) return pos;   /* orders 1 and 2 share the channel permutation */
     static const int p8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
     return (pos & ~(int64_t)7) + p8[pos & 7];
 }
@@ -52,6 +55,7 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
 #pragma omp parallel
     {
         float *acc = (float *)malloc(sizeof(float) * (size_t)c_out);
+        float *part = (float *)malloc(sizeof(float) * (size_t)c_out);
 #pragma omp for schedule(dynamic, 64)
         for (int64_t o = 0; o < n_out; ++o) {
             int64_t dst = out_map ? out_map[o] : o;
@@ -61,12 +65,15 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
                 int64_t r = nbr ? nbr[k * n_out + o] : o;
                 if (r < 0) continue;
                 const float *wk = w + k * c_in * c_out;
+                float *tgt = order == 2 ? part : acc;
+                if (order == 2) for (int64_t j = 0; j < c_out; ++j) part[j] = 0.0f;
                 for (int64_t pos = 0; pos < c_in; ++pos) {
                     int64_t c = chan_at(pos, order);
                     float xv = c < c1 ? x1[r * ld1 + c] : x2[r * ld2 + (c - c1)];
                     const float *wr = wk + c * c_out;
-                    for (int64_t j = 0; j < c_out; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+                    for (int64_t j = 0; j < c_out; ++j) tgt[j] = fmaf(xv, wr[j], tgt[j]);
                 }
+                if (order == 2) for (int64_t j = 0; j < c_out; ++j) acc[j] = acc[j] + part[j];
             }
             float *orow = out + dst * ldo;
             for (int64_t j = 0; j < c_out; ++j) {
@@ -79,5 +86,6 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
             }
         }
         free(acc);
+        free(part);
     }
 }

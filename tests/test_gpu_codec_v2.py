@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from fastpcc_amd.engine import summation_order as ME_order
 from oracle.codec_v2 import OracleV2
 from util import batched, enliven, surface_cloud
 
@@ -51,7 +52,7 @@ def test_encode_decode_against_oracle(setup):
     assert len(np.unique(rec, axis=0)) == len(rec)
     assert model.compress(dev) == data                                  # deterministic, order independent
 
-    o = OracleV2(weights, cfg, conv='chain', order_fn=ops.conv_order)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     want = o.compress(coords)
     assert (sym['residual'].reshape(-1) == o.symbols['residual'].reshape(-1)).all()
     assert (sym['occupancy'].astype(bool) == np.concatenate(o.symbols['occupancy'])).all()
@@ -86,7 +87,7 @@ def test_layer_activations_bit_exact(setup):
     xyz, coords = _cloud(2, 64, 12000)
     coords[:, 1:] -= coords[:, 1:].min(0)                # compress() codes coordinates relative to their minimum
     dev = torch.from_numpy(coords).to(torch.int32).cuda()
-    o = OracleV2(weights, cfg, conv='chain', order_fn=ops.conv_order)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     o.keep_trace = True
     o.compress(coords)
     with torch.no_grad():
@@ -124,7 +125,7 @@ def test_tiny_cloud(setup):
     data = model.compress(dev)
     rec = model.decompress(data).cpu().numpy()
     assert rec.shape == (4, 3)
-    o = OracleV2(weights, cfg, conv='chain', order_fn=ops.conv_order)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     want = o.compress(coords)
     assert len(want) == len(data)
 

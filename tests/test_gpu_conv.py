@@ -148,3 +148,55 @@ def test_argument_checks(ops):
         ops.conv_f32(x, w, 8, 4, act=ops.ACT_PRELU)                                          # PReLU without slope
     with pytest.raises((ops.FpccError, TypeError)):
         ops.conv_f32(x.cpu(), w, 8, 4)                                                       # host tensor
+
+
+def test_single_channel_conv3_two_phase_bit_exact(ops, scene):
+    """C_out == 1: per-row dot products on the MFMA kernel + scalar gather-sum == oracle order 2"""
+    rng = np.random.default_rng(77)
+    lvl, table = scene['lvl'], scene['k3']
+    n = lvl.n
+    for c_in in (32, 128):
+        x = rng.normal(size=(n, c_in)).astype(np.float32)
+        w = (rng.normal(size=(27, c_in, 1)) / np.sqrt(13 * c_in)).astype(np.float32)
+        b = rng.normal(size=1).astype(np.float32)
+        wt = np.zeros((c_in, 32), np.float32)
+        wt[:, :27] = w[:, :, 0].T
+        y = ops.conv_f32(_cuda(x), _cuda(wt), 32, n)
+        got = ops.gather_sum(y, _cuda(table), 27, n, 1, n, bias=_cuda(b), clip=0.7)
+        want = sc.conv_chain(x, table, w, b, n, clip=0.7, order=2)
+        assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
+def test_engine_layers_match_oracle_orders(ops, scene):
+    """the fused evaluations chosen inside fastpcc_amd.engine (packed generative GEMM, two-phase conv3 -> 1) agree bit for
+    bit with the oracle when it is told the order engine.summation_order reports"""
+    from fastpcc_amd import engine as ME
+    rng = np.random.default_rng(5)
+    lvl = scene['lvl']
+    coords = torch.from_numpy(lvl.coords).to(torch.int32).cuda()
+    coords2 = coords.clone()
+    coords2[:, 1:] *= 2                      # the same cloud at tensor stride 2, so that it can be upsampled
+    with torch.no_grad():
+        for c_in, c_out in ((64, 16), (128, 32), (16, 4), (1, 1)):
+            cm = ME.CoordinateManager()
+            x = rng.normal(size=(lvl.n, c_in)).astype(np.float32)
+            st = ME.SparseTensor(_cuda(x), coordinates=coords2, tensor_stride=2, coordinate_manager=cm)
+            conv = ME.MinkowskiGenerativeConvolutionTranspose(c_in, c_out, kernel_size=2, stride=2, bias=True).cuda()
+            out = conv(st)
+            w = conv.kernel.detach().cpu().numpy()
+            b = conv.bias.detach().cpu().numpy().reshape(-1)
+            order = ME.summation_order('gen', c_in, 0, c_out)
+            want = np.zeros((8 * lvl.n, c_out), np.float32)
+            for g in range(8):
+                want[g::8] = sc.conv_chain(x, None, w[g], b, lvl.n, order=order)
+            assert (_bits(out.F.cpu().numpy()) == _bits(want)).all(), (c_in, c_out)
+        for c_in in (32, 128, 8):
+            cm = ME.CoordinateManager()
+            x = rng.normal(size=(lvl.n, c_in)).astype(np.float32)
+            st = ME.SparseTensor(_cuda(x), coordinates=coords, coordinate_manager=cm)
+            conv = ME.MinkowskiConvolution(c_in, 1, kernel_size=3, stride=1, bias=True).cuda()
+            out = conv(st)
+            want = sc.conv_chain(x, scene['k3'], conv.kernel.detach().cpu().numpy(),
+                                 conv.bias.detach().cpu().numpy().reshape(-1), lvl.n,
+                                 order=ME.summation_order('k3', c_in, 0, 1))
+            assert (_bits(out.F.cpu().numpy()) == _bits(want)).all(), c_in
