@@ -50,6 +50,24 @@ def conv_flops(info, counts_cache):
     return 2.0 * pairs * info['c_in'] * info['c_out']
 
 
+def pmc_traffic():
+    """HBM bytes per k_conv_mfma launch from the newest committed rocprofv3 PMC passes (profiles/r*/..._pmc_traffic.json,
+    made by profiles/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950
+    guide prescribes).  PMC counters cannot be collected from inside this process, so the committed measurement of the
+    same command is reported; None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_traffic.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    launches = sum(v['launches'] for k, v in data.items() if k.startswith('k_conv_mfma'))
+    total = sum(v['fetch_bytes'] + v['write_bytes'] for k, v in data.items() if k.startswith('k_conv_mfma'))
+    if not launches:
+        return None, None
+    return total / launches, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(cfg, weights, resolution):
     """the CPU oracle (plain C restatement, OpenMP over output rows) timed on a bounded sample of the same workload"""
     import numpy as np
@@ -156,13 +174,19 @@ def main():
     if rank == 0:
         # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
         cache = {}
-        flops = ms = 0.0
+        flops = ms = bytes_fused = 0.0
         n_launch = 0
         ms_valu = 0.0
         for ev0, ev1, info in trace:
             dt = ev0.elapsed_time(ev1)
             if info['mfma']:
-                flops += conv_flops(info, cache)
+                fl = conv_flops(info, cache)
+                flops += fl
+                # B_fused of SURVEY.md 8(d): inputs and outputs once, 8 B per rulebook pair, weights once
+                pairs = fl / (2.0 * info['c_in'] * info['c_out'])
+                rows_in = info['n_out'] if info['nbr'] is None or info['n_offsets'] == 27 else pairs
+                bytes_fused += 4.0 * (rows_in * info['c_in'] + info['n_out'] * info['groups'] * info['c_out']) + \
+                    8.0 * pairs + 4.0 * info['groups'] * info['n_offsets'] * info['c_in'] * info['c_out']
                 ms += dt
                 n_launch += 1
             else:
@@ -179,6 +203,7 @@ def main():
                     f.write(f"{'mfma' if info['mfma'] else 'valu'} {info['c_in']} {info['c_out']} {info['n_out']} "
                             f"{info['n_offsets']} {info['groups']} {dt:.4f} {fl / 1e9:.3f} {fl / dt / 1e9:.2f} "
                             f"{dense / dt / 1e9:.2f}\n")
+        traffic, traffic_src = pmc_traffic()
         out = {
             'metric': 'encode+decode Mpoints/sec, lossy_coord_v2 baseline_r1',
             'value': round(total_points / elapsed_max / 1e6, 4),
@@ -193,7 +218,11 @@ def main():
                        'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
                        'bytes': len(data), 'bpp': round(8 * len(data) / n_points, 4)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         'traffic': None if traffic is None else round(traffic),
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE)',
+                         'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': round(bytes_fused / max(n_launch, 1)),
                          'kernel': 'k_conv_mfma (fp32 gather->MFMA sparse convolution)',
                          'launches_per_step': n_launch // max(args.steps, 1),
                          'kernel_ms_per_step': round(ms / args.steps, 3),
