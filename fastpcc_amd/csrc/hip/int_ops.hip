@@ -1,0 +1,504 @@
+// Integer-only pipeline of the lossl_coord_int codec on gfx950: coordinate hash table, int8 sparse convolution / linear
+// on v_mfma_i32_32x32x32_i8 with the fixed-point epilogue fused, stand-alone fixed-point epilogues, LUT softmax -> CDF.
+//
+// Everything here is exact integer arithmetic, so results are independent of summation order and are compared BIT FOR
+// BIT with the oracle (oracle/int_ops.c), including the final rANS stream.
+//
+// The convolution is output-stationary like the float one: a wave owns 32 output rows x (up to) 128 output channels,
+// walks the kernel offsets present in its rows and feeds the MFMA straight from global memory (A: 16 B of the gathered
+// input row per lane, B: 16 B of a weight row per lane).  No LDS, no barriers: in this codec the whole network is
+// ~0.3 TOP (worked example 2) while it issues >150 launches per frame -- it is launch- and
+// dependency-bound, not math-bound, so the kernel favours few launches (bias/PReLU/requant fused, raw conv optional)
+// over peak MFMA rate.
+#include "common.h"
+
+namespace fpcc {
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------------------------------
+// coordinate hash table (layout and hash of the reference's GPUHashTable so that cached tables are interchangeable)
+__device__ __forceinline__ uint64_t coord_hash(int a, int b, int c, int d) {
+    uint64_t h = 14695981039346656037ull;
+    h = (h ^ (uint32_t)a) * 1099511628211ull;
+    h = (h ^ (uint32_t)b) * 1099511628211ull;
+    h = (h ^ (uint32_t)c) * 1099511628211ull;
+    h = (h ^ (uint32_t)d) * 1099511628211ull;
+    return h;
+}
+
+__device__ __forceinline__ void table_insert(unsigned long long *keys, int32_t *vals, int cap, uint64_t key, int32_t value) {
+    int slot = (int)(key % (uint64_t)cap);
+    for (int probes = 0; probes < cap; ++probes) {
+        const unsigned long long prev = atomicCAS(&keys[slot], 0ull, (unsigned long long)key);
+        if (prev == 0ull || prev == key) {
+            vals[slot] = value;
+            return;
+        }
+        slot = slot + 1 == cap ? 0 : slot + 1;
+    }
+}
+
+__device__ __forceinline__ int32_t table_find(const unsigned long long *keys, const int32_t *vals, int cap, uint64_t key) {
+    int slot = (int)(key % (uint64_t)cap);
+    int32_t found = 0;
+    for (int probes = 0; probes < cap; ++probes) {
+        const unsigned long long cur = keys[slot];
+        if (cur == key) found = vals[slot];
+        if (cur == 0ull) break;
+        slot = slot + 1 == cap ? 0 : slot + 1;
+    }
+    return found;
+}
+
+__global__ void k_hash_insert_coords(unsigned long long *keys, int32_t *vals, int cap, const int4 *__restrict__ coords, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coords[i];
+    table_insert(keys, vals, cap, coord_hash(c.x, c.y, c.z, c.w), i + 1);
+}
+
+__global__ void k_hash_insert_keys(unsigned long long *keys, int32_t *vals, int cap, const int64_t *__restrict__ in, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    table_insert(keys, vals, cap, (uint64_t)in[i], i + 1);
+}
+
+__global__ void k_hash_lookup_keys(const unsigned long long *keys, const int32_t *vals, int cap,
+                                   const int64_t *__restrict__ in, int n, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = table_find(keys, vals, cap, (uint64_t)in[i]);
+}
+
+struct I3 { int v[3]; };
+
+// one thread per (output point, kernel offset); offset order of the reference: odd kernel volume -> first axis fastest,
+// even -> last axis fastest; offsets (k % ks) - (ks - 1) / 2
+__global__ void k_hash_lookup_coords(const unsigned long long *keys, const int32_t *vals, int cap,
+                                     const int4 *__restrict__ coords, int n, I3 ks, I3 st, int volume,
+                                     int32_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / volume;
+    if (i >= n) return;
+    const int k = (int)(t - i * volume);
+    const int4 c = coords[i];
+    const int base[3] = {c.x, c.y, c.z};
+    int q[3];
+    int rem = k;
+    if (volume & 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { q[a] = base[a] * st.v[a] + rem % ks.v[a] - (ks.v[a] - 1) / 2; rem /= ks.v[a]; }
+    } else {
+#pragma unroll
+        for (int a = 2; a >= 0; --a) { q[a] = base[a] * st.v[a] + rem % ks.v[a] - (ks.v[a] - 1) / 2; rem /= ks.v[a]; }
+    }
+    out[i * volume + k] = table_find(keys, vals, cap, coord_hash(q[0], q[1], q[2], c.w));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fixed-point epilogue shared by the fused and the stand-alone kernels
+__device__ __forceinline__ int64_t rha(int64_t p, int s) {   // round half away from zero, arithmetic shift
+    if (s <= 0) return p;
+    const int64_t half = (int64_t)1 << (s - 1);
+    return p >= 0 ? (p + half) >> s : -((-p + half) >> s);
+}
+
+__device__ __forceinline__ int64_t prelu_q625(int64_t v, int32_t slope) { return v < 0 ? rha(v * (int64_t)slope, 25) : v; }
+
+__device__ __forceinline__ int32_t requant(int64_t v, uint32_t mul, int64_t zp, int shift, int out_bits) {
+    const int64_t r = rha(v * (int64_t)mul + zp, shift);
+    const int64_t lo = out_bits == 8 ? -128 : (out_bits == 16 ? -32768 : (int64_t)INT32_MIN);
+    const int64_t hi = out_bits == 8 ? 127 : (out_bits == 16 ? 32767 : (int64_t)INT32_MAX);
+    return (int32_t)(r < lo ? lo : (r > hi ? hi : r));
+}
+
+struct ConvI8Args {
+    const int8_t *a; int lda;               // [n_in][lda] int8, lda % 16 == 0, columns >= c_in zero
+    const int32_t *nbr; int n_off; int64_t nbr_ks; int64_t nbr_os; int nbr_bias;   // input row = nbr[...] - nbr_bias, < 0 absent
+    const int8_t *w; int ldw;               // [n_off][c_out][ldw] int8, ldw % 16 == 0
+    int k_steps;                            // ceil(c_in / 32)
+    const int32_t *zp_comp;                 // [n_off][c_out] or NULL
+    const int32_t *bias; const int32_t *slope; const uint32_t *mul; const int64_t *zp; int shift; int out_bits;
+    void *out; int ldo; int c_out; int64_t n_out; int out_pad;   // columns [c_out, out_pad) of an int8 output are zeroed
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (row0 >= p.n_out) return;
+    const int col0 = blockIdx.y * 32 * NB;
+    const int64_t my_row = row0 + li;
+
+    i32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0;
+
+    const i32x4 zero4 = {0, 0, 0, 0};
+    for (int k = 0; k < p.n_off; ++k) {
+        int64_t idx = -1;
+        if (my_row < p.n_out) idx = p.nbr ? (int64_t)p.nbr[(int64_t)k * p.nbr_ks + my_row * p.nbr_os] - p.nbr_bias : my_row;
+        const unsigned long long present = __ballot(idx >= 0);
+        if (present == 0ull) continue;
+        const int8_t *arow = p.a + (idx >= 0 ? idx : 0) * p.lda + 16 * lh;
+        const int8_t *wk = p.w + (int64_t)k * p.c_out * p.ldw + 16 * lh;
+        for (int s = 0; s < p.k_steps; ++s) {
+            // the second 16-byte half of the last step may lie past the padded row: it is zero by contract when inside,
+            // and skipped when outside
+            const bool in_row = 32 * s + 16 * lh < p.lda;
+            i32x4 av = zero4;
+            if (idx >= 0 && in_row) av = *reinterpret_cast<const i32x4 *>(arow + 32 * s);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = col0 + 32 * nb + li;
+                i32x4 bv = zero4;
+                if (col < p.c_out && 32 * s + 16 * lh < p.ldw)
+                    bv = *reinterpret_cast<const i32x4 *>(wk + (int64_t)col * p.ldw + 32 * s);
+                acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[nb], 0, 0, 0);
+            }
+        }
+        if (p.zp_comp) {
+            const unsigned rows_present = (unsigned)(present & 0xffffffffull);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = col0 + 32 * nb + li;
+                const int32_t comp = col < p.c_out ? p.zp_comp[(int64_t)k * p.c_out + col] : 0;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if ((rows_present >> rr) & 1u) acc[nb][reg] += comp;
+                }
+            }
+        }
+    }
+
+    const int32_t slope = p.slope ? p.slope[0] : 0;
+    const int64_t zp = p.zp ? p.zp[0] : 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + 32 * nb + li;
+        const bool live = col < p.c_out;
+        const bool pad = !live && p.out_bits == 8 && col < p.out_pad;
+        if (!live && !pad) continue;
+        const int32_t b = (live && p.bias) ? p.bias[col] : 0;
+        const uint32_t m = (live && p.mul) ? p.mul[col] : 0u;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t o = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (o >= p.n_out) continue;
+            int32_t v = 0;
+            if (live) {
+                if (p.mul) {
+                    int64_t t = (int64_t)acc[nb][reg] + b;
+                    if (p.slope) t = prelu_q625(t, slope);
+                    v = requant(t, m, zp, p.shift, p.out_bits);
+                } else {
+                    v = acc[nb][reg];
+                }
+            }
+            if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
+            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = v;
+        }
+    }
+}
+
+// stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
+__global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const int32_t *bias, const int32_t *slope,
+                               const uint32_t *mul, int mul_stride, const int64_t *zp, int shift, int out_bits,
+                               void *out, int ldo, int64_t n, int ch, int out_pad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = out_pad > ch ? out_pad : ch;
+    if (e >= n * width) return;
+    const int64_t r = e / width;
+    const int c = (int)(e - r * width);
+    int32_t v = 0;
+    if (c < ch) {
+        int64_t t = (int64_t)in[r * ldi + c] + (bias ? (int64_t)bias[c] : 0);
+        if (slope) t = prelu_q625(t, slope[0]);
+        v = requant(t, mul[c * mul_stride], zp ? zp[0] : 0, shift, out_bits);
+    }
+    if (out_bits == 8) static_cast<int8_t *>(out)[r * ldo + c] = (int8_t)v;
+    else if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = v;
+}
+
+// out = clamp_i32(prelu_q625(a (+ b)))
+__global__ void k_prelu_i32(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const int32_t *slope, int64_t n,
+                            int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t x = a[i];
+    if (b) x = (int32_t)((uint32_t)x + (uint32_t)b[i]);    // the reference's int32 tensor add wraps
+    const int64_t v = prelu_q625((int64_t)x, slope[0]);
+    out[i] = (int32_t)(v < (int64_t)INT32_MIN ? (int64_t)INT32_MIN : (v > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : v));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LUT softmax.  lut[k] = llround(65536 * exp(-k / 512)), k = 0 .. 6144 (filled once by fpcc_int_init on the host)
+constexpr int kLutSize = 12 * 512 + 1;
+__device__ int32_t g_exp_lut[kLutSize];
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per row, rows of up to 256 entries (4 per lane).  MODE 0: Q0.32 probabilities (softmax_int32);
+// MODE 1: uint16 CDF rows of batch_quantize_pmf; MODE 2: (start, freq - 1) of one symbol per row.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_softmax_rows(const int32_t *__restrict__ in, int64_t n, int c, int pre_shift,
+                                                      uint32_t *__restrict__ prob_out, uint16_t *__restrict__ cdf_out,
+                                                      const int16_t *__restrict__ sym, uint16_t *__restrict__ start_out,
+                                                      uint16_t *__restrict__ freqm1_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int32_t *x = in + row * c;
+    int32_t q[4];
+    int m = INT32_MIN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * lane + j;
+        q[j] = e < c ? (x[e] >> pre_shift) : INT32_MIN;
+        m = max(m, q[j]);
+    }
+    const int top = wave_max(m) + 64;
+    int32_t ex[4];
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * lane + j;
+        int id = (int)(((int64_t)top - (int64_t)q[j]) >> 7);
+        id = id > kLutSize - 1 ? kLutSize - 1 : id;
+        ex[j] = e < c ? g_exp_lut[id] : 0;
+        local += ex[j];
+    }
+    const int sum = wave_sum(local);
+    const uint64_t inv = sum > 0 ? (((uint64_t)1 << 32) + (uint64_t)(sum >> 1)) / (uint64_t)sum : ((uint64_t)1 << 32) / (uint64_t)c;
+    uint32_t pr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t t = (uint64_t)(uint32_t)ex[j] * inv;
+        pr[j] = t > 0xffffffffull ? 0xffffffffu : (uint32_t)t;
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * lane + j < c) prob_out[row * c + 4 * lane + j] = pr[j];
+        return;
+    }
+    // frequencies and their inclusive prefix sum over the row
+    uint32_t f[4];
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = 4 * lane + j < c ? (uint32_t)(((uint64_t)pr[j] * (uint64_t)(65536 - c)) >> 32) + 1u : 0u;
+        run += f[j];
+        f[j] = run;                                  // inclusive within the lane
+    }
+    uint32_t scan = run;                             // inclusive scan of lane totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(scan, o);
+        if (lane >= o) scan += up;
+    }
+    const uint32_t before = scan - run;
+    uint32_t edge[4];                                // upper edge of entry e; the last entry is forced to 65535
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * lane + j;
+        edge[j] = e == c - 1 ? 65535u : before + f[j];
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * lane + j < c) cdf_out[row * c + 4 * lane + j] = (uint16_t)edge[j];
+        return;
+    }
+    // MODE 2: the range of symbol s: [edge[s-1], edge[s]) with edge[-1] = 0 and the last upper edge 65536
+    const int s = (int)(uint16_t)sym[row];
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * lane + j;
+        if (e == s - 1) lo = edge[j];
+        if (e == s) hi = e == c - 1 ? 65536u : edge[j];
+    }
+    lo = (uint32_t)wave_sum((int)lo);                // exactly one lane holds a non-zero contribution
+    hi = (uint32_t)wave_sum((int)hi);
+    if (lane == 0) {
+        start_out[row] = (uint16_t)lo;
+        freqm1_out[row] = (uint16_t)(hi - lo - 1u);
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace fpcc
+
+using namespace fpcc;
+
+extern "C" int fpcc_int_init(void) {
+    static bool done = false;
+    if (done) return FPCC_OK;
+    static int32_t host_lut[kLutSize];
+    for (int k = 0; k < kLutSize; ++k) host_lut[k] = (int32_t)llround(exp(-(double)k / 512.0) * 65536.0);
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exp_lut), host_lut, sizeof host_lut));
+    done = true;
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_insert_coords(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int32_t *coords,
+                                       int64_t n, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0 || n > capacity) return fail_arg("hash_insert_coords: bad capacity / n");
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !coords || !aligned16(coords)) return fail_arg("hash_insert_coords: null or unaligned pointer");
+    hipLaunchKernelGGL(k_hash_insert_coords, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(table_keys), table_vals, (int)capacity,
+                       reinterpret_cast<const int4 *>(coords), (int)n);
+    FPCC_LAUNCHED(k_hash_insert_coords);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_lookup_coords(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity,
+                                       const int32_t *coords, int64_t n, const int32_t *kernel_sizes_host,
+                                       const int32_t *strides_host, int32_t *out, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0 || !kernel_sizes_host || !strides_host)
+        return fail_arg("hash_lookup_coords: bad arguments");
+    I3 ks, st;
+    int volume = 1;
+    for (int a = 0; a < 3; ++a) {
+        ks.v[a] = kernel_sizes_host[a];
+        st.v[a] = strides_host[a];
+        if (ks.v[a] < 1 || st.v[a] < 1) return fail_arg("hash_lookup_coords: kernel sizes and strides must be positive");
+        volume *= ks.v[a];
+    }
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !coords || !out || !aligned16(coords)) return fail_arg("hash_lookup_coords: null or unaligned pointer");
+    hipLaunchKernelGGL(k_hash_lookup_coords, dim3(blocks_for(n * volume, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned long long *>(table_keys), table_vals, (int)capacity,
+                       reinterpret_cast<const int4 *>(coords), (int)n, ks, st, volume, out);
+    FPCC_LAUNCHED(k_hash_lookup_coords);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_insert_keys(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int64_t *keys,
+                                     int64_t n, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0 || n > capacity) return fail_arg("hash_insert_keys: bad capacity / n");
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !keys) return fail_arg("hash_insert_keys: null pointer");
+    hipLaunchKernelGGL(k_hash_insert_keys, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(table_keys), table_vals, (int)capacity, keys, (int)n);
+    FPCC_LAUNCHED(k_hash_insert_keys);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_lookup_keys(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity,
+                                     const int64_t *keys, int64_t n, int32_t *out, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0) return fail_arg("hash_lookup_keys: bad capacity / n");
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !keys || !out) return fail_arg("hash_lookup_keys: null pointer");
+    hipLaunchKernelGGL(k_hash_lookup_keys, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned long long *>(table_keys), table_vals, (int)capacity, keys, (int)n, out);
+    FPCC_LAUNCHED(k_hash_lookup_keys);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
+                            int64_t nbr_os, int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp,
+                            const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul, const int64_t *zero_point,
+                            int shift, int out_bits, void *out, int ldo, int out_pad, int c_out, int64_t n_out, void *stream) {
+    if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1) return fail_arg("conv_i8: sizes out of range");
+    if (n_out == 0) return FPCC_OK;
+    if (!a || !w || !out) return fail_arg("conv_i8: null pointer");
+    if (!nbr && n_offsets != 1) return fail_arg("conv_i8: identity map needs n_offsets == 1");
+    if (lda % 16 || ldw % 16 || lda < c_in || ldw < c_in || !aligned16(a) || !aligned16(w))
+        return fail_arg("conv_i8: rows of A and W must be 16-byte aligned with strides that are multiples of 16 and >= c_in");
+    if (out_bits != 8 && out_bits != 32) return fail_arg("conv_i8: out_bits must be 8 or 32");
+    if (requant_mul && shift < 0) return fail_arg("conv_i8: negative requant shift");
+    if (!requant_mul && out_bits != 32) return fail_arg("conv_i8: raw accumulators are int32");
+    if (ldo < c_out || out_pad > ldo) return fail_arg("conv_i8: output row stride too small");
+    ConvI8Args p{a, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, (c_in + 31) / 32, zp_comp,
+                 bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad};
+    const int width = out_pad > c_out ? out_pad : c_out;
+    const unsigned gx = (unsigned)((n_out + 127) / 128);
+    hipStream_t s = as_stream(stream);
+    if (width > 64) {
+        hipLaunchKernelGGL((k_conv_i8<4>), dim3(gx, (width + 127) / 128), dim3(256), 0, s, p);
+    } else if (width > 32) {
+        hipLaunchKernelGGL((k_conv_i8<2>), dim3(gx, 1), dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((k_conv_i8<1>), dim3(gx, 1), dim3(256), 0, s, p);
+    }
+    FPCC_LAUNCHED(k_conv_i8);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope,
+                                 const uint32_t *requant_mul, int mul_per_channel, const int64_t *zero_point, int shift,
+                                 int out_bits, void *out, int ldo, int out_pad, int64_t n, int ch, void *stream) {
+    if (n < 0 || ch < 1 || shift < 0) return fail_arg("epilogue_i32: bad sizes or negative shift");
+    if (n == 0) return FPCC_OK;
+    if (!in || !requant_mul || !out) return fail_arg("epilogue_i32: null pointer");
+    if (out_bits != 8 && out_bits != 16 && out_bits != 32) return fail_arg("epilogue_i32: out_bits must be 8, 16 or 32");
+    if (out_bits == 16) return fail_arg("epilogue_i32: int16 outputs are not used by any in-scope model");
+    const int width = out_pad > ch ? out_pad : ch;
+    if (ldo < width || ldi < ch) return fail_arg("epilogue_i32: row stride too small");
+    hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n * width, kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
+                       bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch,
+                       out_bits == 8 ? out_pad : 0);
+    FPCC_LAUNCHED(k_epilogue_i32);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_prelu_i32(const int32_t *a, const int32_t *b, const int32_t *slope, int64_t n, int32_t *out, void *stream) {
+    if (n < 0) return fail_arg("prelu_i32: n < 0");
+    if (n == 0) return FPCC_OK;
+    if (!a || !slope || !out) return fail_arg("prelu_i32: null pointer");
+    hipLaunchKernelGGL(k_prelu_i32, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), a, b, slope, n, out);
+    FPCC_LAUNCHED(k_prelu_i32);
+    return FPCC_OK;
+}
+
+static int softmax_common(int mode, const int32_t *in, int64_t n, int c, int pre_shift, uint32_t *prob, uint16_t *cdf,
+                          const int16_t *sym, uint16_t *start, uint16_t *freqm1, void *stream) {
+    if (n < 0 || c < 2 || c > 256 || pre_shift < 0 || pre_shift > 31) return fail_arg("softmax: rows of 2..256 entries, shift 0..31");
+    if (n == 0) return FPCC_OK;
+    if (!in) return fail_arg("softmax: null pointer");
+    if (int rc = fpcc_int_init()) return rc;
+    const dim3 grid(blocks_for(n, 4)), block(256);
+    hipStream_t s = as_stream(stream);
+    if (mode == 0) hipLaunchKernelGGL((k_softmax_rows<0>), grid, block, 0, s, in, n, c, pre_shift, prob, cdf, sym, start, freqm1);
+    else if (mode == 1) hipLaunchKernelGGL((k_softmax_rows<1>), grid, block, 0, s, in, n, c, pre_shift, prob, cdf, sym, start, freqm1);
+    else hipLaunchKernelGGL((k_softmax_rows<2>), grid, block, 0, s, in, n, c, pre_shift, prob, cdf, sym, start, freqm1);
+    FPCC_LAUNCHED(k_softmax_rows);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_softmax_i32(const int32_t *in, int64_t n, int c, uint32_t *out, void *stream) {
+    if (n > 0 && !out) return fail_arg("softmax_i32: null pointer");
+    return softmax_common(0, in, n, c, 0, out, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int fpcc_logits_to_cdf16(const int32_t *logits, int64_t n, int c, int pre_shift, uint16_t *cdf_out, void *stream) {
+    if (n > 0 && !cdf_out) return fail_arg("logits_to_cdf16: null pointer");
+    return softmax_common(1, logits, n, c, pre_shift, nullptr, cdf_out, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift, const int16_t *symbols,
+                                     uint16_t *start_out, uint16_t *freq_minus_1_out, void *stream) {
+    if (n > 0 && (!symbols || !start_out || !freq_minus_1_out)) return fail_arg("logits_to_ranges: null pointer");
+    return softmax_common(2, logits, n, c, pre_shift, nullptr, nullptr, symbols, start_out, freq_minus_1_out, stream);
+}

@@ -36,6 +36,18 @@ _SIGS = {
     'fpcc_topk_keep': (_i64, [_vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     'fpcc_gather_rows_f32': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     'fpcc_compact_coords': (_i64, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_int_init': (_i32, []),
+    'fpcc_hash_insert_coords': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    'fpcc_hash_lookup_coords': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'fpcc_hash_insert_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    'fpcc_hash_lookup_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'fpcc_conv_i8': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                            _vp, _i32, _i32, _i32, _i64, _vp]),
+    'fpcc_epilogue_i32': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    'fpcc_prelu_i32': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    'fpcc_softmax_i32': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'fpcc_logits_to_cdf16': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    'fpcc_logits_to_ranges': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
@@ -335,3 +347,144 @@ def compact_coords(pkeys: torch.Tensor, mask: torch.Tensor, level: int, bits: in
                               _dev(offset_xyz, torch.int32, 'offset', True), out.data_ptr(), count.data_ptr(),
                               ws.data_ptr(), need, _stream()))
     return out, count
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integer pipeline
+
+def _any(t: Optional[torch.Tensor], name: str, dtypes, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f'{name} is required')
+    if not t.is_cuda:
+        raise FpccError(f'{name} must live on the GPU (libfpcc_hip has no CPU path)')
+    if t.dtype not in dtypes:
+        raise TypeError(f'{name} must be one of {dtypes}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+_U32 = (torch.uint32, torch.int32, torch.int64)
+
+
+def _mul_u32(t: torch.Tensor) -> torch.Tensor:
+    """requant multipliers live as uint32 in the library; checkpoints carry them as int64 (torch.save has no uint32)"""
+    if t.dtype == torch.int64:
+        return t.to(torch.int32) if int(t.max()) < 2 ** 31 else (t & 0xffffffff).to(torch.uint32)
+    return t
+
+
+def hash_insert_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor) -> None:
+    _ok(lib().fpcc_hash_insert_coords(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+                                      table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), coords_xyzb.shape[0],
+                                      _stream()))
+
+
+def hash_lookup_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor, kernel_size,
+                       stride) -> torch.Tensor:
+    """-> int32 [ceil(n/128)*128, volume], entry = input row + 1 or 0 (rows past n are zero), as the reference returns"""
+    n = coords_xyzb.shape[0]
+    ks = (C.c_int32 * 3)(*[int(v) for v in kernel_size])
+    st = (C.c_int32 * 3)(*[int(v) for v in stride])
+    volume = int(kernel_size[0]) * int(kernel_size[1]) * int(kernel_size[2])
+    rows = (n + 127) // 128 * 128
+    out = torch.zeros((rows, volume), dtype=torch.int32, device=coords_xyzb.device)
+    _ok(lib().fpcc_hash_lookup_coords(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+                                      table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), n, ks, st,
+                                      out.data_ptr(), _stream()))
+    return out
+
+
+def hash_insert_keys(table_keys, table_vals, keys) -> None:
+    _ok(lib().fpcc_hash_insert_keys(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+                                    table_keys.shape[0], _dev(keys, torch.int64, 'keys'), keys.shape[0], _stream()))
+
+
+def hash_lookup_keys(table_keys, table_vals, keys) -> torch.Tensor:
+    n = keys.shape[0]
+    out = torch.zeros((n + 127) // 128 * 128, dtype=torch.int32, device=keys.device)
+    _ok(lib().fpcc_hash_lookup_keys(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+                                    table_keys.shape[0], _dev(keys, torch.int64, 'keys'), n, out.data_ptr(), _stream()))
+    return out
+
+
+def _rows_i8(t: torch.Tensor, name: str) -> torch.Tensor:
+    """int8 [n, C] -> contiguous [n, ceil16(C)] with a zero pad when C is not a multiple of 16"""
+    if t.dtype != torch.int8 or t.dim() != 2 or not t.is_cuda:
+        raise TypeError(f'{name} must be a 2-D int8 GPU tensor')
+    c = t.shape[1]
+    if c % 16:
+        return torch.nn.functional.pad(t, (0, 16 - c % 16)).contiguous()
+    return t.contiguous()
+
+
+def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_out: int, *,
+            nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1, nbr_bias: int = 0,
+            zp_comp: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+            slope: Optional[torch.Tensor] = None, requant_mul: Optional[torch.Tensor] = None,
+            zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32) -> torch.Tensor:
+    """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw]."""
+    a = _rows_i8(a, 'a')
+    if w_padded.dtype != torch.int8 or not w_padded.is_contiguous() or w_padded.dim() != 3 or \
+            w_padded.shape[0] != n_offsets or w_padded.shape[1] != c_out or w_padded.shape[2] % 16:
+        raise ValueError('weights must be contiguous int8 [n_offsets, c_out, ldw] with ldw a multiple of 16')
+    out = torch.empty((n_out, c_out), dtype=torch.int8 if out_bits == 8 else torch.int32, device=a.device)
+    mul = None if requant_mul is None else _mul_u32(requant_mul)
+    _ok(lib().fpcc_conv_i8(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                           nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
+                           _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
+                           _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
+                           int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _stream()))
+    return out
+
+
+def epilogue_i32(x: torch.Tensor, requant_mul: torch.Tensor, zero_point: Optional[torch.Tensor], shift: int, out_bits: int,
+                 *, bias: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """requant_to_int8/int32 and their bias / PReLU variants on an int32 matrix [n, ch]"""
+    if x.dtype != torch.int32 or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
+        raise TypeError('input must be a 2-D int32 GPU tensor with unit column stride')
+    n, ch = x.shape
+    mul = _mul_u32(requant_mul)
+    per_channel = 1 if mul.numel() == ch and ch > 1 else (1 if mul.numel() == ch else 0)
+    if mul.numel() not in (1, ch):
+        raise ValueError('requant_mul must have 1 or ch entries')
+    out = torch.empty((n, ch), dtype=torch.int8 if out_bits == 8 else torch.int32, device=x.device)
+    _ok(lib().fpcc_epilogue_i32(x.data_ptr(), x.stride(0) if n > 1 else ch, _dev(bias, torch.int32, 'bias', True),
+                                _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
+                                per_channel, _dev(zero_point, torch.int64, 'zero_point', True), int(shift), out_bits,
+                                out.data_ptr(), ch, 0, n, ch, _stream()))
+    return out
+
+
+def prelu_i32(a: torch.Tensor, slope: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    _ok(lib().fpcc_prelu_i32(_dev(a, torch.int32, 'a'), None if add is None else _dev(add.contiguous(), torch.int32, 'add'),
+                             _dev(slope, torch.int32, 'slope'), a.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def softmax_i32(x: torch.Tensor) -> torch.Tensor:
+    n, c = x.shape
+    out = torch.empty((n, c), dtype=torch.uint32, device=x.device)
+    _ok(lib().fpcc_softmax_i32(_dev(x, torch.int32, 'x'), n, c, out.data_ptr(), _stream()))
+    return out
+
+
+def logits_to_cdf16(logits: torch.Tensor, pre_shift: int) -> torch.Tensor:
+    """uint16 CDF rows returned in an int16 tensor (same bits)"""
+    n, c = logits.shape
+    out = torch.empty((n, c), dtype=torch.int16, device=logits.device)
+    _ok(lib().fpcc_logits_to_cdf16(_dev(logits, torch.int32, 'logits'), n, c, pre_shift, out.data_ptr(), _stream()))
+    return out
+
+
+def logits_to_ranges(logits: torch.Tensor, pre_shift: int, symbols: torch.Tensor):
+    n, c = logits.shape
+    start = torch.empty(n, dtype=torch.int16, device=logits.device)
+    freqm1 = torch.empty(n, dtype=torch.int16, device=logits.device)
+    _ok(lib().fpcc_logits_to_ranges(_dev(logits, torch.int32, 'logits'), n, c, pre_shift,
+                                    _dev(symbols, torch.int16, 'symbols'), start.data_ptr(), freqm1.data_ptr(), _stream()))
+    return start, freqm1

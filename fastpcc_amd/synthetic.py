@@ -52,3 +52,32 @@ SCALE = {1024: 1.25, 2048: 0.735}      # 997 645 voxels at 10 bit (cfg#2), 1 997
 
 def batched(xyz: np.ndarray, batch: int = 0) -> np.ndarray:
     return np.concatenate((np.full((len(xyz), 1), batch, dtype=np.int32), xyz.astype(np.int32)), 1)
+
+
+def lidar_cloud(seed: int = 3, beams: int = 64, azimuths: int = 2048, resolution: int = 65536, extent: float = 400.0,
+                drop: float = 0.1) -> np.ndarray:
+    """KITTI-like spinning-LiDAR frame (cfg#3): rays cast against a ground plane and random boxes, range noise, dropped
+    returns, quantised as the reference's KITTI loader does (round((p - min) * (resolution - 1) / extent),
+    lib/datasets/KITTIOdometry/dataset.py:91-102).  Returns unique int32 voxels [n, 3]."""
+    rng = np.random.default_rng(seed)
+    az = np.linspace(0, 2 * np.pi, azimuths, endpoint=False)
+    el = np.deg2rad(np.linspace(-24.8, 2.0, beams))
+    a, e = np.meshgrid(az, el)
+    d = np.stack((np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)), -1).reshape(-1, 3)
+    t = np.full(len(d), np.inf)
+    down = d[:, 2] < -1e-3
+    t[down] = -1.73 / d[down, 2]                                   # ground plane z = -1.73 m
+    for _ in range(40):                                            # axis-aligned boxes
+        c = np.array([rng.uniform(-60, 60), rng.uniform(-60, 60), rng.uniform(-1.7, 0.5)])
+        h = np.array([rng.uniform(0.5, 6), rng.uniform(0.5, 6), rng.uniform(0.5, 4)])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t1, t2 = (c - h) / d, (c + h) / d
+        near, far = np.minimum(t1, t2).max(1), np.maximum(t1, t2).min(1)
+        hit = (near <= far) & (near > 0.5)
+        t = np.where(hit & (near < t), near, t)
+    ok = np.isfinite(t) & (t < 120)
+    ok &= rng.random(len(t)) >= drop
+    p = d[ok] * (t[ok] + rng.normal(0, 0.02, ok.sum()))[:, None]
+    q = np.round((p - p.min(0)) * ((resolution - 1) / extent)).astype(np.int64)
+    key = np.unique((q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2])
+    return np.stack(((key >> 42), (key >> 21) & 0x1fffff, key & 0x1fffff), 1).astype(np.int32)

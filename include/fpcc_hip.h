@@ -167,6 +167,72 @@ int64_t fpcc_compact_coords(const int64_t *pkeys, int64_t m, const uint8_t *mask
                             const int32_t *offset_xyz, int32_t *xyz_out, int32_t *count_out,
                             void *ws, int64_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Integer-only pipeline (lossl_coord_int).  Replaces the pybind module `int_sparse_conv_ext`                      */
+/* (lib/int_sparse_conv/src/binding.cu:114-145).  All arithmetic is exact: results are order independent.          */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* One-time upload of the exponent table of the LUT softmax (lib/int_sparse_conv/src/softmax.cu:13-22,108-117).  Called
+ * lazily by the softmax entry points; call it explicitly before capturing a graph. */
+int fpcc_int_init(void);
+
+/* GPUHashTable(keys int64[cap], vals int32[cap]) -- caller-owned, zero-initialised storage, same slot layout and hash
+ * as the reference (lib/int_sparse_conv/src/hashmap/hashmap_cuda.cuh:59-73,146-191), so cached tables interchange.
+ *   insert_coords : coords int32 [n][4] = (x, y, z, batch), value = row + 1            (hashmap_cuda.cuh:171-191)
+ *   lookup_coords : out int32 [n][volume], entry = row + 1 of the voxel at coord*stride + offset_k, 0 when absent;
+ *                   kernel_sizes / strides are HOST int32[3] (the reference passes device tensors only to read them in
+ *                   the kernel); offset order as in hashmap_cuda.cuh:239-258 (odd volume: x fastest, even: z fastest)
+ *   insert_keys / lookup_keys : the generic-key variants (hashmap_cuda.cuh:146-168,195-218). */
+int fpcc_hash_insert_coords(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int32_t *coords, int64_t n,
+                            void *stream);
+int fpcc_hash_lookup_coords(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, const int32_t *coords,
+                            int64_t n, const int32_t *kernel_sizes_host, const int32_t *strides_host, int32_t *out,
+                            void *stream);
+int fpcc_hash_insert_keys(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int64_t *keys, int64_t n,
+                          void *stream);
+int fpcc_hash_lookup_keys(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, const int64_t *keys,
+                          int64_t n, int32_t *out, void *stream);
+
+/* int8 x int8 -> int32 sparse convolution / linear with the fixed-point epilogue fused:
+ *      acc[o][j] = sum_k  A[in_k(o), :] . W[k][j, :]  (+ zp_comp[k][j] for every present offset k)
+ *      out[o][j] = requant_mul == NULL ? acc
+ *                : clamp_T( rha( prelu_q6.25(acc + bias[j]) * requant_mul[j] + zero_point, shift ) ),  T = int8 | int32
+ * Replaces cutlass_gather_gemm_scatter_int8 + cutlass_gemm_int8 (gather_gemm_scatter.cu:216-268, gemm.cu:197-247) as
+ * driven by sparse_conv_in8w8out32 (lib/int_sparse_conv/cuda_ops.py:95-169), and the epilogue kernels
+ * {bias_,prelu_,bias_prelu_,}requant_to_int{8,32} (src/element_wise/*.cu) that follow them (cuda_ops.py:383-403,609-635).
+ *   A        int8 [n_in][lda], lda a multiple of 16, columns c_in..lda zero;
+ *   nbr      input row of (offset k, output row o) = nbr[k*nbr_ks + o*nbr_os] - nbr_bias, negative = absent
+ *            (a lookup_coords result is used directly with (ks, os, bias) = (1, volume, 1)); NULL = identity;
+ *   W        int8 [n_offsets][c_out][ldw] (the reference's [K, C_out, C_in] with rows padded to ldw, multiple of 16);
+ *   slope    device int32[1] (Q6.25) or NULL; zero_point device int64[1] or NULL;
+ *   out      int8 or int32 [n_out][ldo]; for int8 outputs the columns c_out..out_pad are written as zeros so that the
+ *            tensor can feed the next layer as A. */
+int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                 int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope,
+                 const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
+                 int out_pad, int c_out, int64_t n_out, void *stream);
+
+/* Stand-alone epilogue on an int32 matrix [n][ch] (row stride ldi): requant_to_int{8,32}, bias_requant_*, prelu_requant_*,
+ * bias_prelu_requant_* (src/element_wise/*.cu).  mul_per_channel == 0 broadcasts requant_mul[0]
+ * (RequantFxpToScaledInt8, cuda_ops.py:505-509). */
+int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
+                      int mul_per_channel, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
+                      int out_pad, int64_t n, int ch, void *stream);
+
+/* out = clamp_i32(prelu_q6.25(a (+ b, wrapping))): `prelu` (src/element_wise/prelu.cu) with the residual add of
+ * SparseResBlockIn32W8Out32.forward (cuda_ops.py:90) fused; b may be NULL. */
+int fpcc_prelu_i32(const int32_t *a, const int32_t *b, const int32_t *slope, int64_t n, int32_t *out, void *stream);
+
+/* softmax_int32 (src/softmax.cu:119-144): in int32 [n][c] Q15.16 -> out uint32 [n][c] Q0.32, 2 <= c <= 256. */
+int fpcc_softmax_i32(const int32_t *in, int64_t n, int c, uint32_t *out, void *stream);
+/* Model.batch_quantize_pmf_torch (models/convolutional/lossl_coord_int/model.py:345-353) in one pass: logits >> pre_shift,
+ * LUT softmax, ((p * (65536 - c)) >> 32) + 1, cumulative sum, last entry 65535 -> uint16 CDF rows [n][c]. */
+int fpcc_logits_to_cdf16(const int32_t *logits, int64_t n, int c, int pre_shift, uint16_t *cdf_out, void *stream);
+/* Encoder side of the same: only the (start, freq - 1) of the coded symbol of every row leaves the device (4 B per
+ * symbol instead of 2*c), ready for fpcc_simple_enc_push_ranges. */
+int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift, const int16_t *symbols,
+                          uint16_t *start_out, uint16_t *freq_minus_1_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,380 @@
+"""TEST ORACLE -- not product code.
+
+CPU restatement of the integer-only lossless codec of the reference, driven by a dict of tensors with the reference's
+state_dict keys:
+
+    Model.compress / decompress / get_bin / batch_quantize_pmf_torch   /root/reference/models/convolutional/lossl_coord_int/model.py:216-521
+    OneScalePredictor, OneScaleMultiStepPredictor                        /root/reference/models/convolutional/lossl_coord_int/model.py:28-213
+    sparse_conv_in8w8out32, the In8W8 modules, requant / PReLU          /root/reference/lib/int_sparse_conv/cuda_ops.py:62-169,323-635
+    kernel-offset enumeration of the hash lookup                         /root/reference/lib/int_sparse_conv/src/hashmap/hashmap_cuda.cuh:239-258
+    epilogues, LUT softmax                                               oracle/int_ops.c (which cites the .cu sources)
+    rANS stream                                                          oracle/rans.c
+
+Parity: UNPINNED against the reference binary (CUDA + CUTLASS only); the arithmetic is exact
+integer math specified by the reference's scalar device functions, the exponent table and the coder are pinned by golden
+data.  int8 GEMMs are evaluated per kernel offset in float32 BLAS, which is exact here (|sum| <= 127*127*832 < 2^24) and
+accumulated in int64.
+"""
+import ctypes as C
+import io
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import lib
+from .coords import morton_encode
+from .rans import RansDecoder, RansEncoder
+
+SHIFT = 23
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _np(t) -> np.ndarray:
+    if hasattr(t, 'detach'):
+        import torch
+        t = t.detach().cpu()
+        if t.dtype == torch.uint32:
+            t = t.to(torch.int64)
+        return t.numpy()
+    return np.asarray(t)
+
+
+def epilogue(x: np.ndarray, bias, slope, mul, zp: int, shift: int, out_bits: int) -> np.ndarray:
+    fn = lib().orc_epilogue_i32
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    n, ch = x.shape
+    mul = np.ascontiguousarray(np.broadcast_to(np.asarray(mul, dtype=np.int64).reshape(-1), (ch,)) & 0xffffffff, dtype=np.uint32)
+    bias = None if bias is None else np.ascontiguousarray(bias, dtype=np.int32)
+    slope = None if slope is None else np.ascontiguousarray(slope, dtype=np.int32).reshape(1)
+    out = np.empty_like(x)
+    assert shift >= 0
+    fn(_p(x), _p(bias), _p(slope), _p(mul), int(zp), int(shift), out_bits, n, ch, _p(out))
+    return out
+
+
+def prelu_i32(x: np.ndarray, slope: int) -> np.ndarray:
+    fn = lib().orc_prelu_i32
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    out = np.empty_like(x)
+    fn(_p(x), int(slope), x.size, _p(out))
+    return out
+
+
+def softmax_i32(x: np.ndarray) -> np.ndarray:
+    fn = lib().orc_softmax_i32
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    out = np.empty(x.shape, dtype=np.uint32)
+    fn(_p(x), x.shape[0], x.shape[1], _p(out))
+    return out
+
+
+def quantize_pmf(logits: np.ndarray) -> np.ndarray:
+    """Model.batch_quantize_pmf_torch (model.py:345-353): Q8.23 logits -> uint16 CDF rows"""
+    p = softmax_i32(logits >> (SHIFT - 16)).astype(np.int64)
+    f = ((p * (65536 - logits.shape[1])) >> 32) + 1
+    cdf = np.cumsum(f, axis=1)
+    cdf[:, -1] = 65535
+    return cdf.astype(np.uint16)
+
+
+def _key(c: np.ndarray) -> np.ndarray:
+    c = c.astype(np.int64)
+    return (c[:, 0] << 60) | (c[:, 1] << 40) | (c[:, 2] << 20) | c[:, 3]
+
+
+def kernel_table(in_coords: np.ndarray, out_coords: np.ndarray, ks: Tuple[int, int, int], st: Tuple[int, int, int]) -> np.ndarray:
+    """[K, N_out] input row per (kernel offset, output row), -1 absent.  Neighbour = out*stride + offset with
+    offset_i = (k_i % ks_i) - (ks_i - 1)//2; odd volume: x fastest, even volume: z fastest (hashmap_cuda.cuh:239-258)."""
+    order = np.argsort(_key(in_coords), kind='stable')
+    keys = _key(in_coords)[order]
+    volume = ks[0] * ks[1] * ks[2]
+    table = np.full((volume, len(out_coords)), -1, dtype=np.int64)
+    axes = (0, 1, 2) if volume % 2 else (2, 1, 0)
+    for k in range(volume):
+        rem, q = k, out_coords.astype(np.int64).copy()
+        for a in axes:
+            q[:, 1 + a] = q[:, 1 + a] * st[a] + rem % ks[a] - (ks[a] - 1) // 2
+            rem //= ks[a]
+        ok = (q[:, 1:] >= 0).all(1)
+        kq = _key(np.where(ok[:, None], q, 0))
+        pos = np.minimum(np.searchsorted(keys, kq), len(keys) - 1)
+        hit = ok & (keys[pos] == kq)
+        table[k, hit] = order[pos[hit]]
+    return table
+
+
+def conv_i8(a: np.ndarray, table: Optional[np.ndarray], w: np.ndarray, zp_comp: Optional[np.ndarray] = None) -> np.ndarray:
+    """a int8 [N, C_in], w int8 [K, C_out, C_in] -> int32 [N_out, C_out] accumulators (cuda_ops.py:153-166)"""
+    n_out = a.shape[0] if table is None else table.shape[1]
+    out = np.zeros((n_out, w.shape[1]), dtype=np.int64)
+    af = a.astype(np.float32)
+    for k in range(w.shape[0]):
+        wk = w[k].astype(np.float32).T
+        if table is None:
+            out += (af @ wk).astype(np.int64)
+            continue
+        rows = np.nonzero(table[k] >= 0)[0]
+        if len(rows) == 0:
+            continue
+        out[rows] += (af[table[k, rows]] @ wk).astype(np.int64)
+        if zp_comp is not None:
+            out[rows] += zp_comp[k].astype(np.int64)
+    assert np.abs(out).max(initial=0) < 2 ** 31
+    return out.astype(np.int32)
+
+
+class Sp:
+    """feats + coords [N, 4] (batch, x, y, z) in level units + stride, with caches shared along a cloud"""
+
+    def __init__(self, F, C_, stride, caches=None):
+        self.F, self.C, self.stride = F, C_, stride
+        self.caches = caches if caches is not None else {'cmaps': {}, 'tables': {}}
+
+
+class OracleInt:
+    def __init__(self, weights: Dict[str, object], cfg):
+        self.P = {k: _np(v) for k, v in weights.items()}
+        self.cfg = cfg
+        self.levels_wo_rec = int(np.log2(cfg.max_stride_wo_recurrent))
+        self.levels = int(np.log2(cfg.max_stride))
+        self.bin2oct = np.arange(7, -1, -1)
+        self.unfold = np.array([(0, dx, dy, dz) for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)], dtype=np.int64)[None]
+        self.cdf1 = np.arange(2, 65537, dtype=np.int64).astype(np.uint16)[None].copy()
+        self.cdf2 = (np.arange(1, 129, dtype=np.int64) * 512).astype(np.uint16)[None].copy()
+        self.cdf1[:, -1] = 65535
+        self.cdf2[:, -1] = 65535
+
+    # -- parameterised layers ------------------------------------------------------------------------------------------
+    def _has(self, pre):
+        return (pre + '.requant_mul') in self.P
+
+    def requant(self, pre: str, x: np.ndarray) -> np.ndarray:
+        P = self.P
+        return epilogue(x, None, None, P[pre + '.requant_mul'], int(P[pre + '.int_zero_point_out'][0]),
+                        SHIFT + int(P[pre + '.requant_shift'][0]), 8).astype(np.int8)
+
+    def _finish(self, pre: str, acc: np.ndarray, with_bias: bool) -> np.ndarray:
+        P = self.P
+        out8 = float(P[pre + '.scale_out'][0]) > 0           # scaled-int outputs carry a scale, fixed-point ones keep -1
+        shift = int(P[pre + '.requant_shift'][0]) - (0 if out8 else SHIFT)
+        slope = P.get(pre + '.slope')
+        out = epilogue(acc, P[pre + '.bias'] if with_bias else None, slope, P[pre + '.requant_mul'],
+                       int(P[pre + '.int_zero_point_out'][0]), shift, 8 if out8 else 32)
+        return out.astype(np.int8) if out8 else out
+
+    def sconv(self, pre: str, x: Sp, ks=(3, 3, 3), st=(1, 1, 1)) -> Sp:
+        w = self.P[pre + '.weight']
+        if st == (1, 1, 1):
+            out_c, out_stride = x.C, x.stride
+        else:
+            out_stride = x.stride * st[0]
+            out_c = x.caches['cmaps'][out_stride]
+        tag = (x.stride, ks, st)
+        if tag not in x.caches['tables']:
+            x.caches['tables'][tag] = kernel_table(x.C, out_c, ks, st)
+        x.caches['cmaps'].setdefault(x.stride, x.C)
+        acc = conv_i8(x.F, x.caches['tables'][tag], w, self.P.get(pre + '.int_zero_point_in_comp'))
+        return Sp(self._finish(pre, acc, True), out_c, out_stride, x.caches)
+
+    def linear(self, pre: str, f: np.ndarray) -> np.ndarray:
+        acc = conv_i8(f, None, self.P[pre + '.weight'][None])
+        acc = (acc.astype(np.int64) + self.P[pre + '.bias'].astype(np.int64)).astype(np.int32)     # gemm adds the bias (cuda_ops.py:610-611)
+        return self._finish(pre, acc, False)
+
+    def resblock(self, pre: str, x: Sp) -> Sp:
+        y = Sp(self.requant(pre + '.input_requant', x.F), x.C, x.stride, x.caches)
+        y = self.sconv(pre + '.conv2', self.sconv(pre + '.conv_prelu', y))
+        s = (x.F.astype(np.int64) + y.F.astype(np.int64)).astype(np.int32)      # wrapping int32 add
+        return Sp(prelu_i32(s, int(self.P[pre + '.prelu.slope'][0])), x.C, x.stride, x.caches)
+
+    # -- predictors ----------------------------------------------------------------------------------------------------
+    def _symbols(self, bits):
+        return ((bits.astype(np.int64) << self.bin2oct).sum(1) - 1).astype(np.uint16)
+
+    def _bits(self, symbols):
+        return (((symbols.astype(np.int64)[:, None] + 1) >> self.bin2oct) & 1).astype(bool)
+
+    def _children(self, coords, mask):
+        c = coords.astype(np.int64)[:, None].copy()
+        c[..., 1:] <<= 1
+        return (c + self.unfold)[mask]
+
+    def one_scale_trunk(self, pre: str, x: Sp):
+        if x.F.shape[1] == 1:
+            x = self.sconv(pre + '.dec_init', x)
+        x = self.resblock(pre + '.dec', x)
+        y = Sp(self.requant(pre + '.pred.0', x.F), x.C, x.stride, x.caches)
+        y = self.sconv(pre + '.pred.1', y)
+        return x, self.linear(pre + '.pred.2', y.F)
+
+    def one_scale_expand(self, pre: str, x: Sp, bits: np.ndarray, child_coords, caches) -> Sp:
+        f = np.concatenate((x.F, bits.astype(np.int32) << SHIFT), 1)
+        u = pre + '.upsample'
+        y = Sp(self.linear(u + '.1', self.requant(u + '.0', f)), x.C, x.stride, x.caches)
+        y = self.resblock(u + '.2', y)
+        f = self.linear(u + '.4', self.requant(u + '.3', y.F))
+        f = f.reshape(f.shape[0], 8, f.shape[1] // 8)[bits.astype(bool)]
+        return Sp(f, child_coords, x.stride // 2, caches)
+
+    def multi_refresh(self, pre: str, x: Sp, embed_bits, embed_coords, embed_stride) -> Sp:
+        e = Sp(embed_bits.astype(np.int32) << SHIFT, embed_coords, embed_stride, x.caches)
+        if self._has(pre + '.embed.0'):
+            span = x.stride // embed_stride
+            e.F = self.requant(pre + '.embed.0', e.F)
+            e = self.sconv(pre + '.embed.1', e, (span,) * 3, (span,) * 3)
+        f = np.concatenate((x.F, e.F), 1)
+        d = pre + '.dec'
+        if self._has(d + '.0'):
+            y = Sp(self.linear(d + '.1', self.requant(d + '.0', f)), x.C, x.stride, x.caches)
+            return self.resblock(d + '.2', y)
+        return self.resblock(d, Sp(f, x.C, x.stride, x.caches))
+
+    def multi_descend(self, pre: str, x: Sp, steps: int, masks, below, coords, strides) -> np.ndarray:
+        p = pre + '.pred'
+        y = Sp(self.requant(p + '.0.0', x.F), x.C, x.stride, x.caches)
+        f = self.linear(p + '.0.2', self.sconv(p + '.0.1', y).F)
+        for i in range(1, steps):
+            f = f.reshape(f.shape[0], 8, f.shape[1] // 8)[masks[i - 1]]
+            q = f'{p}.{i}'
+            if i != steps - 1:
+                f = np.concatenate((f, below[i - 1].astype(np.int32) << SHIFT), 1)
+                f = prelu_i32(f, int(self.P[q + '.0.slope'][0]))
+                f = self.linear(q + '.2', self.requant(q + '.1', f))
+                y = self.sconv(q + '.3', Sp(f, coords[i - 1], strides[i - 1], x.caches))
+                f = self.linear(q + '.4', y.F)
+            else:
+                y = self.sconv(q + '.1', Sp(self.requant(q + '.0', f), coords[i - 1], strides[i - 1], x.caches))
+                f = self.linear(q + '.2', y.F)
+        return f
+
+    # -- side information ----------------------------------------------------------------------------------------------
+    @staticmethod
+    def bottom_cdf(values: np.ndarray) -> np.ndarray:
+        counts = np.bincount(values.astype(np.int64), minlength=2).astype(np.int64)
+        f = ((counts * (((65536 - counts.shape[0]) << 8) // values.size)) >> 8) + 1
+        cdf = np.cumsum(f)
+        cdf[-1] = 65535
+        return cdf.astype(np.uint16)
+
+    def _block(self, idx: int, n_blocks: int, skip: int):
+        if idx > n_blocks:
+            return 'block_dec_recurrent', 'one', True
+        j = idx - 1 + skip
+        steps = int(np.log2(self.cfg.fea_stride)) - j
+        if steps < 1:
+            return f'blocks_dec.{j}', 'one', True
+        if steps == 1:
+            return f'blocks_dec.{j}', 'one', False
+        return f'blocks_dec.{j}', steps, None
+
+    # -- codec ---------------------------------------------------------------------------------------------------------
+    def compress(self, xyz: np.ndarray) -> bytes:
+        xyz = np.asarray(xyz, dtype=np.int64)
+        offset = xyz[:, 1:].min(0)
+        xyz = xyz.copy()
+        xyz[:, 1:] -= offset
+        xyz = xyz[np.argsort(morton_encode(xyz[:, 1:], 'xyz', inverse=True), kind='stable')]
+        skip = self.cfg.skip_top_scales_num
+        levels = self.levels - skip
+        n_blocks = self.levels_wo_rec - skip
+        caches = {'cmaps': {}, 'tables': {}}
+        coords, bits = [xyz], [None]
+        for _ in range(levels):
+            c = coords[-1].copy()
+            c[:, 1:] >>= 1
+            keep = np.ones(len(c), bool)
+            keep[1:] = (c[1:] != c[:-1]).any(1)
+            parents = c[keep]
+            table = kernel_table(coords[-1], parents, (2, 2, 2), (2, 2, 2))
+            bits.append((table >= 0).T.astype(np.int32))
+            coords.append(parents)
+        for l, c in enumerate(coords):
+            caches['cmaps'][1 << l] = c
+        cur = Sp(np.ones((len(coords[-1]), 1), np.int8), coords[-1], 1 << levels, caches)
+        self.symbols, self.cdfs = [], []
+        for idx in range(levels, 0, -1):
+            pre, kind, can_up = self._block(idx, n_blocks, skip)
+            if kind == 'one':
+                cur, logits = self.one_scale_trunk(pre, cur)
+                sym = self._symbols(bits[idx])
+                if idx != 1 and can_up:
+                    cur = self.one_scale_expand(pre, cur, bits[idx], coords[idx - 1], caches)
+            else:
+                steps = kind
+                cur = self.multi_refresh(pre, cur, bits[idx + 1], coords[idx + 1], 1 << (idx + 1))
+                lv = [idx + steps - 1 - i for i in range(1, steps)]            # levels reached by the refinements
+                masks = [bits[l + 1].astype(bool) for l in lv]
+                below = [bits[l] for l in lv]
+                logits = self.multi_descend(pre, cur, steps, masks, below, [coords[l] for l in lv], [1 << l for l in lv])
+                sym = self._symbols(bits[idx])
+            self.symbols.append(sym)
+            self.cdfs.append(quantize_pmf(logits))
+        enc = RansEncoder(32 << 20)
+        for cdf, sym in zip(reversed(self.cdfs), reversed(self.symbols)):
+            enc.encode(cdf, sym)
+        bottom = coords[-1][:, 1:].reshape(-1)
+        bcdf = self.bottom_cdf(bottom)
+        enc.encode(bcdf[None], bottom.astype(np.uint16))
+        enc.encode(self.cdf1, (bcdf[:-1] - 1).astype(np.uint16))
+        enc.encode(self.cdf2, np.array([len(bcdf) - 2], dtype=np.uint16))
+        return b''.join(int(v).to_bytes(2, 'little') for v in offset.tolist()) + \
+            (len(bottom) // 3).to_bytes(2, 'little') + enc.flush()
+
+    def decompress(self, data: bytes) -> np.ndarray:
+        offset = np.array([int.from_bytes(data[i:i + 2], 'little') for i in (0, 2, 4)], dtype=np.int64)
+        n_bottom = int.from_bytes(data[6:8], 'little')
+        dec = RansDecoder()
+        dec.flush(data[8:])
+        cdf_len = np.empty(1, np.uint16)
+        dec.decode(self.cdf2, cdf_len)
+        cdf = np.empty(int(cdf_len[0]) + 1, np.uint16)
+        dec.decode(self.cdf1, cdf)
+        cdf = np.pad(cdf + 1, (0, 1))
+        cdf[-1] = 65535
+        bottom = np.empty(n_bottom * 3, np.uint16)
+        dec.decode(cdf[None], bottom)
+
+        def pop(logits):
+            out = np.empty(logits.shape[0], np.uint16)
+            dec.decode(quantize_pmf(logits), out)
+            return out
+
+        skip = self.cfg.skip_top_scales_num
+        levels = self.levels - skip
+        n_blocks = self.levels_wo_rec - skip
+        coords = np.concatenate((np.zeros((n_bottom, 1), np.int64), bottom.astype(np.int64).reshape(-1, 3)), 1)
+        cur = Sp(np.ones((n_bottom, 1), np.int8), coords, 1 << levels)
+        hist: List[np.ndarray] = []
+        top, top_stride, cur_bin = None, None, None
+        for idx in range(levels, 0, -1):
+            pre, kind, can_up = self._block(idx, n_blocks, skip)
+            if kind == 'one':
+                cur, logits = self.one_scale_trunk(pre, cur)
+                cur_bin = self._bits(pop(logits))
+                if idx != 1 and can_up:
+                    cur = self.one_scale_expand(pre, cur, cur_bin, self._children(cur.C, cur_bin), None)
+            else:
+                steps = kind
+                hist.append(cur_bin)
+                if len(hist) == 1:
+                    top, top_stride = cur.C, cur.stride
+                top = self._children(top, hist[-1])
+                top_stride //= 2
+                cur.caches['cmaps'][top_stride] = top
+                cur = self.multi_refresh(pre, cur, hist[-1], cur.caches['cmaps'][top_stride * 2], top_stride * 2)
+                strides = [cur.stride >> i for i in range(1, steps)]
+                masks = [hist[i - 1] for i in range(1, steps)]
+                below = [hist[i] if i < len(hist) else None for i in range(1, steps)]
+                logits = self.multi_descend(pre, cur, steps, masks, below, [cur.caches['cmaps'][s] for s in strides], strides)
+                cur_bin = self._bits(pop(logits))
+        parents = cur.C if top is None else top
+        return (self._children(parents, cur_bin)[:, 1:] + offset).astype(np.int32)
