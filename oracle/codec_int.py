@@ -121,6 +121,8 @@ def conv_i8(a: np.ndarray, table: Optional[np.ndarray], w: np.ndarray, zp_comp: 
         wk = w[k].astype(np.float32).T
         if table is None:
             out += (af @ wk).astype(np.int64)
+            if zp_comp is not None:
+                out += zp_comp[k].astype(np.int64)
             continue
         rows = np.nonzero(table[k] >= 0)[0]
         if len(rows) == 0:

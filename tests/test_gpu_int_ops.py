@@ -149,7 +149,8 @@ def test_softmax_and_cdf(ops, c):
     assert (cdf == want).all()
     sym = rng.integers(0, c, len(x)).astype(np.int16)
     start, fm1 = ops.logits_to_ranges(_cuda(x), 7, _cuda(sym))
-    lo = np.where(sym > 0, want[np.arange(len(x)), np.maximum(sym - 1, 0)], 0).astype(np.int64)
-    hi = np.where(sym == c - 1, 65536, want[np.arange(len(x)), sym]).astype(np.int64)
+    w64 = want.astype(np.int64)
+    lo = np.where(sym > 0, w64[np.arange(len(x)), np.maximum(sym - 1, 0)], 0)
+    hi = np.where(sym == c - 1, 65536, w64[np.arange(len(x)), sym])
     assert (start.cpu().numpy().view(np.uint16) == lo).all()
     assert (fm1.cpu().numpy().view(np.uint16) == hi - lo - 1).all()
