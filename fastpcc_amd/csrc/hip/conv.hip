@@ -236,6 +236,275 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Pair-compacted variant for large maps ("order 2").
+//
+// The dense tile above executes every row of a 32-row block for every offset present in the block; on surfaces only
+// ~48 % of the (row, offset) pairs exist, so it runs ~1.8x the algorithmic flop.  Here a workgroup (8 waves, 128 output
+// rows) compacts, per kernel offset, the rows that HAVE that neighbour, runs the MFMAs over ceil(count/32) packed row
+// blocks only, and adds the finished per-offset partial sums into an fp32 accumulator tile in LDS (each (row, column)
+// has one writer per offset, offsets are separated by barriers: plain read-modify-write, no atomics, reproducible).
+// Summation order: per offset an FMA chain from zero (MFMA channel order), partial sums added in ascending offset
+// order, then the bias -- "order 2" of fpcc_hip.h, the association of a per-offset gather-GEMM-scatter-add evaluation.
+// Loads run two stages ahead through two register sets (one workgroup per CU: 145 KB of LDS).
+constexpr int kCmpRows = 128;
+constexpr int kCmpThreads = 512;
+
+template <int NBT, int CH>
+struct CmpCfg {
+    static constexpr int C_OUT = 32 * NBT;
+    static constexpr int NPG = 8 / NBT;                              // waves sharing a column block split the row passes
+    static constexpr int MAXP = (4 + NPG - 1) / NPG;                 // passes per wave (a tile has at most 4)
+    static constexpr int PPR = CH / 4;
+    static constexpr int A_TOTAL = kCmpRows * PPR;
+    static constexpr int A_PIECES = (A_TOTAL + kCmpThreads - 1) / kCmpThreads;
+    static constexpr int W_TOTAL = CH * C_OUT / 4;
+    static constexpr int W_PIECES = (W_TOTAL + kCmpThreads - 1) / kCmpThreads;
+};
+
+template <typename C, int CH>
+__device__ __forceinline__ void cmp_fetch(const ConvArgs &a, const float *wg, const int32_t *s_in, int c_in, int tid, int k,
+                                          int cc, int rows, f32x4 (&ra)[C::A_PIECES], f32x4 (&rw)[C::W_PIECES]) {
+    const bool in_x1 = cc * CH < a.c1;
+    const float *xb = in_x1 ? a.x1 + cc * CH : a.x2 + (cc * CH - a.c1);
+    const int64_t ld = in_x1 ? a.ld1 : a.ld2;
+#pragma unroll
+    for (int j = 0; j < C::A_PIECES; ++j) {
+        const int p = tid + kCmpThreads * j;
+        const int r = p / C::PPR, q = p % C::PPR;
+        // branch-free: rows past the packed count read the zero row (a branch around the load would make hipcc wait
+        // vmcnt(0) per piece and serialise the gather)
+        const int32_t idx = r < rows ? s_in[k * kCmpRows + r] : -1;
+        const float *src = idx >= 0 ? xb + (int64_t)idx * ld + 4 * q : (const float *)g_zero_row;
+        ra[j] = *reinterpret_cast<const f32x4 *>(src);
+    }
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wg + ((int64_t)k * c_in + (int64_t)cc * CH) * C::C_OUT);
+#pragma unroll
+    for (int j = 0; j < C::W_PIECES; ++j) {
+        const int p = tid + kCmpThreads * j;
+        if (C::W_TOTAL % kCmpThreads == 0 || p < C::W_TOTAL) rw[j] = wsrc[p];
+    }
+}
+
+template <typename C, int CH>
+__device__ __forceinline__ void cmp_stash(float *dA, float *dWf, int tid, int /*rows*/, const f32x4 (&ra)[C::A_PIECES],
+                                          const f32x4 (&rw)[C::W_PIECES]) {
+#pragma unroll
+    for (int j = 0; j < C::A_PIECES; ++j) {
+        const int p = tid + kCmpThreads * j;
+        const int r = p / C::PPR, q = p % C::PPR;
+        *reinterpret_cast<f32x4 *>(dA + r * CH + 4 * (q ^ swz<CH>(r))) = ra[j];
+    }
+    f32x4 *dW = reinterpret_cast<f32x4 *>(dWf);
+#pragma unroll
+    for (int j = 0; j < C::W_PIECES; ++j) {
+        const int p = tid + kCmpThreads * j;
+        if (C::W_TOTAL % kCmpThreads == 0 || p < C::W_TOTAL) dW[p] = rw[j];
+    }
+}
+
+template <int NBT, int CH>
+__global__ __launch_bounds__(kCmpThreads) void k_conv_cmp(ConvArgs a) {
+    using C = CmpCfg<NBT, CH>;
+    constexpr int C_OUT = C::C_OUT;
+    constexpr int TM = kCmpRows;
+    constexpr int MAXP = C::MAXP;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    float *sA = reinterpret_cast<float *>(dyn_smem);                       // [2][TM*CH]
+    float *sW = sA + 2 * TM * CH;                                          // [2][CH*C_OUT]
+    float *sOut = sW + 2 * CH * C_OUT;                                     // [TM][C_OUT]
+    int32_t *s_in = reinterpret_cast<int32_t *>(sOut + TM * C_OUT);        // [27][TM] compact input rows (-1 padded)
+    uint8_t *s_row = reinterpret_cast<uint8_t *>(s_in + kMaxOffsets * TM); // [27][TM] compact -> local output row
+    int32_t *s_cnt = reinterpret_cast<int32_t *>(s_row + kMaxOffsets * TM);// [27]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cb = wave % NBT, pg = wave / NBT;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)tile * TM;
+    const int c_in = a.c1 + a.c2;
+    const int n_chunks = c_in / CH;
+    const float *wg = a.w;
+
+    // --- per offset: compact the rows that have this neighbour (one wave per offset, 2 x 64 rows) ---------------------
+    for (int k = wave; k < a.n_off; k += 8) {
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 64 * h + lane;
+            const int64_t row = row0 + r;
+            int32_t v = -1;
+            if (row < a.n_out) v = a.nbr[(int64_t)k * a.nbr_ks + row * a.nbr_os];
+            const unsigned long long m = __ballot(v >= 0);
+            if (v >= 0) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                s_in[k * TM + pos] = v;
+                s_row[k * TM + pos] = (uint8_t)r;
+            }
+            base += __popcll(m);
+        }
+        const int padded = (base + 31) & ~31;
+        for (int j = base + lane; j < padded; j += 64) s_in[k * TM + j] = -1;
+        if (lane == 0) s_cnt[k] = base;
+    }
+    for (int e = tid; e < TM * C_OUT; e += kCmpThreads) sOut[e] = 0.0f;
+    __syncthreads();
+
+    unsigned kmask = 0;
+    for (int k = 0; k < a.n_off; ++k) if (s_cnt[k] > 0) kmask |= 1u << k;
+    const int n_stages = __popc(kmask) * n_chunks;
+
+    f32x16 acc[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    f32x4 ra0[C::A_PIECES], rw0[C::W_PIECES], ra1[C::A_PIECES], rw1[C::W_PIECES];
+
+    // stage cursor: (offset, chunk) in ascending offset order
+    struct Cursor { unsigned rest; int k, cc; };
+    auto first = [&](Cursor &c) { c.rest = kmask; c.k = __ffs(c.rest) - 1; c.cc = 0; };
+    auto next = [&](Cursor &c) {
+        if (++c.cc == n_chunks) { c.cc = 0; c.rest &= c.rest - 1; c.k = c.rest ? __ffs(c.rest) - 1 : 0; }
+    };
+    auto rows_of = [&](int k) { return (s_cnt[k] + 31) & ~31; };
+
+    auto compute = [&](int buf, int k, int cc) {
+        const float *cA = sA + buf * TM * CH;
+        const float *cW = sW + buf * CH * C_OUT;
+        const int cnt = s_cnt[k];
+        const int npass = (cnt + 31) >> 5;
+        if (pg < npass) {
+#pragma unroll
+            for (int g8 = 0; g8 < CH / 8; ++g8) {
+                const float *wrow = cW + (8 * g8 + 4 * lh) * C_OUT + 32 * cb + li;
+                const float b0 = wrow[0], b1 = wrow[C_OUT], b2 = wrow[2 * C_OUT], b3 = wrow[3 * C_OUT];
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    const int p = pg + i * C::NPG;
+                    if (p < npass) {
+                        const int r = 32 * p + li;
+                        const int q = 2 * g8 + lh;
+                        const f32x4 av = *reinterpret_cast<const f32x4 *>(cA + r * CH + 4 * (q ^ swz<CH>(r)));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            if (cc == n_chunks - 1) {
+                // this offset's partial sums are complete: add them into the accumulator tile
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    const int p = pg + i * C::NPG;
+                    if (p < npass) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int j = 32 * p + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                            if (j < cnt) {
+                                float *dst = sOut + (int)s_row[k * TM + j] * C_OUT + 32 * cb + li;
+                                *dst = *dst + acc[i][reg];
+                            }
+                            acc[i][reg] = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    if (n_stages > 0) {
+        // Software pipeline, two slots per iteration (static register-set names): stage s is FETCHED in slot s, written to
+        // LDS at the end of slot s+1 and COMPUTED in slot s+2, so a gather has two slots to land.  Every global load is
+        // unconditional and the loop is entered with nothing in flight (the first two slots only fetch): with loads
+        // under a branch, or in flight across the loop entry, hipcc cannot count the younger loads and waits vmcnt(0)
+        // before the LDS writes, which would serialise the pipeline.  Past the last stage the cursor parks on a valid
+        // stage whose data is never used.
+        Cursor cf;
+        first(cf);
+        int k0 = 0, c0 = 0, k1 = 0, c1 = 0;          // stage held by register set 0 / 1
+        int kb0 = 0, cb0 = 0, kb1 = 0, cb1 = 0;      // stage resident in LDS buffer 0 / 1
+        for (int it = 0; it < n_stages + 2; it += 2) {
+            {   // even slot: fetch stage `it` -> set 0; compute stage it-2 (buffer 0); set 1 (stage it-1) -> buffer 1
+                const int ke = cf.k, ce = cf.cc;
+                cmp_fetch<C, CH>(a, wg, s_in, c_in, tid, ke, ce, rows_of(ke), ra0, rw0);
+                next(cf);
+                if (it >= 2) compute(0, kb0, cb0);
+                if (it >= 1) {
+                    cmp_stash<C, CH>(sA + TM * CH, sW + CH * C_OUT, tid, 0, ra1, rw1);
+                    kb1 = k1;
+                    cb1 = c1;
+                }
+                k0 = ke;
+                c0 = ce;
+                __syncthreads();
+            }
+            {   // odd slot: fetch stage it+1 -> set 1; compute stage it-1 (buffer 1); set 0 (stage it) -> buffer 0
+                const int ko = cf.k, co = cf.cc;
+                cmp_fetch<C, CH>(a, wg, s_in, c_in, tid, ko, co, rows_of(ko), ra1, rw1);
+                next(cf);
+                if (it >= 1 && it - 1 < n_stages) compute(1, kb1, cb1);
+                cmp_stash<C, CH>(sA, sW, tid, 0, ra0, rw0);
+                kb0 = k0;
+                cb0 = c0;
+                k1 = ko;
+                c1 = co;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+
+    // --- epilogue: accumulator tile -> bias, activation, clamp -> global, 16 bytes per thread ---------------------------
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    constexpr int VPR = C_OUT / 4;
+    for (int e = tid; e < TM * VPR; e += kCmpThreads) {
+        const int r = e / VPR, v = e % VPR;
+        const int64_t o = row0 + r;
+        if (o >= a.n_out) continue;
+        const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os] : o;
+        if (dst < 0) continue;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(sOut + r * C_OUT + 4 * v);
+        f32x4 res;
+        res.x = finish(t.x, a.bias ? a.bias[4 * v] : 0.0f, a.act, slope, a.clip);
+        res.y = finish(t.y, a.bias ? a.bias[4 * v + 1] : 0.0f, a.act, slope, a.clip);
+        res.z = finish(t.z, a.bias ? a.bias[4 * v + 2] : 0.0f, a.act, slope, a.clip);
+        res.w = finish(t.w, a.bias ? a.bias[4 * v + 3] : 0.0f, a.act, slope, a.clip);
+        float *orow = a.out + dst * a.ldo + 4 * v;
+        if ((a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+            *reinterpret_cast<f32x4 *>(orow) = res;
+        } else {
+            orow[0] = res.x; orow[1] = res.y; orow[2] = res.z; orow[3] = res.w;
+        }
+    }
+}
+
+template <int NBT, int CH>
+constexpr size_t cmp_lds_bytes() {
+    return sizeof(float) * (2 * kCmpRows * CH + 2 * CH * 32 * NBT + kCmpRows * 32 * NBT) +
+           sizeof(int32_t) * kMaxOffsets * kCmpRows + kMaxOffsets * kCmpRows + sizeof(int32_t) * 32;
+}
+
+template <int NBT, int CH>
+int launch_cmp(const ConvArgs &a, hipStream_t s) {
+    const unsigned tiles = (unsigned)((a.n_out + kCmpRows - 1) / kCmpRows);
+    constexpr size_t lds = cmp_lds_bytes<NBT, CH>();
+    static bool configured = false;
+    if (!configured) {
+        if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_cmp<NBT, CH>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                               "hipFuncSetAttribute(k_conv_cmp)"))
+            return rc;
+        configured = true;
+    }
+    hipLaunchKernelGGL((k_conv_cmp<NBT, CH>), dim3(tiles), dim3(kCmpThreads), lds, s, a);
+    return check_hip(hipGetLastError(), "k_conv_cmp");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // VALU path: thread = (output row, group, block of JB output channels); natural channel order.
 template <int JB>
 __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
@@ -326,7 +595,22 @@ int launch_valu(const ConvArgs &a, hipStream_t s) {
 
 using namespace fpcc;
 
+// rows from which the pair-compacted kernel is used for multi-offset convolutions
+constexpr int64_t kCmpMinRows = 32 * 1024;
+
+// Measured on MI355X (profiles/r01): the compacted kernel executes ~35 % fewer MFMAs but runs one workgroup per CU
+// (145 KB of LDS); it wins for C_in >= 128, C_out = 128 and loses to the dense tile for narrower layers.
+static bool use_cmp(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
+    return mfma_chunk(c1, c2, c_out) == 32 && c1 + c2 >= 128 && c_out == 128 && n_offsets >= 8 &&
+           n_offsets <= kMaxOffsets && groups == 1 && n_out >= kCmpMinRows;
+}
+
 extern "C" int fpcc_conv_f32_order(int c1, int c2, int c_out) { return mfma_chunk(c1, c2, c_out) ? 1 : 0; }
+
+extern "C" int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
+    if (use_cmp(c1, c2, c_out, n_offsets, groups, n_out)) return 2;
+    return mfma_chunk(c1, c2, c_out) ? 1 : 0;
+}
 
 extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2, const int32_t *nbr,
                              int n_offsets, int64_t nbr_ks, int64_t nbr_os, const float *w, const float *bias, int c_out,
@@ -350,6 +634,11 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
     if (ch && n_offsets > kMaxOffsets) return fail_arg("conv_f32: the MFMA path supports at most 27 kernel offsets");
     if (ch && !(aligned16(x1) && ld1 % 4 == 0 && aligned16(w) && (c2 == 0 || (aligned16(x2) && ld2 % 4 == 0))))
         return fail_arg("conv_f32: the MFMA path needs 16-byte aligned inputs and row strides that are multiples of 4");
+    if (nbr && use_cmp(c1, c2, c_out, n_offsets, groups, n_out)) {
+        if (c_out == 128) return launch_cmp<4, 32>(a, s);
+        if (c_out == 64) return launch_cmp<2, 32>(a, s);
+        return launch_cmp<1, 32>(a, s);
+    }
     if (ch == 32) {
         if (c_out == 128) return launch_mfma<4, 32>(a, s);
         if (c_out == 64) return launch_mfma<2, 32>(a, s);

@@ -445,15 +445,18 @@ def _split_k3_ok(c_in: int, c2: int, c_out: int) -> bool:
     return c_out == 1 and c2 == 0 and c_in % 16 == 0
 
 
-def summation_order(kind: str, c1: int, c2: int, c_out: int) -> int:
-    """Which documented fp32 summation order (include/fpcc_hip.h) a layer of this shape is evaluated in:
+def summation_order(kind: str, c1: int, c2: int, c_out: int, n_out: int = 0) -> int:
+    """Which documented fp32 summation order (include/fpcc_hip.h) a layer of this shape and size is evaluated in:
     0 natural chain, 1 MFMA chain (0,4,1,5,2,6,3,7 inside groups of 8 channels), 2 per-offset chains then offset sum.
-    kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen' | 'mlp'.  Tests hand this to the oracle to compare bit for bit."""
+    kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen' | 'mlp'; n_out = output rows of the launch.  Tests hand this to the
+    oracle to compare bit for bit."""
     if kind == 'gen' and c2 == 0 and _packed_gen_ok(c1, c_out):
         return 1
     if kind == 'k3' and _split_k3_ok(c1, c2, c_out):
         return 2
-    return ops.conv_order(c1, c2, c_out)
+    n_off = {'k3': 27, 'k2s2': 8}.get(kind, 1)
+    groups = 8 if kind in ('gen', 'k2s2T') else 1
+    return ops.conv_order(c1, c2, c_out, n_off, groups, n_out)
 
 
 class _ConvBase(nn.Module):

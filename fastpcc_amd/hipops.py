@@ -29,6 +29,7 @@ _SIGS = {
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
+    'fpcc_conv_f32_order_ex': (_i32, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_gather_sum_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _f32, _vp, _vp]),
     'fpcc_logit_to_prob16': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_quantize_symbols': (_i32, [_vp, _i64, _f32, _vp, _vp]),
@@ -262,14 +263,14 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     if trace is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out)), 'c_in': c1 + c2, 'c_out': c_out,
+        trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
                                  'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
                                  'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
     return out
 
 
-def conv_order(c1: int, c2: int, c_out: int) -> int:
-    return lib().fpcc_conv_f32_order(c1, c2, c_out)
+def conv_order(c1: int, c2: int, c_out: int, n_offsets: int = 1, groups: int = 1, n_out: int = 0) -> int:
+    return lib().fpcc_conv_f32_order_ex(c1, c2, c_out, n_offsets, groups, n_out)
 
 
 def gather_sum(y: torch.Tensor, nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, *,

@@ -126,6 +126,10 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
                   const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
                   int act, const float *slope, float clip, void *stream);
 int fpcc_conv_f32_order(int c1, int c2, int c_out);
+/* Same, including the launch-dependent choice: multi-offset convolutions (8 <= n_offsets <= 27, groups == 1) with
+ * C_in >= 128 and C_out == 128 on maps of at least 32 Ki rows run the pair-compacted kernel, whose order is 2 (per-offset FMA chains from zero, partial sums
+ * added in ascending offset order, then the bias). */
+int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out);
 
 /* out[o] = act( sum_k y[nbr[k*nbr_ks + o*nbr_os]][k] + bias[0] ): the gather half of a 3x3x3 convolution with ONE output
  * channel, whose per-offset dot products y = X @ [w_0 | ... | w_26] (padded to 32 columns) were computed per input row

@@ -14,7 +14,7 @@ coding oracle/rans.py.  Parity: the rANS and framing parts are PINNED (golden ve
 network part is UNPINNED against MinkowskiEngine -- what is checked is GPU == this oracle.
 
 `conv='mm'` evaluates convolutions the reference-shaped way (gather, GEMM, scatter-add); `conv='chain'` uses the
-fixed-order FMA chain with `order_fn(kind, c1, c2, c_out) -> 0|1|2` choosing the summation order per layer (see
+fixed-order FMA chain with `order_fn(kind, c1, c2, c_out, n_out) -> 0|1|2` choosing the summation order per layer (see
 oracle/sparse_conv.c), which makes the activations comparable bit for bit with a device kernel of the same order.
 """
 import io
@@ -71,11 +71,11 @@ class Feature:
 
 class OracleV2:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg, conv: str = 'mm',
-                 order_fn: Optional[Callable[[str, int, int, int], int]] = None):
+                 order_fn: Optional[Callable[[str, int, int, int, int], int]] = None):
         self.P = {k: v.detach().cpu().float() for k, v in weights.items()}
         self.cfg = cfg
         self.conv = conv
-        self.order_fn = order_fn or (lambda kind, c1, c2, c_out: 0)
+        self.order_fn = order_fn or (lambda kind, c1, c2, c_out, n_out: 0)
         self._kmaps = {}
         self.trace: Dict[str, np.ndarray] = {}     # activations by layer prefix (filled when keep_trace)
         self.keep_trace = False
@@ -97,7 +97,7 @@ class OracleV2:
             table = oc.dense_table(kmap, n_out)
             out = torch.from_numpy(sc.conv_chain(x1.numpy(), table, w.numpy(), None if b is None else b.numpy(), n_out,
                                                  x2=None if x2 is None else x2.numpy(), act=act, slope=slope,
-                                                 clip=clip, order=self.order_fn(kind, c1, c2, c_out)))
+                                                 clip=clip, order=self.order_fn(kind, c1, c2, c_out, n_out)))
         if self.keep_trace:
             self.trace[name] = out.numpy().copy()
         return out

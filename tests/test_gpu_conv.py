@@ -53,7 +53,7 @@ def test_conv3_bit_exact(ops, scene, c1, c2, c_out):
     slope = torch.tensor([0.2], device='cuda')
     got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
                        n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope, clip=1.5)
-    order = ops.conv_order(c1, c2, c_out)
+    order = ops.conv_order(c1, c2, c_out, 27, 1, n)
     want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.2, clip=1.5, order=order)
     assert (_bits(got.cpu().numpy()) == _bits(want)).all()
     # reference-shaped evaluation, tolerance
@@ -78,7 +78,7 @@ def test_stride2_conv_bit_exact(ops, scene, c_in, c_out):
     child_row = np.ascontiguousarray(table.T)                    # [m, 8], the layout the pyramid keeps
     got = ops.conv_f32(_cuda(x), _cuda(w), c_out, up.n, nbr=_cuda(child_row), n_offsets=8, nbr_ks=1, nbr_os=8,
                        bias=_cuda(b), act=ops.ACT_RELU)
-    want = sc.conv_chain(x, table, w, b, up.n, act=sc.ACT_RELU, order=ops.conv_order(c_in, 0, c_out))
+    want = sc.conv_chain(x, table, w, b, up.n, act=sc.ACT_RELU, order=ops.conv_order(c_in, 0, c_out, 8, 1, up.n))
     assert (_bits(got.cpu().numpy()) == _bits(want)).all()
 
 
@@ -185,7 +185,7 @@ def test_engine_layers_match_oracle_orders(ops, scene):
             out = conv(st)
             w = conv.kernel.detach().cpu().numpy()
             b = conv.bias.detach().cpu().numpy().reshape(-1)
-            order = ME.summation_order('gen', c_in, 0, c_out)
+            order = ME.summation_order('gen', c_in, 0, c_out, lvl.n)
             want = np.zeros((8 * lvl.n, c_out), np.float32)
             for g in range(8):
                 want[g::8] = sc.conv_chain(x, None, w[g], b, lvl.n, order=order)
@@ -198,5 +198,29 @@ def test_engine_layers_match_oracle_orders(ops, scene):
             out = conv(st)
             want = sc.conv_chain(x, scene['k3'], conv.kernel.detach().cpu().numpy(),
                                  conv.bias.detach().cpu().numpy().reshape(-1), lvl.n,
-                                 order=ME.summation_order('k3', c_in, 0, 1))
+                                 order=ME.summation_order('k3', c_in, 0, 1, lvl.n))
             assert (_bits(out.F.cpu().numpy()) == _bits(want)).all(), c_in
+
+
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (256, 0, 128)])
+def test_pair_compacted_kernel_is_used_and_exact(ops, c1, c2, c_out):
+    """maps of >= 32 Ki rows: per-offset compaction + LDS accumulation (summation order 2), against the oracle's order 2"""
+    xyz = surface_cloud(33, 256, 400000)
+    lvl = oc.Level(batched(xyz), 1)
+    assert lvl.n >= 32 * 1024 + 100
+    n = lvl.n - 37                                   # ragged tail tile
+    table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
+    assert ops.conv_order(c1, c2, c_out, 27, 1, n) == 2 and ops.conv_order(c1, c2, c_out, 27, 1, 1000) == 1
+    rng = np.random.default_rng(c1 + c_out)
+    x1 = rng.normal(size=(lvl.n, c1)).astype(np.float32)
+    x2 = rng.normal(size=(lvl.n, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.1], device='cuda')
+    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
+                       n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.1, order=2)
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+    again = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
+                         n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
+    assert torch.equal(got, again)                   # reproducible
