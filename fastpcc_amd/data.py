@@ -23,6 +23,7 @@ def batched_coordinates(coords: Sequence[torch.Tensor]):
 class PCData:
     xyz: Union[torch.Tensor, List[torch.Tensor]]
     batch_size: int = 1
+    color: Optional[torch.Tensor] = None
     org_points_num: Optional[List[int]] = None
     resolution: Optional[List[int]] = None
     file_path: Optional[List[str]] = None

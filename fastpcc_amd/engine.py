@@ -445,6 +445,18 @@ def _split_k3_ok(c_in: int, c2: int, c_out: int) -> bool:
     return c_out == 1 and c2 == 0 and c_in % 16 == 0
 
 
+def _pad_plan(c1: int, c2: int, c_out: int, n_out: int):
+    """Shapes the MFMA kernel does not take as they are (C_in not a multiple of 16, C_out not 32/64/128) but that are big
+    enough to matter are zero-padded to the next MFMA shape: -> (c1p, c2p, c_outp) or None.  Zero channels add exact
+    zeros to the FMA chains, so only the (documented) summation order changes."""
+    if ops.conv_order(c1, c2, c_out) != 0 or c_out > 128 or c1 + c2 < 4 or (c1 + c2) * c_out < 32 or n_out < 8192:
+        return None
+    c1p = (c1 + 15) // 16 * 16
+    c2p = (c2 + 15) // 16 * 16 if c2 else 0
+    c_outp = 32 if c_out <= 32 else (64 if c_out <= 64 else 128)
+    return c1p, c2p, c_outp
+
+
 def summation_order(kind: str, c1: int, c2: int, c_out: int, n_out: int = 0) -> int:
     """Which documented fp32 summation order (include/fpcc_hip.h) a layer of this shape and size is evaluated in:
     0 natural chain, 1 MFMA chain (0,4,1,5,2,6,3,7 inside groups of 8 channels), 2 per-offset chains then offset sum.
@@ -456,6 +468,10 @@ def summation_order(kind: str, c1: int, c2: int, c_out: int, n_out: int = 0) -> 
         return 2
     n_off = {'k3': 27, 'k2s2': 8}.get(kind, 1)
     groups = 8 if kind in ('gen', 'k2s2T') else 1
+    if kind in ('k1', 'k3'):
+        plan = _pad_plan(c1, c2, c_out, n_out)
+        if plan is not None:
+            return ops.conv_order(plan[0], plan[1], plan[2], n_off, groups, n_out)
     return ops.conv_order(c1, c2, c_out, n_off, groups, n_out)
 
 
@@ -504,6 +520,31 @@ class _ConvBase(nn.Module):
                 d['k3_w'] = wt
             self._packed, self._packed_tag = d, tag
         return self._packed
+
+    def _padded_weights(self, c1: int, c2: int, plan):
+        """kernel / bias zero-padded to the MFMA shape `plan` = (c1p, c2p, c_outp) (cached)"""
+        d = self._derived()
+        key = ('pad', c1, c2) + tuple(plan)
+        if key not in d:
+            c1p, c2p, cop = plan
+            k = self.kernel.detach()
+            k = k.reshape(-1, k.shape[-2], k.shape[-1])
+            w = torch.zeros((k.shape[0], c1p + c2p, cop), dtype=k.dtype, device=k.device)
+            w[:, :c1, :self.out_channels] = k[:, :c1]
+            if c2:
+                w[:, c1p:c1p + c2, :self.out_channels] = k[:, c1:]
+            b = None
+            if self.bias is not None:
+                b = torch.zeros(cop, dtype=k.dtype, device=k.device)
+                b[:self.out_channels] = self.bias.detach().view(-1)
+            d[key] = (w, b)
+        return d[key]
+
+    @staticmethod
+    def _pad_cols(x: Optional[torch.Tensor], width: int) -> Optional[torch.Tensor]:
+        if x is None or x.shape[1] == width:
+            return x
+        return torch.nn.functional.pad(x, (0, width - x.shape[1]))
 
     def reset_parameters(self):
         # MinkowskiEngine 0.5's default: U(-1/sqrt(n), 1/sqrt(n)), n = (C_out if transposed else C_in) * volume
@@ -559,13 +600,27 @@ class _ConvBase(nn.Module):
                                    out_rows=dst.n, **kw)
         elif self.ks == 1:
             dst = src
-            out = ops.conv_f32(x1, w, c_out, src.n, **kw)
+            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
+            if plan is not None:
+                wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
+                out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
+                                   act=act.kind, slope=act.slope, clip=clip)[:, :c_out]
+            else:
+                out = ops.conv_f32(x1, w, c_out, src.n, **kw)
         elif self.ks == 3:
             dst = src
             if coordinates is not None and cm._map(coordinates) is not src:
                 raise NotImplementedError('stride-1 convolution onto a different coordinate map')
             d = self._derived()
-            if x2 is None and 'k3_w' in d:
+            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
+            if plan is not None:
+                wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
+                out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
+                                   nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
+                                   clip=clip)[:, :c_out]
+                if c_out < 8:
+                    out = out.contiguous()
+            elif x2 is None and 'k3_w' in d:
                 y = ops.conv_f32(x1, d['k3_w'], 32, src.n)       # per input row: its dot product with every offset's kernel
                 out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
                                      slope=act.slope, clip=clip)

@@ -35,6 +35,7 @@ _SIGS = {
     'fpcc_quantize_symbols': (_i32, [_vp, _i64, _f32, _vp, _vp]),
     'fpcc_child_mask': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_topk_keep': (_i64, [_vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    'fpcc_topk_keep_cells': (_i64, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     'fpcc_gather_rows_f32': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     'fpcc_compact_coords': (_i64, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_int_init': (_i32, []),
@@ -330,6 +331,20 @@ def topk_keep(logit: torch.Tensor, target: int) -> torch.Tensor:
     ws, need = _ws(lambda: L.fpcc_topk_keep(None, m, target, None, None, 0, None), logit.device)
     _ok(L.fpcc_topk_keep(_dev(logit, torch.float32, 'logit'), m, int(target), out.data_ptr(), ws.data_ptr(), need,
                          _stream()))
+    return out
+
+
+def topk_keep_cells(logit: torch.Tensor, cell_of_group: torch.Tensor, n_cells: int, target: int) -> torch.Tensor:
+    """top-k keep where the local-maximum cell of candidate group p is cell_of_group[p] (see fpcc_topk_keep_cells)"""
+    n = logit.numel()
+    m = n // 8
+    if n % 8 or cell_of_group.shape[0] != m:
+        raise ValueError('one cell id per group of 8 candidates expected')
+    out = torch.empty(n, dtype=torch.uint8, device=logit.device)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_topk_keep_cells(None, m, None, n_cells, target, None, None, 0, None), logit.device)
+    _ok(L.fpcc_topk_keep_cells(_dev(logit, torch.float32, 'logit'), m, _dev(cell_of_group, torch.int32, 'cell_of_group'),
+                               n_cells, int(target), out.data_ptr(), ws.data_ptr(), need, _stream()))
     return out
 
 

@@ -171,6 +171,13 @@ int64_t fpcc_compact_coords(const int64_t *pkeys, int64_t m, const uint8_t *mask
                             const int32_t *offset_xyz, int32_t *xyz_out, int32_t *count_out,
                             void *ws, int64_t ws_bytes, void *stream);
 
+/* Same rule with coarser cells, as Decoder.get_keep needs when a stage sits more than one level below the coarsest
+ * decoder level (models/convolutional/lossy_coord_lossy_color/layers.py:183-190: pooling stride = 2^stages / stride):
+ * candidate group p (8 children of one voxel) belongs to cell cell_of_group[p] in [0, n_cells); a candidate is a local
+ * maximum when it equals the maximum over its whole cell. */
+int64_t fpcc_topk_keep_cells(const float *logit, int64_t m, const int32_t *cell_of_group, int64_t n_cells, int64_t target,
+                             uint8_t *keep_out, void *ws, int64_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Integer-only pipeline (lossl_coord_int).  Replaces the pybind module `int_sparse_conv_ext`                      */
 /* (lib/int_sparse_conv/src/binding.cu:114-145).  All arithmetic is exact: results are order independent.          */

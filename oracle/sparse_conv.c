@@ -19,7 +19,8 @@
  * selected by `order`:
  *      order 0: natural 0,1,2,...
  *      order 1: inside every aligned group of 8 channels: 0,4,1,5,2,6,3,7  (the order in which gfx950's
- *               v_mfma_f32_32x32x2_f32 consumes a 16-byte-per-lane A fragment; C_in must be a multiple of 8)
+ *               v_mfma_f32_32x32x2_f32 consumes a 16-byte-per-lane A fragment; a trailing partial group keeps
+ *               its relative order, as if zero padded)
  *      order 2: per kernel offset its own chain (channels as in order 1) starting from zero; the offsets' partial
  *               sums are then added in ascending offset order -- the association of a per-offset
  *               gather-GEMM-scatter-add evaluation (and of MinkowskiEngine's own loop over kernel offsets)
@@ -67,8 +68,11 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
                 const float *wk = w + k * c_in * c_out;
                 float *tgt = order == 2 ? part : acc;
                 if (order == 2) for (int64_t j = 0; j < c_out; ++j) part[j] = 0.0f;
-                for (int64_t pos = 0; pos < c_in; ++pos) {
+                /* orders 1 and 2 walk whole groups of 8: channels past c_in (zero padding on the device) are skipped */
+                const int64_t span = order == 0 ? c_in : ((c_in + 7) & ~(int64_t)7);
+                for (int64_t pos = 0; pos < span; ++pos) {
                     int64_t c = chan_at(pos, order);
+                    if (c >= c_in) continue;
                     float xv = c < c1 ? x1[r * ld1 + c] : x2[r * ld2 + (c - c1)];
                     const float *wr = wk + c * c_out;
                     for (int64_t j = 0; j < c_out; ++j) tgt[j] = fmaf(xv, wr[j], tgt[j]);
