@@ -613,17 +613,17 @@ class _ConvBase(nn.Module):
                 raise NotImplementedError('stride-1 convolution onto a different coordinate map')
             d = self._derived()
             plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
-            if plan is not None:
+            if x2 is None and 'k3_w' in d:
+                y = ops.conv_f32(x1, d['k3_w'], 32, src.n)       # per input row: its dot product with every offset's kernel
+                out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
+                                     slope=act.slope, clip=clip)
+            elif plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
                                    nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
                                    clip=clip)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
-            elif x2 is None and 'k3_w' in d:
-                y = ops.conv_f32(x1, d['k3_w'], 32, src.n)       # per input row: its dot product with every offset's kernel
-                out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
-                                     slope=act.slope, clip=clip)
             else:
                 out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, **kw)
         else:   # kernel 2, stride 2
