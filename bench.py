@@ -117,7 +117,7 @@ def main():
     torch.manual_seed(0)
     model = Model(cfg)
     enliven(model, 0)
-    weights = {k: v.clone() for k, v in model.state_dict().items()}
+    weights = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
     model = model.cuda().eval()
 
     # every rank codes its own frame (different seed), all ~1M voxels

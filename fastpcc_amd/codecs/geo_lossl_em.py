@@ -23,13 +23,14 @@ from .. import engine as ME
 from .. import hipops as ops
 from .._native import host, host_check
 from ..bitstream import BytesListUtils, bytes_to_int, int_to_bytes
+from ..entropy_models import NoisyDeepFactorizedEntropyModel
 from ..rans_coder import BinaryRansCoder, IndexedRansCoder
 
 
 class GeoLosslessEntropyModel(nn.Module):
     def __init__(self, compressed_channels: int, bottleneck_process: str, bottleneck_scaler: int,
                  skip_encoding_fea: int, encoder: nn.Module, residual_block: nn.Module, decoder_block: nn.Module,
-                 hyper_decoder_coord: nn.Module, hyper_decoder_fea: nn.Module, bottom_fea_entropy_model=None):
+                 hyper_decoder_coord: nn.Module, hyper_decoder_fea: nn.Module):
         super().__init__()
         if compressed_channels != 1:
             raise NotImplementedError('one coded channel per level, as in every in-scope configuration')
@@ -37,9 +38,11 @@ class GeoLosslessEntropyModel(nn.Module):
         self.broadcast_shape_bytes = 3
         self.bottleneck_scaler = bottleneck_scaler
         self.skip_encoding_fea = skip_encoding_fea
-        # The noisy deep-factorised bottleneck only acts in training; it is kept as a sub-module when supplied so that
-        # checkpoints keep their keys.
-        self.bottom_fea_entropy_model = bottom_fea_entropy_model
+        # The noisy deep-factorised bottleneck prices the residual features in the rate objective (forward()); the coded
+        # path uses empirical histograms instead.  Same sub-module name / state-dict keys as the reference (:38-48).
+        self.bottom_fea_entropy_model = NoisyDeepFactorizedEntropyModel(
+            batch_shape=torch.Size([compressed_channels]), coding_ndim=2, bottleneck_process=bottleneck_process,
+            bottleneck_scaler=bottleneck_scaler, init_scale=10, broadcast_shape_bytes=(self.broadcast_shape_bytes,))
         self.rans_coder = IndexedRansCoder(False, 1)
         self.binary_rans_coder = BinaryRansCoder(1)
         assert len(encoder) == len(residual_block) == len(decoder_block) == len(hyper_decoder_fea)
@@ -81,6 +84,38 @@ class GeoLosslessEntropyModel(nn.Module):
         out = np.empty((1, rows * width), np.int32)
         self.rans_coder.decode([payload], out)
         return out.reshape(rows, width), cdf
+
+    # -- rate objective (geo_lossl_em.py:115-158) -----------------------------------------------------------------------
+    def forward(self, y_top: ME.SparseTensor, batch_size: int = 1):
+        """Training-mode forward: returns (reconstructed top features, {'fea_bottom_bits_loss', 'coord_i_bits_loss',
+        'fea_i_bits_loss'}).  The sparse convolutions of this build are forward-only, so the terms carry gradients
+        only w.r.t. the entropy-model parameters; back-propagation through the convolutions is not built yet."""
+        if not self.training:
+            raise RuntimeError('forward() evaluates the training objective; use compress() / decompress() for coding')
+        cm = y_top.coordinate_manager
+        *feas, bottom = self.encoder(y_top, batch_size)
+        loss = {}
+        tilde, d = self.bottom_fea_entropy_model(bottom.F[None])
+        loss['fea_bottom_bits_loss'] = d['bits_loss']
+        lower = ME.SparseTensor(tilde[0], coordinate_map_key=bottom.coordinate_map_key, coordinate_manager=cm)
+        for idx in range(len(feas) - 1, -1, -1):
+            fea = feas[idx]
+            target_key = fea.coordinate_map_key
+            target_map = cm._map(target_key)
+            if cm._map(lower.coordinate_map_key) is not target_map:
+                logits = self.hyper_decoder_coord[idx](lower)
+                mask = ops.child_mask(target_map.child_row).to(torch.float)
+                loss[f'coord_{idx}_bits_loss'] = nn.functional.binary_cross_entropy_with_logits(
+                    logits.F.view(-1), mask, reduction='sum') / math.log(2)
+            fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
+            if idx > self.skip_encoding_fea:
+                res = self.residual_block[idx](fea, fea_pred)
+                res_tilde, d = self.bottom_fea_entropy_model(res.F[None])
+                loss[f'fea_{idx}_bits_loss'] = d['bits_loss']
+                lower = self.decoder_block[idx](res_tilde[0], fea_pred)
+            else:
+                lower = self.decoder_block[idx](fea_pred)
+        return lower, loss
 
     # -- compress -------------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -72,7 +72,7 @@ class Feature:
 class OracleV2:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg, conv: str = 'mm',
                  order_fn: Optional[Callable[[str, int, int, int, int], int]] = None):
-        self.P = {k: v.detach().cpu().float() for k, v in weights.items()}
+        self.P = {k: v.detach().cpu().float() for k, v in weights.items() if isinstance(v, torch.Tensor)}
         self.cfg = cfg
         self.conv = conv
         self.order_fn = order_fn or (lambda kind, c1, c2, c_out, n_out: 0)

@@ -11,6 +11,9 @@ Sources of truth used:
                  /root/reference/lib/entropy_models/rans_coder/__init__.py:72-77
   morton.json    /root/reference/lib/space_filling_curves/__init__.py:65-88 (CPU path, imported with the CUDA loader stubbed)
   byteslist.json /root/reference/lib/entropy_models/hyperprior/noisy_deep_factorized/utils.py:8-77
+  entropy_model.json  NoisyDeepFactorizedEntropyModel of /root/reference/lib/entropy_models/continuous_batched.py
+                 (imported with lib.entropy_models.rans_coder -> oracle/_ref coder and the MinkowskiEngine wrapper
+                 stubbed): seeded parameters, log_prob / prob, quantised CDF tables, compress strings
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -176,8 +179,93 @@ def make_explut():
             'head': vals[:8], 'tail': vals[-8:], 'at_512': vals[512], 'at_3000': vals[3000]}
 
 
+def make_entropy_model():
+    import torch
+    import rans_ext_cpp as R
+    stub_rc = types.ModuleType('lib.entropy_models.rans_coder')
+    stub_rc.IndexedRansCoder = R.IndexedRansCoder
+    stub_wr = types.ModuleType('lib.minkowski_sparse_conv_layers')
+    stub_wr.minkowski_tensor_wrapped_fn = lambda *a, **k: (lambda f: f)
+    stub_wr.minkowski_tensor_wrapped_op = lambda *a, **k: (lambda f: f)
+    sys.modules['lib.entropy_models.rans_coder'] = stub_rc
+    sys.modules['lib.minkowski_sparse_conv_layers'] = stub_wr
+    sys.path.insert(0, REF)
+    from lib.entropy_models.continuous_batched import NoisyDeepFactorizedEntropyModel as RefEM
+    from lib.entropy_models.utils import lower_bound, upper_bound, grad_scaler
+
+    def tl(t):
+        return t.detach().double().reshape(-1).tolist()
+
+    out = {'cases': [], 'bounds': []}
+    for ci, (ch, scaler, lo, hi, init_scale, n, spread) in enumerate((
+            (1, 1, -64, 64, 10, 100, 3.0), (8, 1, -64, 64, 10, 60, 4.0), (8, 1, -10, 10, 10, 60, 9.0),
+            (4, 2, -16, 16, 3, 50, 2.0), (32, 1, -64, 64, 10, 17, 30.0))):
+        torch.manual_seed(ci)
+        em = RefEM(batch_shape=torch.Size([ch]), coding_ndim=2, bottleneck_process='noise', bottleneck_scaler=scaler,
+                   init_scale=init_scale, lower_bound=lo, upper_bound=hi, broadcast_shape_bytes=(3,))
+        with torch.no_grad():        # leave the initial point so that factors / unequal weights are exercised
+            for p in em.parameters():
+                p.add_(torch.randn_like(p) * 0.3)
+        x = torch.randn(1, n, ch) * spread
+        x[0, 0, 0] = 500.25          # far outside the table: overflow coding
+        probe = torch.cat((torch.linspace(-40, 40, 33)[:, None].expand(33, ch), x[0, :8]))
+        rec = {'ch': ch, 'scaler': scaler, 'lower': lo, 'upper': hi, 'init_scale': init_scale,
+               'weights': [tl(p) for p in em.prior_weights], 'biases': [tl(p) for p in em.prior_biases],
+               'factors': [tl(p) for p in em.prior_factors], 'x': tl(x), 'x_shape': list(x.shape),
+               'probe': tl(probe), 'probe_shape': list(probe.shape)}
+        with torch.no_grad():
+            rec['log_prob'] = tl(em.prior.log_prob(probe))
+            rec['prob'] = tl(em.prior.prob(probe))
+            rec['logits_cdf'] = tl(em.prior.base.base.logits_cdf(probe))
+        em.train()
+        torch.manual_seed(100 + ci)
+        y, loss = em(x)
+        rec['train_noise_seed'] = 100 + ci
+        rec['train_y'] = tl(y)
+        rec['bits_loss'] = float(loss['bits_loss'])
+        loss['bits_loss'].backward()
+        rec['grad_w0'] = tl(em.prior_weights[0].grad)
+        rec['grad_f0'] = tl(em.prior_factors[0].grad)
+        rec['grad_b_last'] = tl(em.prior_biases[-1].grad)
+        em.eval()
+        rec['cdfs'] = [list(map(int, c)) for c in em.prior.cdf_list]
+        rec['cdf_offsets'] = [int(v) for v in em.prior.cdf_offset_list]
+        strings, bshape, deq, bits = em.compress(x.clone(), estimate_bits=True)
+        rec['strings'] = [t.hex() for t in strings]
+        rec['est_bits'] = float(bits)
+        rec['dequantized'] = tl(deq)
+        back = em.decompress(strings, bshape, torch.device('cpu'))
+        assert torch.equal(back, deq), ci
+        sd = em.state_dict()
+        rec['state_keys'] = sorted(sd.keys())
+        out['cases'].append(rec)
+    # a freshly initialised model (seed 0) and 100 values ~ N(0, 3^2)
+    torch.manual_seed(0)
+    em = RefEM(batch_shape=torch.Size([1]), coding_ndim=2, init_scale=10, broadcast_shape_bytes=(3,))
+    out['fresh'] = {'biases': [tl(p) for p in em.prior_biases], 'weights0': tl(em.prior_weights[0])[:1],
+                    'weights': [tl(p) for p in em.prior_weights]}
+    x = torch.randn(1, 100, 1) * 3
+    em.eval()
+    strings, _, _, bits = em.compress(x.clone(), estimate_bits=True)
+    out['fresh'].update({'est_bits': float(bits), 'cdf_len': len(em.prior.cdf_list[0]), 'cdf_offset': int(em.prior.cdf_offset_list[0]),
+                         'string': strings[0].hex()})
+    # gradient-shaping helpers
+    for name, fn in (('lower', lower_bound), ('upper', upper_bound)):
+        for mode in ('identity_if_towards', 'disconnected'):
+            x = torch.tensor([-2.0, -0.5, 0.0, 0.5, 2.0, 1.0, -1.0], requires_grad=True)
+            g = torch.tensor([1.0, -1.0, 1.0, -1.0, 1.0, -1.0, 1.0])
+            y = fn(x, 0.25, mode) if mode != 'identity_if_towards' else fn(x, 0.25)
+            y.backward(g)
+            out['bounds'].append({'fn': name, 'mode': mode, 'x': tl(x), 'g': tl(g), 'y': tl(y), 'dx': tl(x.grad)})
+    x = torch.tensor([1.0, -3.0], requires_grad=True)
+    y = grad_scaler(x, 0.125)
+    y.sum().backward()
+    out['bounds'].append({'fn': 'grad_scaler', 'mode': '0.125', 'x': tl(x), 'g': [1.0, 1.0], 'y': tl(y), 'dx': tl(x.grad)})
+    return out
+
+
 def main():
-    for name, fn in (('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         data = fn()
         path = os.path.join(HERE, name + '.json')
         with open(path, 'w') as f:

@@ -28,7 +28,7 @@ def setup():
     torch.manual_seed(0)
     model = Model(cfg)
     enliven(model, 0)
-    weights = {k: v.clone() for k, v in model.state_dict().items()}
+    weights = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
     model = model.cuda().eval()
     model.em_lossless_based.keep_symbols = True
     return cfg, model, weights, hipops
@@ -140,3 +140,40 @@ def test_partitioned_stream(setup):
     assert rec.shape[0] == dev.shape[0]
     n0 = int.from_bytes(blob[:3], 'little')
     assert blob[3:3 + n0] == model.compress(half[0])
+
+
+def test_rate_objective_tracks_the_coded_size(setup):
+    """GeoLosslessEntropyModel.forward (training-mode rate terms): the occupancy cross-entropy must price the
+    occupancy streams the binary coder actually writes (same logits, same masks) to within 1 % + 64 bits a stream,
+    and every level has its term.  State-dict keys of the noisy deep-factorised prior are the reference's."""
+    cfg, model, weights, ops = setup
+    xyz, coords = _cloud(5, 64, 20000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    model.compress(dev)
+    sizes = model.em_lossless_based.last_symbols['sizes']
+    sym = model.em_lossless_based.last_symbols
+    # ideal code length of the coded masks under the coded 16-bit probabilities
+    p = sym['prob'].astype(np.float64) / 65536
+    bits_ideal = -(np.log2(np.where(sym['occupancy'].astype(bool), p, 1 - p))).sum()
+    em = model.em_lossless_based
+    em.train()
+    try:
+        with torch.no_grad():
+            sparse_pc = model.get_sparse_pc(dev)
+            feature, _ = model.encoder(sparse_pc)
+            torch.manual_seed(3)
+            top, loss = em(feature, 1)
+    finally:
+        em.eval()
+    coord_keys = sorted(k for k in loss if k.startswith('coord_'))
+    assert len(coord_keys) == len(sizes) == 6
+    # the training forward feeds NOISY residuals down the pyramid, so its logits differ slightly from the coded ones
+    total = sum(float(loss[k]) for k in coord_keys)
+    assert total == pytest.approx(bits_ideal, rel=0.25)
+    fea_keys = [k for k in loss if k.startswith('fea_')]
+    assert 'fea_bottom_bits_loss' in fea_keys and len(fea_keys) == 1 + 10
+    assert all(np.isfinite(float(v)) and float(v) > 0 for v in loss.values())
+    assert top.F.shape == feature.F.shape
+    keys = [k for k in model.state_dict() if 'bottom_fea_entropy_model' in k]
+    assert 'em_lossless_based.bottom_fea_entropy_model.prior._extra_state' in keys
+    assert sum('prior_weights' in k for k in keys) == 5 and sum('prior_factors' in k for k in keys) == 4

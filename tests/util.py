@@ -38,6 +38,8 @@ def enliven(model: torch.nn.Module, seed: int, gain: float = 2.35) -> None:
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
+            if '.prior_' in name:                       # deep-factorised prior: keep make_parameters' init
+                continue
             if name.endswith('module.weight'):          # PReLU slope
                 p.copy_(0.1 + 0.3 * torch.rand(p.shape, generator=g))
             elif name.endswith('kernel') or name.endswith('linear.weight'):
