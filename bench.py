@@ -97,14 +97,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from fastpcc_amd import replicas
+    rank, world, local = replicas.env_rank()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group('nccl', init_method='env://')
+    replicas.init('nccl')          # RCCL; only the barrier and two scalar reductions use it
+    device = torch.device('cuda', local)
 
     from util import enliven
     from fastpcc_amd import hipops
@@ -139,9 +138,7 @@ def main():
     assert rec.shape[0] == n_points
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        replicas.barrier(device)
 
     hipops.CONV_TRACE = []
     t_enc = t_dec = 0.0
@@ -163,13 +160,7 @@ def main():
     elapsed = time.perf_counter() - t0
     trace, hipops.CONV_TRACE = hipops.CONV_TRACE, None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    pts = torch.tensor([float(n_points)], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t.item())
-    total_points = float(pts.item()) * args.steps
+    elapsed_max, total_points = replicas.aggregate(elapsed, float(n_points) * args.steps, device)
 
     if rank == 0:
         # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
