@@ -44,6 +44,11 @@ def host():
             'fpcc_simple_enc_finish': [vp, vp, i64],
             'fpcc_simple_dec_pop': [vp, vp, i64, i64, vp, i64],
             'fpcc_simple_dec_pop_bin': [vp, vp, i64, vp, i64],
+            'fpcc_pool_binary_encode': [vp, vp, C.c_uint32, vp, vp, i64, vp, i64, vp],
+            'fpcc_pool_histogram_encode': [vp, vp, C.c_uint32, vp, i64, i32, vp, vp, i64, vp, vp, i64, vp],
+            'fpcc_pool_table_decode': [vp, vp, i64, i64, vp, i64, i32, vp, i64, vp],
+            'fpcc_progress_wait': [vp, i64],
+            'fpcc_pool_wait': [vp],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -57,6 +62,10 @@ def host():
         L.fpcc_simple_dec_new.argtypes = [vp, i64]
         L.fpcc_simple_dec_free.restype = None
         L.fpcc_simple_dec_free.argtypes = [vp]
+        L.fpcc_pool_new.restype = vp
+        L.fpcc_pool_new.argtypes = [i32]
+        L.fpcc_pool_free.restype = None
+        L.fpcc_pool_free.argtypes = [vp]
         _host = L
     return _host
 
@@ -72,7 +81,8 @@ HOST_SYMBOLS = (
     'fpcc_rans_binary_encode', 'fpcc_rans_binary_decode', 'fpcc_rans_binary_encode_multi', 'fpcc_simple_enc_new',
     'fpcc_simple_enc_free', 'fpcc_simple_enc_push', 'fpcc_simple_enc_push_bin', 'fpcc_simple_enc_push_ranges',
     'fpcc_simple_enc_finish', 'fpcc_simple_dec_new', 'fpcc_simple_dec_free', 'fpcc_simple_dec_pop',
-    'fpcc_simple_dec_pop_bin')
+    'fpcc_simple_dec_pop_bin', 'fpcc_pool_new', 'fpcc_pool_free', 'fpcc_pool_binary_encode',
+    'fpcc_pool_histogram_encode', 'fpcc_pool_table_decode', 'fpcc_progress_wait', 'fpcc_pool_wait')
 
 
 def hip():

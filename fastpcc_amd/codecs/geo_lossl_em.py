@@ -13,6 +13,7 @@ What differs is where the work happens:
 """
 import io
 import math
+import time
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -23,6 +24,7 @@ from .. import engine as ME
 from .. import hipops as ops
 from .._native import host, host_check
 from ..bitstream import BytesListUtils, bytes_to_int, int_to_bytes
+from ..coder_pool import CoderPool
 from ..entropy_models import NoisyDeepFactorizedEntropyModel
 from ..rans_coder import BinaryRansCoder, IndexedRansCoder
 
@@ -54,6 +56,9 @@ class GeoLosslessEntropyModel(nn.Module):
         self.host_threads = 8
         self.keep_symbols = False
         self.last_symbols = None
+        self.evaluate_unused_tail = False
+        self._overlap = {}
+        self.timing = None          # set to a dict to collect host-side wall-clock marks (seconds) of the last call
 
     # -- rANS of an integer array under its own histogram (geo_lossl_em.py:59-93) -------------------------------------
     def rans_encode_with_cdf(self, target: np.ndarray, bs: io.BytesIO, offset: Optional[int] = None):
@@ -118,18 +123,98 @@ class GeoLosslessEntropyModel(nn.Module):
         return lower, loss
 
     # -- compress -------------------------------------------------------------------------------------------------------
+    def _overlap_state(self, dev: torch.device):
+        st = self._overlap.get(dev)
+        if st is None:
+            st = {'pool': CoderPool(self.host_threads), 'side': torch.cuda.Stream(device=dev),
+                  'flags': torch.zeros(64, dtype=torch.int32, pin_memory=True),
+                  'ones': torch.ones(64, dtype=torch.int32, device=dev)}
+            self._overlap[dev] = st
+        return st
+
+    @staticmethod
+    def _ship(st, tensors: List[torch.Tensor], flag: Optional[int]) -> List[np.ndarray]:
+        """stream-ordered device->pinned-host copies on the side stream, then (optionally) the flag that releases the
+        host job reading them; the main stream is not blocked"""
+        ev = torch.cuda.Event()
+        ev.record()
+        side = st['side']
+        out = []
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(side)
+                out.append(h)
+            if flag is not None:
+                st['flags'][flag:flag + 1].copy_(st['ones'][flag:flag + 1], non_blocking=True)
+        st['pinned'].extend(out)
+        return [h.numpy() for h in out]
+
+    def _read_coded(self, bs: io.BytesIO, offset: Optional[int]) -> Tuple[int, int, List[int], bytes]:
+        rows = bytes_to_int(bs.read(self.broadcast_shape_bytes))
+        if offset is None:
+            offset = -bytes_to_int(bs.read(1))
+        inner = bytes_to_int(bs.read(1))
+        cdf = [0, *(bytes_to_int(bs.read(2)) for _ in range(inner)), 1 << 16]
+        payload = bs.read(bytes_to_int(bs.read(3)))
+        return rows, offset, cdf, payload
+
+    def _write_coded(self, bs: io.BytesIO, rows: int, offset: int, cdf: List[int], payload: bytes, write_offset: bool):
+        """byte layout of rans_encode_with_cdf (geo_lossl_em.py:59-74)"""
+        bs.write(int_to_bytes(rows, self.broadcast_shape_bytes))
+        if write_offset:
+            bs.write(int_to_bytes(-offset, 1))
+        bs.write(int_to_bytes(len(cdf) - 2, 1))
+        for edge in cdf[1:-1]:
+            bs.write(int_to_bytes(edge, 2))
+        bs.write(int_to_bytes(len(payload), 3))
+        bs.write(payload)
+
     @torch.no_grad()
     def compress(self, y_top: ME.SparseTensor, batch_size: int = 1) -> bytes:
+        """Entropy coding runs on libfpcc_host's threads WHILE the GPU evaluates the following levels: every level's
+        mask / probabilities (and, after the last residual level, all residual symbols) go to pinned memory on a side
+        stream, followed by a flag that releases the host job (fastpcc_amd/coder_pool.py).  One wait at the end."""
+        tm = self.timing
+        if tm is not None:
+            tm.clear()
+            tm['enc_t0'] = time.perf_counter()
         cm = y_top.coordinate_manager
         *feas, bottom = self.encoder(y_top, batch_size)
         del y_top
         scale = float(self.bottleneck_scaler)
         bottom_f = bottom.F
+        st = self._overlap_state(bottom_f.device)
+        st['pinned'] = []
+        st['flags'].zero_()
+        pool: CoderPool = st['pool']
+        flags = st['flags'].numpy().view(np.uint32)
+        n_flags = 0
         residual_syms = [ops.quantize_symbols_(bottom_f, scale)]         # rounds bottom_f in place
-        occupancy: List[Tuple[torch.Tensor, torch.Tensor]] = []          # (mask u8, prob u16) per coded level
+        occupancy_h: List[Tuple[np.ndarray, np.ndarray]] = []            # (mask u8, prob u16) per coded level, host side
         lower = bottom
         bottom_map = cm._map(bottom.coordinate_map_key)
+        bottom_xyz = (cm.get_coordinates(bottom.coordinate_map_key)[:, 1:] >> bottom_map.level).contiguous()
+        (xyz_h,) = self._ship(st, [bottom_xyz], None)
+        # Last level whose evaluation still feeds the bitstream: the reference keeps evaluating the feature predictors
+        # below it and discards the result (`del lower_fea_recon`, geo_lossl_em.py:210); nothing reads them, so this
+        # build stops there unless `evaluate_unused_tail` is set (identical bytes either way, tested).
+        last_coded = min((i for i in range(len(feas)) if i > self.skip_encoding_fea or self.hyper_decoder_coord[i] is not None),
+                         default=len(feas))
+        last_residual = min((i for i in range(len(feas)) if i > self.skip_encoding_fea), default=len(feas))
+        residual_job = None
 
+        def ship_residuals():
+            nonlocal n_flags
+            (sym_h,) = self._ship(st, [torch.cat(residual_syms)], n_flags)
+            job = pool.histogram_encode(sym_h, None, flags[n_flags:n_flags + 1])
+            n_flags += 1
+            return sym_h, job
+
+        if last_residual == len(feas):
+            residual_job = ship_residuals()
         for idx in range(len(feas) - 1, -1, -1):
             fea = feas[idx]
             feas[idx] = None
@@ -139,90 +224,98 @@ class GeoLosslessEntropyModel(nn.Module):
                 if target_map.parent is not cm._map(lower.coordinate_map_key):
                     raise RuntimeError('pyramid levels are not parent and child')
                 logits = self.hyper_decoder_coord[idx](lower)            # on the 8 candidate children of every voxel
-                occupancy.append((ops.child_mask(target_map.child_row), ops.logit_to_prob16(logits.F.view(-1))))
+                mask_h, prob_h = self._ship(st, [ops.child_mask(target_map.child_row),
+                                                 ops.logit_to_prob16(logits.F.view(-1))], n_flags)
+                prob_h = prob_h.view(np.uint16)
+                pool.binary_encode(mask_h, prob_h, flags[n_flags:n_flags + 1])
+                n_flags += 1
+                occupancy_h.append((mask_h, prob_h))
                 del logits
             elif self.hyper_decoder_coord[idx] is not None:
                 raise RuntimeError('an occupancy predictor exists for a level that does not upsample')
+            if idx <= last_coded and idx <= self.skip_encoding_fea and not self.evaluate_unused_tail:
+                break
 
             fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
             if idx > self.skip_encoding_fea:
                 res = self.residual_block[idx](fea, fea_pred).F
                 del fea
                 residual_syms.append(ops.quantize_symbols_(res, scale))
+                if idx == last_residual:
+                    residual_job = ship_residuals()
+                if idx == last_coded and not self.evaluate_unused_tail:
+                    break
                 lower = self.decoder_block[idx](res, fea_pred)
             else:
                 lower = self.decoder_block[idx](fea_pred)
             del fea_pred
-        del lower
+        lower = fea_pred = None
+        if n_flags > flags.size:
+            raise RuntimeError('too many coded levels for the flag block')
 
-        # one synchronising transfer for everything the host coders need
-        dev = bottom_f.device
-        sym_all = torch.cat(residual_syms)
-        bottom_xyz = (cm.get_coordinates(bottom.coordinate_map_key)[:, 1:] >> bottom_map.level).contiguous()
-        if occupancy:
-            mask_all = torch.cat([m for m, _ in occupancy])
-            prob_all = torch.cat([p for _, p in occupancy])
-        else:
-            mask_all = torch.empty(0, dtype=torch.uint8, device=dev)
-            prob_all = torch.empty(0, dtype=torch.int16, device=dev)
-        sym_h = torch.empty(sym_all.shape, dtype=sym_all.dtype, pin_memory=True)
-        xyz_h = torch.empty(bottom_xyz.shape, dtype=bottom_xyz.dtype, pin_memory=True)
-        mask_h = torch.empty(mask_all.shape, dtype=mask_all.dtype, pin_memory=True)
-        prob_h = torch.empty(prob_all.shape, dtype=prob_all.dtype, pin_memory=True)
-        sym_h.copy_(sym_all, non_blocking=True)
-        xyz_h.copy_(bottom_xyz, non_blocking=True)
-        mask_h.copy_(mask_all, non_blocking=True)
-        prob_h.copy_(prob_all, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-
-        sizes = [m.numel() for m, _ in occupancy]
-        coord_bytes_list = self._encode_occupancy(mask_h.numpy(), prob_h.numpy().view(np.uint16), sizes)
+        if tm is not None:
+            tm['enc_enqueued'] = time.perf_counter()
+        coord_bytes_list = pool.wait()                                   # the only blocking point of the encoder
+        st['side'].synchronize()
+        if tm is not None:
+            tm['enc_synced'] = tm['enc_occupancy_coded'] = time.perf_counter()
+        sym_h, job = residual_job
         if self.keep_symbols:      # test hook: what went into the coders
-            self.last_symbols = {'residual': sym_h.numpy().copy(), 'occupancy': mask_h.numpy().copy(),
-                                 'prob': prob_h.numpy().view(np.uint16).copy(), 'sizes': sizes}
+            self.last_symbols = {'residual': sym_h.copy(),
+                                 'occupancy': np.concatenate([m for m, _ in occupancy_h]) if occupancy_h else np.zeros(0, np.uint8),
+                                 'prob': np.concatenate([q for _, q in occupancy_h]) if occupancy_h else np.zeros(0, np.uint16),
+                                 'sizes': [m.size for m, _ in occupancy_h]}
 
         with io.BytesIO() as bs:
             bs.write(int_to_bytes(bottom_map.level, 1))                                 # log2(bottom stride)
             bs.write(int_to_bytes(bottom_map.n, self.broadcast_shape_bytes))
-            self.rans_encode_with_cdf(sym_h.numpy().reshape(-1, 1), bs)
+            offset, cdf, payload = pool.histogram_result(job)
+            self._write_coded(bs, sym_h.size, offset, cdf, payload, True)
             bs.write(int_to_bytes(len(coord_bytes_list), 1))
             BytesListUtils.concat_bytes_list(coord_bytes_list, bs)
-            self.rans_encode_with_cdf(xyz_h.numpy(), bs, 0)
+            self.rans_encode_with_cdf(xyz_h, bs, 0)
+            st['pinned'] = []
+            if tm is not None:
+                tm['enc_done'] = time.perf_counter()
             return bs.getvalue()
-
-    def _encode_occupancy(self, mask: np.ndarray, prob: np.ndarray, sizes: List[int]) -> List[bytes]:
-        if not sizes:
-            return []
-        start = np.zeros(len(sizes) + 1, dtype=np.int64)
-        np.cumsum(sizes, out=start[1:])
-        cap = 4 * max(sizes) + 64
-        out = np.empty((len(sizes), cap), dtype=np.uint8)
-        lens = np.zeros(len(sizes), dtype=np.int64)
-        host_check(host().fpcc_rans_binary_encode_multi(mask.ctypes.data, prob.ctypes.data, start.ctypes.data,
-                                                        len(sizes), out.ctypes.data, cap, lens.ctypes.data,
-                                                        self.host_threads))
-        return [out[s, cap - int(lens[s]):].tobytes() for s in range(len(sizes))]
 
     # -- decompress -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decompress(self, concat_bytes: bytes, cm: ME.CoordinateManager) -> ME.SparseTensor:
         dev = next(self.parameters()).device
         scale = float(self.bottleneck_scaler)
+        tm = self.timing
+        if tm is not None:
+            tm['dec_t0'] = time.perf_counter()
+            tm['dec_wait'] = tm['dec_host'] = 0.0
         with io.BytesIO(concat_bytes) as bs:
             bottom_level = bytes_to_int(bs.read(1))
             bottom_rows = bytes_to_int(bs.read(self.broadcast_shape_bytes))
-            syms, _ = self.rans_decode_with_cdf(bs)
+            n_sym, sym_offset, sym_cdf, sym_payload = self._read_coded(bs, None)
             n_streams = bytes_to_int(bs.read(1))
             coord_bytes_list = BytesListUtils.split_bytes_list(None, n_streams, bs) if n_streams else []
             bottom_xyz, _ = self.rans_decode_with_cdf(bs, 0, 3)
 
-        res_all = torch.from_numpy(syms.astype(np.float32)).to(dev)
-        if scale != 1.0:
-            res_all /= scale
+        # the residual stream is decoded in the background, coarse levels first -- the order the loop below consumes it
+        pool: CoderPool = self._overlap_state(dev)['pool']
+        sym_t = torch.empty(n_sym * self.compressed_channels, dtype=torch.int32, pin_memory=True)
+        progress = pool.table_decode(sym_payload, sym_t.numel(), sym_cdf, sym_offset, sym_t.numpy(),
+                                     first_chunk=bottom_rows * self.compressed_channels)
+
+        def residuals(first_row: int, rows: int) -> torch.Tensor:
+            if first_row + rows > n_sym:
+                raise ValueError('the bitstream holds fewer residual symbols than the pyramid needs')
+            c = self.compressed_channels
+            pool.need(progress, (first_row + rows) * c)
+            t = sym_t[first_row * c: (first_row + rows) * c].to(dev, non_blocking=True).to(torch.float32).view(rows, c)
+            return t if scale == 1.0 else t / scale
+
         coords = torch.zeros((bottom_rows, 4), dtype=torch.int32)
         coords[:, 1:] = torch.from_numpy(bottom_xyz) << bottom_level
-        lower = ME.SparseTensor(res_all[:bottom_rows].contiguous(), coordinates=coords.to(dev),
+        lower = ME.SparseTensor(residuals(0, bottom_rows), coordinates=coords.to(dev),
                                 tensor_stride=1 << bottom_level, coordinate_manager=cm)
+        if tm is not None:
+            tm['dec_residual_decoded'] = time.perf_counter()
         used = bottom_rows
 
         for idx in range(len(self.residual_block) - 1, -1, -1):
@@ -230,23 +323,34 @@ class GeoLosslessEntropyModel(nn.Module):
             cur_map = cm._map(lower.coordinate_map_key)
             if occ_net is not None:
                 logits = occ_net(lower)
-                prob = ops.logit_to_prob16(logits.F.view(-1)).cpu().numpy().view(np.uint16)   # blocking D2H
-                bits = np.empty((1, prob.size), dtype=np.bool_)
-                self.binary_rans_coder.decode([coord_bytes_list.pop(0)], prob.reshape(1, -1), bits)
-                mask = torch.from_numpy(bits.reshape(-1).view(np.uint8)).to(dev)      # H2D
+                ta = time.perf_counter()
+                prob_d = ops.logit_to_prob16(logits.F.view(-1))
+                prob_t = torch.empty(prob_d.shape, dtype=prob_d.dtype, pin_memory=True)
+                prob_t.copy_(prob_d, non_blocking=True)
+                torch.cuda.current_stream().synchronize()                # the level's dependency: D2H of its probabilities
+                tb = time.perf_counter()
+                bits_t = torch.empty(prob_t.numel(), dtype=torch.uint8, pin_memory=True)
+                stream = np.frombuffer(coord_bytes_list.pop(0), dtype=np.uint8)
+                host_check(host().fpcc_rans_binary_decode(stream.ctypes.data, stream.size, prob_t.numpy().ctypes.data,
+                                                          prob_t.numel(), bits_t.numpy().ctypes.data))
+                mask = bits_t.to(dev, non_blocking=True)                 # H2D
+                if tm is not None:
+                    tm['dec_wait'] += tb - ta
+                    tm['dec_host'] += time.perf_counter() - tb
                 gen_id = logits.coordinate_map_key.get_key()[1]
                 cur_map = cm._refine(cur_map, mask, gen_id + 'pruned')
                 del logits
             target_key = cur_map.key
             fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
             if idx > self.skip_encoding_fea:
-                res = res_all[used: used + cur_map.n]
+                res = residuals(used, cur_map.n)
                 used += cur_map.n
                 lower = self.decoder_block[idx](res, fea_pred)
             else:
                 lower = self.decoder_block[idx](fea_pred)
         if coord_bytes_list:
             raise ValueError('unused occupancy streams in the bitstream')
-        if used != res_all.shape[0]:
+        pool.wait()
+        if used != n_sym:
             raise ValueError('residual symbols left over in the bitstream')
         return lower

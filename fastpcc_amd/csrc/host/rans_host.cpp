@@ -8,7 +8,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -128,16 +133,24 @@ int64_t indexed_encode(const int32_t *sym, const int32_t *index, int64_t n, cons
 
 // One table, no escape symbols, many symbols: resolve the 16-bit slot through a 64 Ki-entry lookup table instead of a
 // binary search per symbol (the decoder's critical path: the next state depends on the decoded symbol).
+// `progress`, when given, is advanced (release order) as symbols become final, so that a consumer on another thread can
+// use out[0 .. *progress) while the rest of the stream is still being decoded.
 int64_t single_table_decode(const uint8_t *stream, int64_t stream_len, int64_t n, const uint32_t *c, int32_t bins,
-                            int32_t offset, int32_t *out) {
+                            int32_t offset, int32_t *out, std::atomic<int64_t> *progress = nullptr,
+                            int64_t first_chunk = 0) {
     std::vector<uint16_t> slot_to_bin(kProbOne);
     for (int32_t b = 0; b < bins; ++b)
         for (uint32_t s = c[b]; s < c[b + 1]; ++s) slot_to_bin[s] = static_cast<uint16_t>(b);
     FrontReader r(stream, stream_len);
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t v = slot_to_bin[r.peek<kProbBits>()];
-        r.take<kProbBits>(c[v], c[v + 1] - c[v]);
-        out[i] = static_cast<int32_t>(v) + offset;
+    int64_t next_mark = progress ? std::min<int64_t>(n, first_chunk > 0 ? first_chunk : 4096) : n;
+    for (int64_t i = 0; i < n;) {
+        for (; i < next_mark; ++i) {
+            const uint32_t v = slot_to_bin[r.peek<kProbBits>()];
+            r.take<kProbBits>(c[v], c[v + 1] - c[v]);
+            out[i] = static_cast<int32_t>(v) + offset;
+        }
+        if (progress) progress->store(i, std::memory_order_release);
+        next_mark = std::min<int64_t>(n, next_mark + 4096);
     }
     return FPCC_HOST_OK;
 }
@@ -200,6 +213,7 @@ const char *fpcc_host_strerror(int64_t code) {
         case FPCC_HOST_E_BUFFER: return "output buffer too small";
         case FPCC_HOST_E_ARG: return "invalid argument";
         case FPCC_HOST_E_CDF: return "cdf cannot be made strictly increasing";
+        case FPCC_HOST_E_TIMEOUT: return "timed out waiting for the inputs of a background job";
         default: return "unknown error";
     }
 }
@@ -408,6 +422,155 @@ int64_t fpcc_simple_dec_pop_bin(fpcc_simple_dec *d, const uint16_t *edge, int64_
         bits_out[i] = one;
     }
     return FPCC_HOST_OK;
+}
+
+// ---- background coder pool ----------------------------------------------------------------------------------------
+// Jobs are ordinary calls of the coders above, started once a host-visible flag has the expected value.  The caller makes
+// the flag the LAST of a stream-ordered group of device->host copies into pinned memory, so a job begins the moment its
+// inputs have landed while the GPU keeps working on later levels; no HIP call is made from this library.
+struct fpcc_pool {
+    std::vector<std::thread> threads;
+    std::deque<std::function<int64_t()>> jobs;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_idle;
+    int64_t pending = 0;
+    int64_t first_error = 0;
+    bool closing = false;
+
+    explicit fpcc_pool(int n) {
+        for (int i = 0; i < n; ++i) threads.emplace_back([this] { run(); });
+    }
+    ~fpcc_pool() {
+        { std::lock_guard<std::mutex> g(mu); closing = true; }
+        cv_job.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void run() {
+        for (;;) {
+            std::function<int64_t()> job;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_job.wait(g, [this] { return closing || !jobs.empty(); });
+                if (jobs.empty()) return;
+                job = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            const int64_t rc = job();
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (rc < 0 && first_error == 0) first_error = rc;
+                --pending;
+            }
+            cv_idle.notify_all();
+        }
+    }
+    void submit(std::function<int64_t()> job) {
+        { std::lock_guard<std::mutex> g(mu); jobs.push_back(std::move(job)); ++pending; }
+        cv_job.notify_one();
+    }
+};
+
+namespace {
+constexpr int64_t kFlagTimeoutUs = 60ll * 1000 * 1000;
+
+bool await_flag(const volatile uint32_t *flag, uint32_t ready) {
+    if (!flag) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        if (*flag == ready) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        if ((spin & 63u) == 63u) {
+            std::this_thread::yield();
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
+                kFlagTimeoutUs) return false;
+        }
+    }
+}
+}  // namespace
+
+fpcc_pool *fpcc_pool_new(int n_threads) {
+    if (n_threads < 1 || n_threads > 256) return nullptr;
+    return new (std::nothrow) fpcc_pool(n_threads);
+}
+void fpcc_pool_free(fpcc_pool *p) { delete p; }
+
+int64_t fpcc_pool_binary_encode(fpcc_pool *p, const volatile uint32_t *flag, uint32_t ready, const uint8_t *bits,
+                                const uint16_t *prob1, int64_t n, uint8_t *out, int64_t cap, int64_t *len_out) {
+    if (!p || !bits || !prob1 || !out || !len_out || n < 0) return FPCC_HOST_E_ARG;
+    p->submit([=]() -> int64_t {
+        if (!await_flag(flag, ready)) return *len_out = FPCC_HOST_E_TIMEOUT;
+        return *len_out = binary_encode(bits, prob1, n, out, cap);
+    });
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_pool_histogram_encode(fpcc_pool *p, const volatile uint32_t *flag, uint32_t ready, const int32_t *symbols,
+                                   int64_t n, int fixed_offset, int32_t *offset_io, uint32_t *cdf_out, int64_t cdf_cap,
+                                   int64_t *cdf_len_out, uint8_t *out, int64_t cap, int64_t *len_out) {
+    if (!p || !symbols || !offset_io || !cdf_out || !cdf_len_out || !out || !len_out || n < 1 || cdf_cap < 2)
+        return FPCC_HOST_E_ARG;
+    p->submit([=]() -> int64_t {
+        if (!await_flag(flag, ready)) return *len_out = FPCC_HOST_E_TIMEOUT;
+        int32_t lo = symbols[0], hi = symbols[0];
+        for (int64_t i = 1; i < n; ++i) { lo = std::min(lo, symbols[i]); hi = std::max(hi, symbols[i]); }
+        if (fixed_offset) {
+            if (lo < *offset_io) return *len_out = FPCC_HOST_E_ARG;
+            lo = *offset_io;
+        }
+        const int64_t bins = int64_t(hi) - lo + 1;
+        if (bins + 1 > cdf_cap) return *len_out = FPCC_HOST_E_BUFFER;
+        std::vector<double> hist(static_cast<size_t>(bins), 0.0);
+        for (int64_t i = 0; i < n; ++i) hist[static_cast<size_t>(symbols[i] - lo)] += 1.0;
+        const int64_t m = fpcc_pmf_to_quantized_cdf(hist.data(), bins, 0, nullptr, cdf_out);
+        if (m < 0) return *len_out = m;
+        *cdf_len_out = m;
+        *offset_io = lo;
+        const int64_t start = 0, len = m;
+        const Tables t{cdf_out, &start, &len, offset_io, 1};
+        return *len_out = indexed_encode<false>(symbols, nullptr, n, t, out, cap);
+    });
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_pool_table_decode(fpcc_pool *p, const uint8_t *stream, int64_t stream_len, int64_t n, const uint32_t *cdf,
+                               int64_t cdf_len, int32_t offset, int32_t *symbols_out, int64_t first_chunk,
+                               int64_t *progress) {
+    if (!p || !stream || !cdf || !symbols_out || !progress || n < 0 || cdf_len < 2 || cdf_len - 1 > 65535 || stream_len < 4)
+        return FPCC_HOST_E_ARG;
+    static_assert(sizeof(std::atomic<int64_t>) == sizeof(int64_t), "progress counter must be a plain 64-bit word");
+    auto *prog = reinterpret_cast<std::atomic<int64_t> *>(progress);
+    prog->store(0, std::memory_order_relaxed);
+    p->submit([=]() -> int64_t {
+        const int64_t rc = single_table_decode(stream, stream_len, n, cdf, static_cast<int32_t>(cdf_len) - 1, offset,
+                                               symbols_out, prog, first_chunk);
+        prog->store(rc < 0 ? rc : n, std::memory_order_release);
+        return rc;
+    });
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_progress_wait(const int64_t *progress, int64_t needed) {
+    if (!progress) return FPCC_HOST_E_ARG;
+    const auto *prog = reinterpret_cast<const std::atomic<int64_t> *>(progress);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        const int64_t v = prog->load(std::memory_order_acquire);
+        if (v < 0) return v;
+        if (v >= needed) return v;
+        if ((spin & 63u) == 63u) {
+            std::this_thread::yield();
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
+                kFlagTimeoutUs) return FPCC_HOST_E_TIMEOUT;
+        }
+    }
+}
+
+int64_t fpcc_pool_wait(fpcc_pool *p) {
+    if (!p) return FPCC_HOST_E_ARG;
+    std::unique_lock<std::mutex> g(p->mu);
+    p->cv_idle.wait(g, [p] { return p->pending == 0; });
+    const int64_t rc = p->first_error;
+    p->first_error = 0;
+    return rc;
 }
 
 }  // extern "C"

@@ -22,7 +22,8 @@ enum {
     FPCC_HOST_OK = 0,
     FPCC_HOST_E_BUFFER = -1,   /* output buffer too small */
     FPCC_HOST_E_ARG = -2,      /* invalid argument (null pointer, bad size, zero-frequency symbol, ...) */
-    FPCC_HOST_E_CDF = -3       /* CDF cannot be made strictly increasing */
+    FPCC_HOST_E_CDF = -3,      /* CDF cannot be made strictly increasing */
+    FPCC_HOST_E_TIMEOUT = -4   /* a background job's input flag never became ready */
 };
 const char *fpcc_host_strerror(int64_t code);
 
@@ -55,6 +56,32 @@ int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const
  * length or a negative error code.  Returns 0 or the first error. */
 int64_t fpcc_rans_binary_encode_multi(const uint8_t *bits, const uint16_t *prob1, const int64_t *start, int64_t n_streams,
                                       uint8_t *out, int64_t cap_each, int64_t *len_out, int n_threads);
+
+/* Background coder pool: the same coders, run on the library's own threads so that entropy coding overlaps the GPU work
+ * of later pyramid levels.  This has no counterpart in the reference, whose coders run inline between blocking .cpu()
+ * calls (geo_lossl_em.py:95-114,59-74); the streams produced are the same bytes.
+ * A job starts when *flag == ready (flag == NULL: at once).  The caller makes `flag` the last of a stream-ordered group of
+ * device->host copies into pinned memory, so the job's inputs are complete when it fires; the library never calls HIP.
+ * Results land in caller-owned buffers (*len_out: stream length at the END of out[0..cap), or a negative code) and
+ * become valid after fpcc_pool_wait, which returns 0 or the first error of the jobs waited for. */
+typedef struct fpcc_pool fpcc_pool;
+fpcc_pool *fpcc_pool_new(int n_threads);
+void fpcc_pool_free(fpcc_pool *p);
+int64_t fpcc_pool_binary_encode(fpcc_pool *p, const volatile uint32_t *flag, uint32_t ready, const uint8_t *bits,
+                                const uint16_t *prob1, int64_t n, uint8_t *out, int64_t cap, int64_t *len_out);
+/* rans_encode_with_cdf (geo_lossl_em.py:59-74) as one job: offset = min(symbols) (or *offset_io when fixed_offset),
+ * histogram -> quantised CDF (no overflow bin) -> one rANS stream.  cdf_out[cdf_cap] receives *cdf_len_out entries. */
+int64_t fpcc_pool_histogram_encode(fpcc_pool *p, const volatile uint32_t *flag, uint32_t ready, const int32_t *symbols,
+                                   int64_t n, int fixed_offset, int32_t *offset_io, uint32_t *cdf_out, int64_t cdf_cap,
+                                   int64_t *cdf_len_out, uint8_t *out, int64_t cap, int64_t *len_out);
+/* Single-table decode (rans_decode_with_cdf, geo_lossl_em.py:76-93) in the background.  *progress counts the symbols that
+ * are final (first published after first_chunk symbols, then every 4096); fpcc_progress_wait blocks until it reaches
+ * `needed` and returns it, or a negative code. */
+int64_t fpcc_pool_table_decode(fpcc_pool *p, const uint8_t *stream, int64_t stream_len, int64_t n, const uint32_t *cdf,
+                               int64_t cdf_len, int32_t offset, int32_t *symbols_out, int64_t first_chunk,
+                               int64_t *progress);
+int64_t fpcc_progress_wait(const int64_t *progress, int64_t needed);
+int64_t fpcc_pool_wait(fpcc_pool *p);
 
 /* Replaces RansEncoder / RansDecoder of simple_rans_ext_cpp: one persistent stream, blocks pushed LIFO.
  * rows: uint16 [n_rows, width], entry s = upper edge of symbol s, last edge implicitly 65536; n_rows == n or 1. */

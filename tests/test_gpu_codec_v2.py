@@ -177,3 +177,20 @@ def test_rate_objective_tracks_the_coded_size(setup):
     keys = [k for k in model.state_dict() if 'bottom_fea_entropy_model' in k]
     assert 'em_lossless_based.bottom_fea_entropy_model.prior._extra_state' in keys
     assert sum('prior_weights' in k for k in keys) == 5 and sum('prior_factors' in k for k in keys) == 4
+
+
+def test_unused_encoder_tail_does_not_change_the_bytes(setup):
+    """compress() stops after the last level that feeds the bitstream; evaluating the remaining feature predictors like
+    the reference does (their result is discarded there) must give the same bytes."""
+    cfg, model, weights, ops = setup
+    xyz, coords = _cloud(6, 128, 60000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    em = model.em_lossless_based
+    short = model.compress(dev)
+    em.evaluate_unused_tail = True
+    try:
+        full = model.compress(dev)
+    finally:
+        em.evaluate_unused_tail = False
+    assert short == full
+    assert model.decompress(short).shape[0] == len(xyz)
