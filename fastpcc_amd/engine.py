@@ -13,6 +13,7 @@ Convolutions are output-stationary (gather -> MFMA GEMM), with bias, activation 
 Inference only: modules hold ordinary nn.Parameters (state_dict keys equal the reference's) but define no backward.
 """
 import math
+import os
 from enum import Enum
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -126,7 +127,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key')
+                 'gen_child', 'key', 'row_order')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -135,6 +136,7 @@ class _Map:
         self.child_row: Optional[torch.Tensor] = None     # [parent.n, 8] row of (parent, octant) in THIS map or -1
         self.generated = False                            # all 8 children of every parent row, row = 8p + octant
         self.nbr27: Optional[torch.Tensor] = None
+        self.row_order = False                            # False: not decided; None: natural order; tensor: permutation
         self.coords: Optional[torch.Tensor] = None
         self.gen_child: Optional['_Map'] = None
         self.key: Optional[CoordinateMapKey] = None
@@ -262,6 +264,19 @@ class CoordinateManager:
                 else:
                     m.nbr27 = ops.nbr27_search(m.keys, m.bits)
         return m.nbr27
+
+    # maps with more rows than this run their 3x3x3 convolutions in neighbour-pattern order (fpcc_conv_row_keys)
+    ROW_ORDER_MIN_ROWS = 8192
+    ROW_ORDER_WINDOW_LOG2 = int(os.environ.get('FPCC_ROW_WINDOW_LOG2', '17'))
+
+    def _row_order(self, m: _Map) -> Optional[torch.Tensor]:
+        """permutation of m's rows that groups like neighbour patterns into the same 32-row MFMA block; cached per map and
+        shared by every 3x3x3 layer on it"""
+        if m.row_order is False:
+            m.row_order = None
+            if m.n > self.ROW_ORDER_MIN_ROWS:
+                m.row_order = ops.conv_row_order(self._nbr27(m), 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2)
+        return m.row_order
 
     def get_coordinates(self, key: CoordinateMapKey) -> torch.Tensor:
         m = self._map(key)
@@ -621,11 +636,13 @@ class _ConvBase(nn.Module):
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
                                    nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
-                                   clip=clip)[:, :c_out]
+                                   clip=clip, row_order=cm._row_order(src))[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
             else:
-                out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, **kw)
+                mfma = ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out) != 0
+                out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1,
+                                   row_order=cm._row_order(src) if mfma else None, **kw)
         else:   # kernel 2, stride 2
             dst = cm._ensure_parent(src)
             if src.generated:

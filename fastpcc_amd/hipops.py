@@ -27,7 +27,9 @@ _SIGS = {
     'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
-                             _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp]),
+                             _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
+    'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
+    'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
     'fpcc_conv_f32_order_ex': (_i32, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_gather_sum_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _f32, _vp, _vp]),
@@ -235,7 +237,8 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
              nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1,
              bias: Optional[torch.Tensor] = None, groups: int = 1, out_map: Optional[torch.Tensor] = None,
              om_os: int = 0, om_gs: int = 1, out: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
-             act: int = ACT_NONE, slope: Optional[torch.Tensor] = None, clip: float = 0.0) -> torch.Tensor:
+             act: int = ACT_NONE, slope: Optional[torch.Tensor] = None, clip: float = 0.0,
+             row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[dst(o,g)] = act(sum_k X[nbr[k*nbr_ks + o*nbr_os]] @ w[g][k] + bias); see include/fpcc_hip.h."""
     p1, c1, ld1 = _rows2d(x1, 'x1')
     if x2 is not None:
@@ -253,6 +256,11 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         raise ValueError('output width mismatch')
     if om_os == 0:
         om_os = groups
+    ws, ws_bytes = None, 0
+    if n_offsets >= 8 and nbr is not None and n_out <= 8192:
+        ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
     trace = CONV_TRACE
     if trace is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -260,7 +268,9 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     _ok(lib().fpcc_conv_f32(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
                             w.data_ptr(), _dev(bias, torch.float32, 'bias', True), c_out, groups,
                             _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
-                            _dev(slope, torch.float32, 'slope', True), float(clip), _stream()))
+                            _dev(slope, torch.float32, 'slope', True), float(clip),
+                            _dev(row_order, torch.int32, 'row_order', True),
+                            None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
     if trace is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
@@ -268,6 +278,15 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
                                  'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
                                  'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
     return out
+
+
+def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13) -> torch.Tensor:
+    """permutation of the n output rows that puts rows with like neighbour patterns into the same MFMA block (windows of
+    2^window_log2 rows); pass it to conv_f32(row_order=...)"""
+    keys = torch.empty(n, dtype=torch.int64, device=nbr.device)
+    _ok(lib().fpcc_conv_row_keys(_dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(),
+                                 _stream()))
+    return sort_keys(keys, 32 + max(1, (n >> window_log2).bit_length()))[1]
 
 
 def conv_order(c1: int, c2: int, c_out: int, n_offsets: int = 1, groups: int = 1, n_out: int = 0) -> int:

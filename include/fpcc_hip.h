@@ -124,11 +124,25 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
                   const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                   const float *w, const float *bias, int c_out, int groups,
                   const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
-                  int act, const float *slope, float clip, void *stream);
+                  int act, const float *slope, float clip, const int32_t *row_order, void *ws, int64_t ws_bytes,
+                  void *stream);
+/* row_order (MFMA path only, NULL = natural): a permutation of [0, n_out); tile position p computes output row
+ * row_order[p].  It changes which rows share a 32-row MFMA block -- and with it how many (block, offset) products are
+ * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows
+ * in the high word, Gray rank of the row's neighbour-presence pattern in the low word); sorting them with
+ * fpcc_sort_keys (end_bit 63) yields a row_order with like patterns adjacent: on voxelised surfaces ~15 instead of ~24
+ * of the 27 offsets per block.  The reference has no counterpart (MinkowskiEngine scatters per offset). */
+int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n, int window_log2,
+                       int64_t *keys_out, void *stream);
+/* Workspace the shape needs (0 for most).  Multi-offset convolutions (8 <= n_offsets <= 27, groups == 1, C_out in
+ * {32, 64, 128}) on maps of at most 8192 rows are evaluated offset-split: one workgroup per (row tile, kernel offset)
+ * writes raw partial sums to ws[n_offsets][n_out][c_out], a second kernel reduces them (order 2 below).  Small pyramid
+ * levels otherwise run as a few workgroups walking a long serial chain of stages.  The caller owns ws (16-byte aligned). */
+int64_t fpcc_conv_f32_ws_bytes(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out);
 int fpcc_conv_f32_order(int c1, int c2, int c_out);
-/* Same, including the launch-dependent choice: multi-offset convolutions (8 <= n_offsets <= 27, groups == 1) with
- * C_in >= 128 and C_out == 128 on maps of at least 32 Ki rows run the pair-compacted kernel, whose order is 2 (per-offset FMA chains from zero, partial sums
- * added in ascending offset order, then the bias). */
+/* Same, including the launch-dependent choice: the offset-split shapes of fpcc_conv_f32_ws_bytes have order 2
+ * (per-offset FMA chains from zero in the MFMA channel order, partial sums added in ascending offset order, then the
+ * bias). */
 int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out);
 
 /* out[o] = act( sum_k y[nbr[k*nbr_ks + o*nbr_os]][k] + bias[0] ): the gather half of a 3x3x3 convolution with ONE output

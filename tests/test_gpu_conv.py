@@ -202,25 +202,95 @@ def test_engine_layers_match_oracle_orders(ops, scene):
             assert (_bits(out.F.cpu().numpy()) == _bits(want)).all(), c_in
 
 
-@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (256, 0, 128)])
-def test_pair_compacted_kernel_is_used_and_exact(ops, c1, c2, c_out):
-    """maps of >= 32 Ki rows: per-offset compaction + LDS accumulation (summation order 2), against the oracle's order 2"""
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (64, 0, 64), (16, 0, 64)])
+def test_row_order_changes_no_result(ops, c1, c2, c_out):
+    """neighbour-pattern row order (fpcc_conv_row_keys + sort): a permutation, windows respected, and the convolution in
+    that order is bit-identical to the natural order and to the oracle chain"""
     xyz = surface_cloud(33, 256, 400000)
     lvl = oc.Level(batched(xyz), 1)
-    assert lvl.n >= 32 * 1024 + 100
     n = lvl.n - 37                                   # ragged tail tile
     table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
-    assert ops.conv_order(c1, c2, c_out, 27, 1, n) == 2 and ops.conv_order(c1, c2, c_out, 27, 1, 1000) == 1
+    nbr = _cuda(table)
+    order = ops.conv_row_order(nbr, 27, n, 1, n, 11)
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(n))
+    assert ((o >> 11) == (np.arange(n) >> 11)).all()                    # rows stay inside their window of 2048
+    # blocks of 32 rows in the new order need fewer (block, offset) products
+    pres = table >= 0
+    def blocks(perm):
+        pad = (-n) % 32
+        p = np.concatenate((pres[:, perm], np.zeros((27, pad), bool)), 1).reshape(27, -1, 32)
+        return p.any(2).sum()
+    assert blocks(o) < 0.85 * blocks(np.arange(n))
     rng = np.random.default_rng(c1 + c_out)
     x1 = rng.normal(size=(lvl.n, c1)).astype(np.float32)
     x2 = rng.normal(size=(lvl.n, c2)).astype(np.float32) if c2 else None
     w = (rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32)
     b = rng.normal(size=c_out).astype(np.float32)
     slope = torch.tensor([0.1], device='cuda')
-    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
-                       n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
-    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.1, order=2)
+    args = dict(x2=None if x2 is None else _cuda(x2), nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b),
+                act=ops.ACT_PRELU, slope=slope)
+    plain = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, **args)
+    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, row_order=order, **args)
+    assert torch.equal(got, plain)
+    assert ops.conv_order(c1, c2, c_out, 27, 1, n) == 1
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.1, order=1)
     assert (_bits(got.cpu().numpy()) == _bits(want)).all()
-    again = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, x2=None if x2 is None else _cuda(x2), nbr=_cuda(table),
-                         n_offsets=27, nbr_ks=n, nbr_os=1, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
-    assert torch.equal(got, again)                   # reproducible
+
+
+def test_row_order_also_serves_the_offset_split_path(ops):
+    xyz = surface_cloud(35, 64, 9000)
+    lvl = oc.Level(batched(xyz), 1)
+    n = min(lvl.n, 5000)
+    table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
+    nbr = _cuda(table)
+    order = ops.conv_row_order(nbr, 27, n, 1, n, 8)
+    rng = np.random.default_rng(3)
+    x = _cuda(rng.normal(size=(lvl.n, 128)).astype(np.float32))
+    w = _cuda((rng.normal(size=(27, 128, 128)) / 40).astype(np.float32))
+    a = ops.conv_f32(x, w, 128, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1)
+    b = ops.conv_f32(x, w, 128, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=order)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('c1,c2,c_out,n_off', [(128, 0, 128, 27), (128, 128, 128, 27), (64, 0, 64, 27), (128, 0, 32, 27),
+                                               (128, 0, 128, 8), (32, 0, 64, 8)])
+@pytest.mark.parametrize('rows', [1, 37, 260, 4470])
+def test_offset_split_small_maps(ops, c1, c2, c_out, n_off, rows):
+    """maps of <= 8192 rows: one workgroup per (tile, offset) + reduction (summation order 2); needs the caller's workspace"""
+    xyz = surface_cloud(35, 64, 9000)
+    lvl = oc.Level(batched(xyz), 1)
+    n = min(rows, lvl.n)
+    if n_off == 27:
+        table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
+        n_in = lvl.n
+    else:
+        up = oc.strided(lvl)
+        n = min(rows, up.n)
+        table = oc.dense_table(oc.kernel_map(lvl, up, 2), up.n)[:, :n].copy()
+        n_in = lvl.n
+    assert ops.conv_order(c1, c2, c_out, n_off, 1, n) == 2
+    assert ops.lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_off, 1, n) == n_off * n * c_out * 4
+    rng = np.random.default_rng(c1 + c_out + rows)
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32)
+    x2 = rng.normal(size=(n_in, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(n_off, c1 + c2, c_out)) / np.sqrt(n_off / 2 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.3], device='cuda')
+    args = dict(x2=None if x2 is None else _cuda(x2), nbr=_cuda(table), n_offsets=n_off, nbr_ks=n, nbr_os=1, bias=_cuda(b),
+                act=ops.ACT_PRELU, slope=slope, clip=2.0)
+    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, **args)
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.3, clip=2.0, order=2)
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+    assert torch.equal(got, ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, **args))
+
+
+def test_offset_split_needs_its_workspace(ops):
+    L = ops.lib()
+    x = torch.zeros((64, 128), device='cuda')
+    w = torch.zeros((27, 128, 128), device='cuda')
+    nbr = torch.full((27, 64), -1, dtype=torch.int32, device='cuda')
+    out = torch.empty((64, 128), device='cuda')
+    rc = L.fpcc_conv_f32(x.data_ptr(), 128, 128, None, 0, 0, nbr.data_ptr(), 27, 64, 1, w.data_ptr(), None, 128, 1, None, 1, 1,
+                         out.data_ptr(), 128, 64, 0, None, 0.0, None, None, 0, None)
+    assert rc != 0 and b'workspace' in L.fpcc_last_error()
