@@ -168,6 +168,11 @@ def main():
 
     elapsed_max, total_points = replicas.aggregate(elapsed, float(n_points) * args.steps, device)
 
+    # rate / distortion of the frame just coded (outside the timed region): bpp and D1-PSNR as the reference's evaluator
+    # reports them, distortion computed on the device (fastpcc_amd/evaluators.py)
+    from fastpcc_amd.evaluators import d1_metrics
+    quality = d1_metrics(frame[:, 1:], rec, args.resolution)
+
     if rank == 0:
         # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
         cache = {}
@@ -213,7 +218,9 @@ def main():
                                    f'body-surface frame per GPU (cfg#2), seeded random-init weights',
                        'parallelism': f'replicas x{world} (independent frames)' if world > 1 else 'single GPU',
                        'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
-                       'bytes': len(data), 'bpp': round(8 * len(data) / n_points, 4)},
+                       'bytes': len(data), 'bpp': round(8 * len(data) / n_points, 4),
+                       'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
+                       'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
                          'traffic': None if traffic is None else round(traffic),

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from ... import engine as ME
 from ...data import PCData
+from ...evaluators import PCCEvaluator
 from ..geo_lossl_em import GeoLosslessEntropyModel
 from .layers import Decoder, DecoderGeoLossl, Encoder, EncoderGeoLossl, HyperDecoderGenUpsample, \
     HyperDecoderUpsample, ResidualGeoLossl
@@ -34,6 +35,7 @@ class PCC(nn.Module):
         super().__init__()
         self.cfg = cfg
         ME.set_sparse_tensor_operation_mode(ME.SparseTensorOperationMode.SHARE_COORDINATE_MANAGER)
+        self.evaluator = PCCEvaluator()
         if len(cfg.compressed_channels) != len(cfg.geo_lossl_channels) or \
                 len(cfg.geo_lossl_if_sample) != len(cfg.geo_lossl_channels) - 1 or \
                 cfg.compressed_channels[-1] != cfg.geo_lossl_channels[-1]:
@@ -142,7 +144,16 @@ class PCC(nn.Module):
             compressed_bytes = pc_data.inv_transform[0].numpy().astype('<f4').tobytes() + compressed_bytes
         else:
             pred_xyz = coord_recon
-        n_org = pc_data.org_points_num[0] if pc_data.org_points_num else \
-            (pc_data.xyz.shape[0] if whole else pc_data.xyz[0].shape[0])
-        return {'pred': pred_xyz, 'compressed_bytes': compressed_bytes, 'bpp': 8 * len(compressed_bytes) / n_org,
-                'encode time': t1 - t0, 'decode time': t3 - t2}
+        org = pc_data.xyz if whole else pc_data.xyz[0]
+        n_org = pc_data.org_points_num[0] if pc_data.org_points_num else org.shape[0]
+        ret = {'pred': pred_xyz, 'compressed_bytes': compressed_bytes, 'bpp': 8 * len(compressed_bytes) / n_org,
+               'encode time': t1 - t0, 'decode time': t3 - t2}
+        if pc_data.resolution is not None:
+            # the reference hands the reconstruction to PCCEvaluator (model.py:215-228), which runs pc_error on files;
+            # here the D1 distortion is computed on the device from the tensors at hand
+            self.evaluator.log(pred=coord_recon, org_points_num=n_org, compressed_bytes=compressed_bytes,
+                               file_path=pc_data.file_path[0] if pc_data.file_path else f'sample{len(self.evaluator.file_path_to_info)}',
+                               resolution=pc_data.resolution[0], results_dir=pc_data.results_dir,
+                               extra_info_dict={'encode time': t1 - t0, 'decode time': t3 - t2},
+                               org_xyz=org[:, 1:] if pc_data.inv_transform is None else None)
+        return ret

@@ -28,6 +28,8 @@ _SIGS = {
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
+    'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
@@ -277,6 +279,24 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
                                  'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
                                  'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
+    return out
+
+
+def nn_dist2(keys: torch.Tensor, bits: int, query: torch.Tensor, want_rows: bool = False):
+    """squared distance from every query (batch, x, y, z) int32 row to its nearest voxel in the sorted key set (-1: none)"""
+    n = query.shape[0]
+    d = torch.empty(n, dtype=torch.int64, device=query.device)
+    rows = torch.empty(n, dtype=torch.int32, device=query.device) if want_rows else None
+    if query.dim() != 2 or query.shape[1] != 4:
+        raise ValueError('query must be int32 [n, 4] = (batch, x, y, z)')
+    _ok(lib().fpcc_nn_dist2(_dev(keys, torch.int64, 'keys', keys.numel() == 0), keys.shape[0], bits, _dev(query, torch.int32, 'query'), n,
+                            d.data_ptr(), None if rows is None else rows.data_ptr(), _stream()))
+    return (d, rows) if want_rows else d
+
+
+def sum_i64(values: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.int64, device=values.device)
+    _ok(lib().fpcc_sum_i64(_dev(values, torch.int64, 'values', values.numel() == 0), values.numel(), out.data_ptr(), _stream()))
     return out
 
 

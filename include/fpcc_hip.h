@@ -193,6 +193,19 @@ int64_t fpcc_topk_keep_cells(const float *logit, int64_t m, const int32_t *cell_
                              uint8_t *keep_out, void *ws, int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* Geometry distortion (D1, point-to-point)                                                                       */
+/* ------------------------------------------------------------------------------------------------------------ */
+/* dist2_out[i] = squared distance from query i = (batch, x, y, z) to its nearest voxel of the same batch in the set given
+ * by sorted unique keys (fpcc_keys_from_coords at level 0, `bits` bits per axis); -1 when the batch is empty in the
+ * set.  nn_row_out (may be NULL) = row of that voxel (ties: the first in key order).  Exact, integer.
+ * Replaces the PLY round trip through the external `pc_error` binary (lib/evaluators.py:94-112,
+ * lib/metrics/pc_error_wrapper.py:40-107) and the brute-force KNN of lib/knn3d/src/knn3d.cu:74-130. */
+int fpcc_nn_dist2(const int64_t *keys, int64_t m, int bits, const int32_t *query, int64_t n, int64_t *dist2_out,
+                  int32_t *nn_row_out, void *stream);
+/* *sum_out (device) = sum of the non-negative entries; integer, so independent of the reduction order. */
+int fpcc_sum_i64(const int64_t *values, int64_t n, uint64_t *sum_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
 /* Integer-only pipeline (lossl_coord_int).  Replaces the pybind module `int_sparse_conv_ext`                      */
 /* (lib/int_sparse_conv/src/binding.cu:114-145).  All arithmetic is exact: results are order independent.          */
 /* ------------------------------------------------------------------------------------------------------------ */

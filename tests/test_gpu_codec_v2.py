@@ -194,3 +194,23 @@ def test_unused_encoder_tail_does_not_change_the_bytes(setup):
         em.evaluate_unused_tail = False
     assert short == full
     assert model.decompress(short).shape[0] == len(xyz)
+
+
+def test_test_forward_reports_rate_and_d1(setup):
+    """PCC.forward in eval mode = the reference's test_forward: bytes, bpp, timings, and the evaluator's D1 numbers
+    (computed on the device) equal the CPU oracle's on the same reconstruction"""
+    from fastpcc_amd.data import PCData
+    from oracle import metrics as om
+    cfg, model, weights, ops = setup
+    xyz, coords = _cloud(7, 64, 15000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    model.evaluator.reset()
+    ret = model(PCData(xyz=dev, resolution=[64], file_path=['cloud7.ply'], org_points_num=[len(xyz)]))
+    assert ret['pred'].shape[1] == 3 and ret['bpp'] == 8 * len(ret['compressed_bytes']) / len(xyz)
+    info = model.evaluator.file_path_to_info['cloud7.ply']
+    want = om.d1(xyz, ret['pred'].cpu().numpy(), 64)
+    for k, v in want.items():
+        assert info[k] == pytest.approx(v, rel=1e-12), k
+    assert info['compressed_bytes'] == len(ret['compressed_bytes']) and info['output_points_num'] == ret['pred'].shape[0]
+    mean = model.evaluator.show(None)
+    assert mean['samples_num'] == 1 and 'mseF,PSNR (p2point)(mean)' in mean

@@ -1,0 +1,97 @@
+"""fpcc_nn_dist2 / fastpcc_amd.evaluators (D1 distortion on the device) against the CPU oracle: integer squared distances
+must agree exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics as om
+from util import surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from fastpcc_amd import hipops
+    return hipops
+
+
+def _keys(ops, pts, bits, batch=None):
+    c = np.zeros((len(pts), 4), np.int32)
+    c[:, 1:] = pts
+    if batch is not None:
+        c[:, 0] = batch
+    t = torch.from_numpy(c).cuda()
+    keys, _ = ops.sort_keys(ops.keys_from_coords(t, 0, bits), 63)
+    return t, keys
+
+
+@pytest.mark.parametrize('seed,jitter', [(0, 1), (1, 3), (2, 40)])
+def test_nn_dist2_matches_kdtree(ops, seed, jitter):
+    rng = np.random.default_rng(seed)
+    a = surface_cloud(seed, 128, 30000)
+    b = np.unique(np.clip(a + rng.integers(-jitter, jitter + 1, a.shape), 0, 127), axis=0)[: len(a) - 500]
+    qa, _ = _keys(ops, a, 7)
+    _, kb = _keys(ops, b, 7)
+    d, rows = ops.nn_dist2(kb, 7, qa, want_rows=True)
+    want, _ = om.nn_dist2(a, b)
+    assert (d.cpu().numpy() == want).all()
+    # the reported row really is at that distance
+    kb_xyz = ops.coords_from_keys(kb, 0, 7).cpu().numpy()[:, 1:]
+    got_rows = rows.cpu().numpy()
+    assert (((a.astype(np.int64) - kb_xyz[got_rows]) ** 2).sum(1) == want).all()
+
+
+def test_far_sparse_and_edge_queries(ops):
+    pts = np.array([[0, 0, 0], [1023, 1023, 1023], [512, 3, 900]], dtype=np.int64)
+    q = np.array([[0, 0, 0], [1023, 0, 0], [500, 500, 500], [1, 1, 1], [1023, 1023, 1022], [0, 1023, 0], [700, 2, 901]], dtype=np.int64)
+    qa, _ = _keys(ops, q, 10)
+    _, kb = _keys(ops, pts, 10)
+    d = ops.nn_dist2(kb, 10, qa).cpu().numpy()
+    assert (d == om.brute_nn_dist2(q, pts)).all()
+
+
+def test_batches_do_not_see_each_other_and_empty_set(ops):
+    pts = np.array([[5, 5, 5], [6, 5, 5]], dtype=np.int64)
+    _, kb = _keys(ops, pts, 4, batch=np.array([0, 1]))
+    q = np.array([[6, 5, 5], [6, 5, 5], [0, 0, 0]], dtype=np.int64)
+    qa, _ = _keys(ops, q, 4, batch=np.array([0, 1, 2]))
+    d = ops.nn_dist2(kb, 4, qa).cpu().numpy()
+    assert d.tolist() == [1, 0, -1]
+    empty = torch.empty(0, dtype=torch.int64, device='cuda')
+    assert ops.nn_dist2(empty, 4, qa).cpu().numpy().tolist() == [-1, -1, -1]
+    assert int(ops.sum_i64(ops.nn_dist2(kb, 4, qa)).item()) == 1        # negative entries are not summed
+
+
+def test_evaluator_matches_oracle_and_reference_keys():
+    from fastpcc_amd.evaluators import PCCEvaluator, d1_metrics
+    rng = np.random.default_rng(4)
+    org = surface_cloud(4, 256, 80000)
+    rec = np.unique(np.clip(org + rng.integers(-2, 3, org.shape), 0, 255), axis=0)
+    rec = rec[rng.permutation(len(rec))[: len(org) - 1000]]
+    got = d1_metrics(torch.from_numpy(org).cuda(), torch.from_numpy(rec).cuda(), 256)
+    want = om.d1(org, rec, 256)
+    for k, v in want.items():
+        assert got[k] == pytest.approx(v, rel=1e-12), k
+    assert got['mse1+mse2 (p2point)'] == got['mse1      (p2point)'] + got['mse2      (p2point)']
+    same = d1_metrics(torch.from_numpy(org).cuda(), torch.from_numpy(org).cuda(), 256)
+    assert same['mseF      (p2point)'] == 0 and same['mseF,PSNR (p2point)'] == float('inf')
+    ev = PCCEvaluator()
+    for name in ('a.ply', 'b.ply'):
+        ev.log(torch.from_numpy(rec).cuda(), len(org), b'x' * 1000, name, 256, org_xyz=torch.from_numpy(org).cuda())
+    mean = ev.show(None)
+    assert mean['samples_num'] == 2 and mean['bpp(mean)'] == pytest.approx(8000 / len(org))
+    assert mean['mseF,PSNR (p2point)(mean)'] == pytest.approx(want['mseF,PSNR (p2point)'], rel=1e-12)
+
+
+def test_colour_psnr_of_identical_clouds_is_infinite():
+    from fastpcc_amd.evaluators import d1_metrics
+    org = surface_cloud(6, 64, 5000)
+    col = torch.randint(0, 256, (len(org), 3), device='cuda')
+    perm = torch.randperm(len(org), device='cuda')
+    xyz = torch.from_numpy(org).cuda()
+    out = d1_metrics(xyz, xyz[perm], 64, col, col[perm])
+    assert out['c[0],PSNRF'] == float('inf') and out['c[3],PSNRF'] == float('inf')
+    noisy = (col[perm] + 2).clamp(max=255)
+    out = d1_metrics(xyz, xyz[perm], 64, col, noisy)
+    assert 35 < out['c[0],PSNRF'] < 50

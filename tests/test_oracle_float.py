@@ -1,6 +1,7 @@
 """Self-consistency of the float oracle (MinkowskiEngine is not available): the two evaluations
 of the convolution sum agree, kernel maps obey the restated ME semantics, and the oracle codec round-trips."""
 import numpy as np
+import pytest
 import torch
 
 from fastpcc_amd.codecs.lossy_coord_v2 import Model
@@ -89,3 +90,16 @@ def test_oracle_codec_roundtrip_and_modes_agree():
     ra, rb = streams['mm'][1]['residual'], streams['chain'][1]['residual']
     assert ra.shape == rb.shape and np.mean(ra != rb) < 0.02
     assert abs(len(streams['mm'][0]) - len(streams['chain'][0])) <= 0.02 * len(streams['mm'][0])
+
+
+def test_d1_known_answers():
+    """hand-derived: A = {(0,0,0), (4,0,0)}, B = {(1,0,0)}: A->B distances 1 and 9 (mse1 = 5), B->A distance 1 (mse2 = 1)"""
+    from oracle import metrics as om
+    a = np.array([[0, 0, 0], [4, 0, 0]])
+    b = np.array([[1, 0, 0]])
+    r = om.d1(a, b, 1024)
+    assert r['mse1      (p2point)'] == 5.0 and r['mse2      (p2point)'] == 1.0 and r['mseF      (p2point)'] == 5.0
+    assert r['mseF,PSNR (p2point)'] == pytest.approx(10 * np.log10(3 * 1023 ** 2 / 5.0), rel=1e-12)
+    rng = np.random.default_rng(0)
+    q, p = rng.integers(0, 50, (300, 3)), rng.integers(0, 50, (200, 3))
+    assert (om.nn_dist2(q, p)[0] == om.brute_nn_dist2(q, p)).all()
