@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""One 3x3x3 convolution layer on a pyramid level of the headline cloud, in isolation (for rocprofv3 --pmc passes and
+quick A/B timing).  usage: conv_probe.py [level=2] [c_in=128] [c_out=128] [reps=20] [resolution=1024]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from fastpcc_amd import engine as ME, hipops as ops
+from fastpcc_amd.synthetic import SCALE, batched, body_cloud
+
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+c_in = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+c_out = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+res = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
+frame = torch.from_numpy(batched(body_cloud(res, SCALE.get(res, 1.0), seed=2))).cuda()
+cm = ME.CoordinateManager(D=3)
+x = ME.SparseTensor(torch.ones((frame.shape[0], 1), device='cuda'), coordinates=frame, coordinate_manager=cm)
+m = cm._map(x.coordinate_map_key)
+for _ in range(level):
+    m = cm._ensure_parent(m)
+nbr = cm._nbr27(m)
+order = cm._row_order(m)
+n = m.n
+torch.manual_seed(0)
+f = torch.randn((n, c_in), device='cuda')
+w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
+pairs = int((nbr >= 0).sum().item())
+def run(row_order):
+    return ops.conv_f32(f, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=row_order)
+for name, ro in (('natural', None), ('pattern', order)):
+    for _ in range(3):
+        run(ro)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        run(ro)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    print(f'level {level} rows {n} pairs/row {pairs / n:.2f} {c_in}->{c_out} {name} order: {dt * 1e6:.1f} us  '
+          f'{2 * pairs * c_in * c_out / dt / 1e12:.1f} TFLOP/s algorithmic')
