@@ -490,6 +490,8 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
             zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32) -> torch.Tensor:
     """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw]."""
     a = _rows_i8(a, 'a')
+    if not w_padded.is_cuda:
+        raise FpccError('weights must live on the GPU (libfpcc_hip has no CPU path); move the model with .cuda()')
     if w_padded.dtype != torch.int8 or not w_padded.is_contiguous() or w_padded.dim() != 3 or \
             w_padded.shape[0] != n_offsets or w_padded.shape[1] != c_out or w_padded.shape[2] % 16:
         raise ValueError('weights must be contiguous int8 [n_offsets, c_out, ldw] with ldw a multiple of 16')
