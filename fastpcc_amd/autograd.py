@@ -1,0 +1,125 @@
+"""Back-propagation through the sparse convolutions (training path).
+
+MinkowskiEngine provides this through its own autograd functions; the model code only ever calls `loss.backward()`
+(/root/reference/train.py:262-270).  Here one torch.autograd.Function wraps the C ABI:
+
+    forward   y  = fpcc_conv_f32(x, W)                                  (raw: bias / activation stay in autograd-land)
+    backward  dx = fpcc_conv_f32(dy, W') on the MIRRORED row maps        -- the input gradient of a sparse convolution is
+                   itself a sparse convolution:
+                     3x3x3 on one map      : the 27-neighbour table is symmetric, W'[k] = W[26-k]^T
+                     stride-2 2x2x2        : the transposed convolution over the same child_row table, W'[g] = W[g]^T
+                     transposed / generative: the stride-2 convolution over the same table (a packed GEMM for a
+                                              generated set), W'[g] = W[g]^T
+                     per-point linear      : W' = W^T
+              dW = fpcc_conv_wgrad_f32(x, dy) on the forward's row maps
+so the backward pass runs on the same MFMA kernel as inference (plus the weight-gradient kernel).
+"""
+from typing import Optional
+
+import torch
+
+from . import hipops as ops
+
+
+class ConvSpec:
+    """row maps of one convolution call.  kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen'"""
+    __slots__ = ('kind', 'n_in', 'n_out', 'table', 'row_order')
+
+    def __init__(self, kind: str, n_in: int, n_out: int, table: Optional[torch.Tensor] = None,
+                 row_order: Optional[torch.Tensor] = None):
+        self.kind, self.n_in, self.n_out, self.table, self.row_order = kind, n_in, n_out, table, row_order
+
+
+def _mfma(c_in: int, c_out: int) -> bool:
+    return ops.conv_order(c_in, 0, c_out) != 0
+
+
+def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
+    c_in, c_out = w.shape[-2], w.shape[-1]
+    if s.kind == 'k1':
+        return ops.conv_f32(x, w.reshape(c_in, c_out), c_out, s.n_in)
+    if s.kind == 'k3':
+        return ops.conv_f32(x, w, c_out, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
+                            row_order=s.row_order if _mfma(c_in, c_out) else None)
+    if s.kind == 'k2s2':
+        return ops.conv_f32(x, w, c_out, s.n_out, nbr=s.table, n_offsets=8, nbr_ks=1, nbr_os=8)
+    if s.kind == 'k2s2T':
+        return ops.conv_f32(x, w, c_out, s.n_in, groups=8, out_map=s.table, om_os=8, om_gs=1, out_rows=s.n_out)
+    if s.kind == 'gen':
+        return ops.conv_f32(x, w, c_out, s.n_in, groups=8)
+    raise ValueError(s.kind)
+
+
+def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
+    c_in, c_out = w.shape[-2], w.shape[-1]
+    if s.kind == 'k1':
+        return ops.conv_f32(dy, w.reshape(c_in, c_out).t().contiguous(), c_in, s.n_in)
+    if s.kind == 'k3':
+        wt = w.flip(0).transpose(1, 2).contiguous()                       # W'[k] = W[26-k]^T
+        return ops.conv_f32(dy, wt, c_in, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
+                            row_order=s.row_order if _mfma(c_out, c_in) else None)
+    wt = w.reshape(8, c_in, c_out).transpose(1, 2).contiguous()             # [8][c_out][c_in]
+    if s.kind == 'k2s2':                                                   # children <- parents: transposed form
+        return ops.conv_f32(dy, wt, c_in, s.n_out, groups=8, out_map=s.table, om_os=8, om_gs=1, out_rows=s.n_in)
+    if s.kind == 'k2s2T':                                                  # parents <- children: strided form
+        return ops.conv_f32(dy, wt, c_in, s.n_in, nbr=s.table, n_offsets=8, nbr_ks=1, nbr_os=8)
+    if s.kind == 'gen':                                                    # dY [8m, c_out] read as [m, 8*c_out]
+        return ops.conv_f32(dy.view(s.n_in, 8 * c_out), wt.reshape(8 * c_out, c_in), c_in, s.n_in)
+    raise ValueError(s.kind)
+
+
+def _weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
+    if s.kind == 'k1':
+        dw = ops.conv_wgrad(x, dy, s.n_in)
+    elif s.kind == 'k3':
+        dw = ops.conv_wgrad(x, dy, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1)
+    elif s.kind == 'k2s2':
+        dw = ops.conv_wgrad(x, dy, s.n_out, nbr=s.table, n_offsets=8, nbr_ks=1, nbr_os=8)
+    elif s.kind == 'k2s2T':
+        dw = ops.conv_wgrad(x, dy, s.n_in, groups=8, out_map=s.table, om_os=8, om_gs=1)
+    elif s.kind == 'gen':
+        dw = ops.conv_wgrad(x, dy, s.n_in, groups=8)
+    else:
+        raise ValueError(s.kind)
+    return dw.view(w.shape)
+
+
+class SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, w: torch.Tensor, spec: ConvSpec):
+        x = x.contiguous()
+        w = w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.spec = spec
+        return _forward(x, w, spec)
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        x, w = ctx.saved_tensors
+        s = ctx.spec
+        dy = dy.contiguous()
+        dx = _input_grad(dy, w, s) if ctx.needs_input_grad[0] else None
+        dw = _weight_grad(x, dy, w, s) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+def sparse_conv(x: torch.Tensor, w: torch.Tensor, spec: ConvSpec) -> torch.Tensor:
+    return SparseConvFn.apply(x, w, spec)
+
+
+class BoundFunction(torch.autograd.Function):
+    """clamp to [-bound, bound]; the gradient is replaced by +1 / -1 where the value left the interval
+    (/root/reference/models/convolutional/lossy_coord_v2/layers.py:13-25)"""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.clip(x, -bound, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        g = g.clone()
+        g[x > bound] = 1
+        g[x < -bound] = -1
+        return g, None

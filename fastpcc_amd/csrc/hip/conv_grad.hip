@@ -1,0 +1,182 @@
+// libfpcc_hip.so -- weight gradient of the sparse convolution (training path).
+//
+//   dW[g][k][ci][co] = sum over output rows o of  X[in(k,o)][ci] * dY[dst(o,g)][co]
+//
+// with in(k,o) / dst(o,g) exactly the row maps of fpcc_conv_f32 (nbr table / output map), so one entry point serves
+// stride-1, strided, transposed and generative convolutions and per-point linear layers.  What MinkowskiEngine computes
+// with one gather + GEMM + accumulate per kernel offset in its backward pass
+// (called through autograd from lib/minkowski_sparse_conv_layers.py:85-91 during train.py:262-270).
+// The input gradient needs no kernel of its own: it is fpcc_conv_f32 on the mirrored row maps with transposed weights
+// (fastpcc_amd/autograd.py).
+//
+// MFMA kernel (C_in, C_out multiples of 32): a workgroup owns (row split s, offset k, 32 input channels) and all output
+// columns, one wave per 32-column block; the reduction dimension of this GEMM is the ROW index, so both operands are
+// read straight from global memory as 128-byte row segments (lane = channel / column), two rows per MFMA k-step.
+// Row splits write partial sums; k_wgrad_reduce adds them in ascending split order (fixed association, reproducible).
+#include "common.h"
+
+#include <algorithm>
+
+namespace fpcc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float *x; int c_in; int ldx;
+    const float *dy; int c_out; int ldy;
+    const int32_t *nbr; int n_off; int64_t nbr_ks; int64_t nbr_os;
+    const int32_t *out_map; int64_t om_os; int64_t om_gs; int groups;
+    int64_t n; int64_t rows_per_split; int splits;
+    float *partial;            // [splits][groups*n_off][c_in][c_out]
+};
+
+__device__ float g_wgrad_zero[128];
+
+__device__ __forceinline__ void row_pair(const WgradArgs &a, int k, int g, int64_t r, int64_t end, int64_t &in_row,
+                                         int64_t &out_row) {
+    in_row = out_row = -1;
+    if (r < end) {
+        in_row = a.nbr ? (int64_t)a.nbr[(int64_t)k * a.nbr_ks + r * a.nbr_os] : r;
+        out_row = a.out_map ? (int64_t)a.out_map[r * a.om_os + g * a.om_gs] : r * a.groups + g;
+        if (in_row < 0 || out_row < 0) in_row = out_row = -1;
+    }
+}
+
+template <int NBT>
+__global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int s = blockIdx.x, kg = blockIdx.y, cb = blockIdx.z;
+    const int g = kg / a.n_off, k = kg % a.n_off;
+    const int64_t begin = (int64_t)s * a.rows_per_split;
+    const int64_t end = min(begin + a.rows_per_split, a.n);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    for (int64_t base = begin; base < end; base += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int64_t in_row, out_row;
+            row_pair(a, k, g, base + 2 * j + lh, end, in_row, out_row);
+            const float *px = in_row >= 0 ? a.x + in_row * a.ldx + 32 * cb + li : g_wgrad_zero + li;
+            const float *pd = out_row >= 0 ? a.dy + out_row * a.ldy + 32 * wave + li : g_wgrad_zero + li;
+            av[j] = *px;
+            bv[j] = *pd;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    }
+    float *dst = a.partial + (((int64_t)s * a.groups * a.n_off + kg) * a.c_in + 32 * cb) * a.c_out + 32 * wave + li;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        dst[(int64_t)ci * a.c_out] = acc[reg];
+    }
+}
+
+// any channel counts: thread = a few (ci, co) pairs, rows walked serially (row maps are wave-uniform scalar loads)
+__global__ __launch_bounds__(256) void k_wgrad_valu(WgradArgs a) {
+    const int s = blockIdx.x, kg = blockIdx.y;
+    const int g = kg / a.n_off, k = kg % a.n_off;
+    const int64_t begin = (int64_t)s * a.rows_per_split;
+    const int64_t end = min(begin + a.rows_per_split, a.n);
+    const int pairs = a.c_in * a.c_out;
+    float *dst = a.partial + ((int64_t)s * a.groups * a.n_off + kg) * pairs;
+    for (int p0 = 0; p0 < pairs; p0 += 256 * 4) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int ci[4], co[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 256 + (int)threadIdx.x;
+            ci[u] = p < pairs ? p / a.c_out : 0;
+            co[u] = p < pairs ? p % a.c_out : 0;
+        }
+        for (int64_t r = begin; r < end; ++r) {
+            int64_t in_row, out_row;
+            row_pair(a, k, g, r, end, in_row, out_row);
+            if (in_row < 0) continue;
+            const float *px = a.x + in_row * a.ldx;
+            const float *pd = a.dy + out_row * a.ldy;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(px[ci[u]], pd[co[u]], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 256 + (int)threadIdx.x;
+            if (p < pairs) dst[p] = acc[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int splits, int64_t count,
+                                                      float *__restrict__ dw, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    float acc = accumulate ? dw[e] : 0.0f;
+    for (int s = 0; s < splits; ++s) acc = acc + partial[(int64_t)s * count + e];
+    dw[e] = acc;
+}
+
+// row splits: enough workgroups to fill the chip ~3x, at least 256 rows each, at most 512 splits
+int pick_splits(int c_in, int c_out, int kg, int64_t n, bool mfma) {
+    const int64_t per_split_items = mfma ? (int64_t)kg * (c_in / 32) : kg;
+    int64_t want = (3 * 256 + per_split_items - 1) / per_split_items;
+    want = std::min<int64_t>(want, (n + 255) / 256);
+    want = std::max<int64_t>(1, std::min<int64_t>(want, 512));
+    (void)c_out;
+    return (int)want;
+}
+
+bool wgrad_mfma_ok(int c_in, int c_out) { return c_in % 32 == 0 && (c_out == 32 || c_out == 64 || c_out == 128); }
+
+}  // namespace
+}  // namespace fpcc
+
+using namespace fpcc;
+
+extern "C" int64_t fpcc_conv_wgrad_ws_bytes(int c_in, int c_out, int n_offsets, int groups, int64_t n) {
+    if (c_in < 1 || c_out < 1 || n_offsets < 1 || groups < 1 || n < 0) return FPCC_E_ARG;
+    const int kg = n_offsets * groups;
+    const int splits = pick_splits(c_in, c_out, kg, n, wgrad_mfma_ok(c_in, c_out));
+    return (int64_t)splits * kg * c_in * c_out * 4;
+}
+
+extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int c_out, int ldy,
+                                   const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                                   const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
+                                   float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream) {
+    if (c_in < 1 || c_out < 1 || n_offsets < 1 || groups < 1 || n < 0) return fail_arg("conv_wgrad: sizes out of range");
+    if (!dw) return fail_arg("conv_wgrad: null pointer");
+    if (!nbr && n_offsets != 1) return fail_arg("conv_wgrad: identity map needs n_offsets == 1");
+    if (ldx < c_in || ldy < c_out) return fail_arg("conv_wgrad: row stride smaller than the row");
+    const int kg = n_offsets * groups;
+    const int64_t count = (int64_t)kg * c_in * c_out;
+    hipStream_t s = as_stream(stream);
+    if (n == 0) {
+        if (!accumulate) return check_hip(hipMemsetAsync(dw, 0, count * 4, s), "hipMemsetAsync");
+        return FPCC_OK;
+    }
+    if (!x || !dy) return fail_arg("conv_wgrad: null pointer");
+    const bool mfma = wgrad_mfma_ok(c_in, c_out);
+    const int splits = pick_splits(c_in, c_out, kg, n, mfma);
+    const int64_t need = (int64_t)splits * count * 4;
+    if (!ws || ws_bytes < need) return fail_arg("conv_wgrad: workspace of fpcc_conv_wgrad_ws_bytes() bytes required");
+    const int64_t rows_per_split = ((n + splits - 1) / splits + 31) / 32 * 32;
+    WgradArgs a{x, c_in, ldx, dy, c_out, ldy, nbr, n_offsets, nbr_ks, nbr_os, out_map, om_os, om_gs, groups, n,
+                rows_per_split, splits, static_cast<float *>(ws)};
+    if (mfma) {
+        const dim3 grid(splits, kg, c_in / 32);
+        if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma<4>), grid, dim3(256), 0, s, a);
+        else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma<2>), grid, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_wgrad_mfma<1>), grid, dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_wgrad_valu, dim3(splits, kg), dim3(256), 0, s, a);
+    }
+    if (int rc = check_hip(hipGetLastError(), "k_wgrad")) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks_for(count, 256)), dim3(256), 0, s, static_cast<const float *>(ws), splits,
+                       count, dw, accumulate);
+    return check_hip(hipGetLastError(), "k_wgrad_reduce");
+}

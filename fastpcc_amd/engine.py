@@ -10,7 +10,9 @@ pyramid: the stride-2 parent of a key is key >> 3, its octant key & 7.  Conseque
   * the 3x3x3 kernel map of a level is derived from its parent's (no hash table).
 Convolutions are output-stationary (gather -> MFMA GEMM), with bias, activation and channel concatenation fused.
 
-Inference only: modules hold ordinary nn.Parameters (state_dict keys equal the reference's) but define no backward.
+Modules hold ordinary nn.Parameters (state_dict keys equal the reference's).  With gradients enabled the convolutions
+run through fastpcc_amd/autograd.py (same kernels; bias / activation as differentiable tensor ops); under
+torch.no_grad() they take the fused inference path.
 """
 import math
 import os
@@ -432,10 +434,10 @@ def cat(*tensors) -> SparseTensor:
 # modules
 class _Act:
     """What a convolution may fuse after its bias."""
-    __slots__ = ('kind', 'slope')
+    __slots__ = ('kind', 'slope', 'param')
 
-    def __init__(self, kind=ops.ACT_NONE, slope=None):
-        self.kind, self.slope = kind, slope
+    def __init__(self, kind=ops.ACT_NONE, slope=None, param=None):
+        self.kind, self.slope, self.param = kind, slope, param       # param: the live nn.Parameter (training path)
 
 
 def _act_of(module: Optional[nn.Module]) -> _Act:
@@ -444,7 +446,7 @@ def _act_of(module: Optional[nn.Module]) -> _Act:
     if isinstance(module, MinkowskiPReLU):
         if module.module.weight.numel() != 1:
             raise NotImplementedError('per-channel PReLU')
-        return _Act(ops.ACT_PRELU, module.module.weight.detach())
+        return _Act(ops.ACT_PRELU, module.module.weight.detach(), module.module.weight)
     if isinstance(module, MinkowskiReLU):
         return _Act(ops.ACT_RELU)
     raise NotImplementedError(f'cannot fuse {type(module).__name__}')
@@ -561,6 +563,36 @@ class _ConvBase(nn.Module):
             return x
         return torch.nn.functional.pad(x, (0, width - x.shape[1]))
 
+    def _forward_autograd(self, x: SparseTensor, cm, src: _Map, coordinates, act: _Act, clip: float) -> SparseTensor:
+        """training path: the convolution as an autograd function (fastpcc_amd/autograd.py), epilogue as tensor ops"""
+        from .autograd import ConvSpec, sparse_conv
+        feats = x.F
+        if self.GENERATIVE:
+            dst = cm._generated(src)
+            spec = ConvSpec('gen', src.n, dst.n)
+        elif self.TRANSPOSED:
+            if coordinates is None:
+                raise ValueError('a transposed convolution needs the target coordinate key')
+            dst = cm._map(coordinates)
+            if dst.parent is not src:
+                raise ValueError('target map is not a stride-2 child of the input map')
+            spec = ConvSpec('gen', src.n, dst.n) if dst.generated else ConvSpec('k2s2T', src.n, dst.n, dst.child_row)
+        elif self.ks == 1:
+            dst = src
+            spec = ConvSpec('k1', src.n, src.n)
+        elif self.ks == 3:
+            dst = src
+            if coordinates is not None and cm._map(coordinates) is not src:
+                raise NotImplementedError('stride-1 convolution onto a different coordinate map')
+            spec = ConvSpec('k3', src.n, src.n, cm._nbr27(src), cm._row_order(src))
+        else:
+            dst = cm._ensure_parent(src)
+            if src.generated:
+                raise NotImplementedError('stride-2 convolution of a generated set')
+            spec = ConvSpec('k2s2', src.n, dst.n, src.child_row)
+        out = _finish_autograd(sparse_conv(feats, self.kernel, spec), self.bias, act, clip)
+        return SparseTensor(out, coordinate_map_key=dst.key, coordinate_manager=cm)
+
     def reset_parameters(self):
         # MinkowskiEngine 0.5's default: U(-1/sqrt(n), 1/sqrt(n)), n = (C_out if transposed else C_in) * volume
         fan = (self.out_channels if (self.TRANSPOSED or self.GENERATIVE) else self.in_channels) * \
@@ -573,11 +605,11 @@ class _ConvBase(nn.Module):
 
     def forward(self, x: SparseTensor, coordinates: Optional[CoordinateMapKey] = None, *, act: Optional[_Act] = None,
                 clip: float = 0.0) -> SparseTensor:
-        if torch.is_grad_enabled() and self.kernel.requires_grad:
-            raise RuntimeError('fastpcc_amd convolutions are inference-only; wrap the call in torch.no_grad()')
         act = act or _Act()
         cm = x.coordinate_manager
         src = cm._map(x.coordinate_map_key)
+        if torch.is_grad_enabled() and (self.kernel.requires_grad or any(p.requires_grad for p in x.parts)):
+            return self._forward_autograd(x, cm, src, coordinates, act, clip)
         parts = x.parts
         x1 = parts[0]
         x2 = parts[1] if len(parts) > 1 else None
@@ -655,6 +687,20 @@ class MinkowskiConvolution(_ConvBase):
     pass
 
 
+def _finish_autograd(out: torch.Tensor, bias: Optional[torch.Tensor], act: _Act, clip: float) -> torch.Tensor:
+    """bias, activation and clamp of the training path as differentiable tensor ops (inference fuses them into the kernel)"""
+    if bias is not None:
+        out = out + bias.view(1, -1)
+    if act.kind == ops.ACT_PRELU:
+        out = torch.nn.functional.prelu(out, act.param if act.param is not None else act.slope)
+    elif act.kind == ops.ACT_RELU:
+        out = torch.relu(out)
+    if clip > 0:
+        from .autograd import BoundFunction
+        out = BoundFunction.apply(out, torch.tensor(float(clip), device=out.device))
+    return out
+
+
 class MinkowskiConvolutionTranspose(_ConvBase):
     TRANSPOSED = True
 
@@ -678,9 +724,13 @@ class MinkowskiLinear(nn.Module):
         return self._wt
 
     def forward(self, x: SparseTensor, *, act: Optional[_Act] = None, clip: float = 0.0) -> SparseTensor:
-        if torch.is_grad_enabled() and self.linear.weight.requires_grad:
-            raise RuntimeError('fastpcc_amd layers are inference-only; wrap the call in torch.no_grad()')
         act = act or _Act()
+        if torch.is_grad_enabled() and (self.linear.weight.requires_grad or any(p.requires_grad for p in x.parts)):
+            from .autograd import ConvSpec, sparse_conv
+            n = x.parts[0].shape[0]
+            out = sparse_conv(x.F, self.linear.weight.t(), ConvSpec('k1', n, n))
+            out = _finish_autograd(out, self.linear.bias, act, clip)
+            return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         parts = x.parts
         b = self.linear.bias
         out = ops.conv_f32(parts[0], self._weight_t(), self.linear.out_features, parts[0].shape[0],
@@ -727,5 +777,9 @@ class MinkowskiPruning(nn.Module):
         if not src.generated:
             raise NotImplementedError('pruning of a non-generated map')
         t = cm._refine(src.parent, mask.contiguous(), 'pruned')
-        rows = torch.nonzero(mask.view(-1)).squeeze(1).to(torch.int32)
-        return SparseTensor(ops.gather_rows(x.F, rows), coordinate_map_key=t.key, coordinate_manager=cm)
+        rows = torch.nonzero(mask.view(-1)).squeeze(1)
+        if torch.is_grad_enabled() and x.F.requires_grad:
+            kept = x.F[rows]                                        # differentiable row selection (training path)
+        else:
+            kept = ops.gather_rows(x.F, rows.to(torch.int32))
+        return SparseTensor(kept, coordinate_map_key=t.key, coordinate_manager=cm)

@@ -30,6 +30,9 @@ _SIGS = {
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
+    'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
+    'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _i32,
+                                   _vp, _i64, _vp]),
     'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
@@ -305,6 +308,28 @@ def nn_dist2(keys: torch.Tensor, bits: int, query: torch.Tensor, want_rows: bool
 def sum_i64(values: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.int64, device=values.device)
     _ok(lib().fpcc_sum_i64(_dev(values, torch.int64, 'values', values.numel() == 0), values.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, *, nbr: Optional[torch.Tensor] = None, n_offsets: int = 1,
+               nbr_ks: int = 0, nbr_os: int = 1, out_map: Optional[torch.Tensor] = None, om_os: int = 0, om_gs: int = 1,
+               groups: int = 1, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dW [groups, n_offsets, c_in, c_out] of the convolution whose forward used these row maps; see fpcc_conv_wgrad_f32"""
+    px, c_in, ldx = _rows2d(x, 'x')
+    pd, c_out, ldy = _rows2d(dy, 'dy')
+    if out is None:
+        out = torch.empty((groups, n_offsets, c_in, c_out), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if not out.is_contiguous() or out.numel() != groups * n_offsets * c_in * c_out or out.dtype != torch.float32:
+        raise ValueError('dw must be contiguous fp32 [groups, n_offsets, c_in, c_out]')
+    L = lib()
+    need = _ok(L.fpcc_conv_wgrad_ws_bytes(c_in, c_out, n_offsets, groups, n))
+    ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=x.device)
+    if om_os == 0:
+        om_os = groups
+    _ok(L.fpcc_conv_wgrad_f32(px, c_in, ldx, pd, c_out, ldy, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                              _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, groups, n, out.data_ptr(),
+                              int(accumulate), ws.data_ptr(), need, _stream()))
     return out
 
 

@@ -145,6 +145,20 @@ int fpcc_conv_f32_order(int c1, int c2, int c_out);
  * bias). */
 int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out);
 
+/* Weight gradient of the same operator (training; MinkowskiEngine's autograd backward, reached from
+ * lib/minkowski_sparse_conv_layers.py:85-91 under train.py:262-270):
+ *     dw[g][k][ci][co] (+)= sum_o x[in(k,o)][ci] * dy[dst(o,g)][co]
+ * with in(k,o) = nbr[k*nbr_ks + o*nbr_os] (NULL: o) and dst(o,g) = out_map[o*om_os + g*om_gs] (NULL: o*groups + g), rows
+ * with a negative entry skipped; o < n.  x is ONE matrix [*, c_in] (concatenate two sources first, or call twice on
+ * the two halves of dw).  ws: fpcc_conv_wgrad_ws_bytes() bytes of partial sums per row split, reduced in ascending split
+ * order (the association is fixed by the shape alone, so results are reproducible).  accumulate != 0 adds to dw.
+ * The input gradient is fpcc_conv_f32 itself on the mirrored row maps with transposed weights (fastpcc_amd/autograd.py). */
+int64_t fpcc_conv_wgrad_ws_bytes(int c_in, int c_out, int n_offsets, int groups, int64_t n);
+int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int c_out, int ldy,
+                        const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                        const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
+                        float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream);
+
 /* out[o] = act( sum_k y[nbr[k*nbr_ks + o*nbr_os]][k] + bias[0] ): the gather half of a 3x3x3 convolution with ONE output
  * channel, whose per-offset dot products y = X @ [w_0 | ... | w_26] (padded to 32 columns) were computed per input row
  * by fpcc_conv_f32.  Together they replace MinkowskiConvolution(C, 1, kernel_size=3) (occupancy / residual heads,
