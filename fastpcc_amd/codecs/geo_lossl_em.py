@@ -93,8 +93,7 @@ class GeoLosslessEntropyModel(nn.Module):
     # -- rate objective (geo_lossl_em.py:115-158) -----------------------------------------------------------------------
     def forward(self, y_top: ME.SparseTensor, batch_size: int = 1):
         """Training-mode forward: returns (reconstructed top features, {'fea_bottom_bits_loss', 'coord_i_bits_loss',
-        'fea_i_bits_loss'}).  The sparse convolutions of this build are forward-only, so the terms carry gradients
-        only w.r.t. the entropy-model parameters; back-propagation through the convolutions is not built yet."""
+        'fea_i_bits_loss'}), differentiable end to end (convolutions through fastpcc_amd/autograd.py)."""
         if not self.training:
             raise RuntimeError('forward() evaluates the training objective; use compress() / decompress() for coding')
         cm = y_top.coordinate_manager

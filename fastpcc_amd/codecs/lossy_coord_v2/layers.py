@@ -10,6 +10,7 @@ from typing import List, Optional, Tuple
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import engine as ME
 from ... import hipops as ops
@@ -76,10 +77,66 @@ class Decoder(nn.Module):
             prev = ch
         self.pruning = ME.MinkowskiPruning()
 
-    def forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None):
+    def forward(self, fea, points_num_list, coord_offset=None):
         if self.training:
-            raise NotImplementedError('training path is not part of this build')
+            return self.train_forward(fea, points_num_list, coord_offset)      # third argument: the target key
         return self.test_forward(fea, points_num_list, coord_offset)
+
+    def train_forward(self, fea, points_num_list, target_key: ME.CoordinateMapKey) -> dict:
+        """per upsampling stage: binary cross-entropy of the occupancy logits against the true finer coordinates, then
+        prune to (adaptive top-k | true) candidates (layers.py:118-137)"""
+        loss = {}
+        n_stage = len(self.upsample_blocks)
+        inv = [1 / sum(c) for c in points_num_list] if points_num_list is not None else None
+        for i, (up, classify) in enumerate(zip(self.upsample_blocks, self.classify_blocks)):
+            fea = up(fea)
+            pred = classify(fea)
+            keep = self.get_keep_train(pred, points_num_list)
+            target = self.get_target(pred, target_key)
+            keep |= target
+            loss[f'coord_{n_stage - i - 1}_recon_loss'] = F.binary_cross_entropy_with_logits(
+                pred.F.squeeze(1), target.to(pred.F.dtype), reduction='sum')
+            if i != n_stage - 1:
+                fea = self.pruning(fea, keep.to(torch.uint8))
+        if inv is not None and len(inv) != 1:
+            total = sum(inv)
+            for i in range(n_stage):
+                loss[f'coord_{i}_recon_loss'] = loss[f'coord_{i}_recon_loss'] * (inv[i] / total * len(inv))
+        return loss
+
+    @torch.no_grad()
+    def get_target(self, pred: ME.SparseTensor, target_key: ME.CoordinateMapKey) -> torch.Tensor:
+        """bool [n]: which generated candidates are voxels of the (strided) target set (layers.py:182-190)"""
+        cm = pred.coordinate_manager
+        gen = cm._map(pred.coordinate_map_key)
+        tgt = cm._map(cm.stride(target_key, pred.tensor_stride))
+        if not gen.generated or tgt.parent is not gen.parent:
+            raise NotImplementedError('the target set must be a child map of the map the candidates were generated from')
+        return ops.child_mask(tgt.child_row).bool()
+
+    @torch.no_grad()
+    def get_keep_train(self, pred: ME.SparseTensor, points_num_list: Optional[List[List[int]]]) -> torch.Tensor:
+        """training-time variant of get_keep for a batch: per sample, the logits above its own k-th value, or the maximum
+        of their 2x2x2 cell.  Bookkeeping under no_grad, written with tensor ops (one stage of upsampling)."""
+        cm = pred.coordinate_manager
+        gen = cm._map(pred.coordinate_map_key)
+        if not gen.generated or len(self.upsample_blocks) != 1:
+            raise NotImplementedError('training-time pruning supports one generative stage (decoder_channels of length 1)')
+        logits = pred.F.view(-1, 8)
+        not_max = logits != logits.max(1, keepdim=True).values
+        if points_num_list is None:
+            keep = logits > 0
+        else:
+            targets = points_num_list.pop()
+            edges = cm.batch_offsets(gen.parent)
+            keep = torch.zeros_like(not_max)
+            for tgt, a, b in zip(targets, edges[:-1], edges[1:]):
+                sample, nm = logits[a:b], not_max[a:b]
+                if not sample.numel() > tgt:
+                    raise ValueError('fewer candidates than points to keep')
+                thr = torch.kthvalue(sample[nm], sample.numel() - tgt).values
+                keep[a:b] = sample > thr
+        return (keep | ~not_max).view(-1)
 
     @torch.no_grad()
     def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -258,7 +315,7 @@ class EncoderGeoLossl(nn.Module):
         return len(self.blocks)
 
     def forward(self, x: ME.SparseTensor, batch_size: int) -> List[ME.SparseTensor]:
-        if batch_size != 1:
+        if batch_size != 1 and not self.training:
             raise NotImplementedError('batch size 1 at test time')
         outs = [self.blocks_out_first(x) if self.blocks_out_first is not None else x]
         last = len(self.blocks) - 1

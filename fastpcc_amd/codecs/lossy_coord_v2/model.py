@@ -59,7 +59,7 @@ class PCC(nn.Module):
     # ---------------------------------------------------------------------------------------------------------------
     def forward(self, pc_data: PCData):
         if self.training:
-            raise NotImplementedError('training is not part of this inference build')
+            return self.train_forward(pc_data.xyz, pc_data.training_step, pc_data.batch_size)
         if pc_data.batch_size != 1:
             raise ValueError('Only supports batch size == 1 during testing.')
         return self.test_forward(pc_data)
@@ -77,6 +77,31 @@ class PCC(nn.Module):
         ones = torch.ones((xyz.shape[0], 1), dtype=torch.float32, device=xyz.device)
         return ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
                                quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+
+    def train_forward(self, batched_coord: torch.Tensor, training_step: int, batch_size: int) -> dict:
+        """rate + distortion objective of one batch (model.py:156-191): returns {'loss': tensor with the autograd graph,
+        every other term as a float}"""
+        sparse_pc = self.get_sparse_pc(batched_coord)
+        feature, points_num_list = self.encoder(sparse_pc)
+        bottleneck_feature, loss_dict = self.em_lossless_based(feature, batch_size)
+        for k, v in self.decoder(bottleneck_feature, points_num_list, sparse_pc.coordinate_map_key).items():
+            loss_dict[k] = loss_dict[k] + v if k in loss_dict else v
+        cfg = self.cfg
+        if training_step < cfg.warmup_fea_loss_steps:
+            step = (cfg.warmup_fea_loss_factor - cfg.bits_loss_factor) / cfg.warmup_fea_loss_steps
+            fea_factor = cfg.warmup_fea_loss_factor - step * training_step if cfg.linear_warmup else cfg.warmup_fea_loss_factor
+        else:
+            fea_factor = cfg.bits_loss_factor
+        for key in loss_dict:
+            if key.endswith('bits_loss'):
+                loss_dict[key] = loss_dict[key] * (fea_factor if 'fea' in key else cfg.bits_loss_factor)
+            if key.startswith('coord_recon_loss'):          # (sic) the reference's prefix test, model.py:187
+                loss_dict[key] = loss_dict[key] * cfg.coord_recon_loss_factor
+        loss_dict['loss'] = sum(loss_dict.values())
+        for key in loss_dict:
+            if key != 'loss':
+                loss_dict[key] = loss_dict[key].item()
+        return loss_dict
 
     # ---------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
