@@ -105,3 +105,52 @@ def test_optimizer_step_lowers_the_loss(setup):
         last = float(out['loss'])
     assert last < first
     model.load_state_dict(state, strict=False)
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from fastpcc_amd import replicas
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+    from fastpcc_amd.data import PCData
+    from fastpcc_amd.train import TrainConfig, Trainer
+    from util import enliven
+    # both ranks share the one GPU of the test box, so the collective runs over gloo (on a node with one GPU per rank the
+    # same code path uses 'nccl' = RCCL)
+    replicas.init('gloo')
+    torch.manual_seed(0)
+    model = Model(baseline_r1())
+    enliven(model, 0)
+    tr = Trainer(model, TrainConfig(batch_size=2), torch.device('cuda', 0))
+    assert isinstance(tr.model, DDP)
+    torch.manual_seed(50 + rank)
+    out = tr.step(PCData(xyz=_batch([20 + rank], n=4000), batch_size=1))
+    probe = {n: p.detach().float().sum().item() for n, p in tr.model.module.named_parameters()}
+    digest = torch.cat([p.detach().reshape(-1)[:8].cpu() for p in tr.model.module.parameters()])
+    q.put((rank, out['loss'], digest.numpy(), len(probe)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_keep_parameters_identical():
+    """the full model under DistributedDataParallel: two ranks, different clouds and noise, one optimiser step ->
+    identical parameters on both ranks (every parameter took part in the backward pass: find_unused_parameters=False)"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][1] != got[1][1]                       # different data -> different local losses
+    assert (got[0][2] == got[1][2]).all()               # same parameters after the all-reduced update
