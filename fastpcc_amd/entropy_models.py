@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .rans_coder import IndexedRansCoder
+from .sparse_conv_layers import minkowski_tensor_wrapped_fn
 
 
 # ---- gradient-shaping helpers --------------------------------------------------------------------------------------
@@ -238,6 +239,7 @@ class NoisyDeepFactorizedEntropyModel(nn.Module):
             x = x + torch.empty_like(x).uniform_(-0.5, 0.5)
         return x
 
+    @minkowski_tensor_wrapped_fn({1: 0})
     def forward(self, x: torch.Tensor):
         if self.bottleneck_scaler != 1:
             x = x * self.bottleneck_scaler
@@ -250,6 +252,7 @@ class NoisyDeepFactorizedEntropyModel(nn.Module):
         return self.decompress(bytes_list, batch_shape, x.device), bytes_list, batch_shape
 
     @torch.no_grad()
+    @minkowski_tensor_wrapped_fn({1: 2})
     def compress(self, x: torch.Tensor, estimate_bits: bool = False):
         s = self.bottleneck_scaler
         if s != 1:
@@ -272,6 +275,7 @@ class NoisyDeepFactorizedEntropyModel(nn.Module):
         return strings, batch_shape, deq
 
     @torch.no_grad()
+    @minkowski_tensor_wrapped_fn({'<del>sparse_tensor_coords_tuple': 0})
     def decompress(self, bytes_list: List[bytes], batch_shape: torch.Size, target_device, broadcast_shape=None):
         total = sum(self.broadcast_shape_bytes)
         if total:

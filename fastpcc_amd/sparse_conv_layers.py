@@ -6,8 +6,11 @@ Difference in execution only: convolution / linear, bias add and activation run 
 (fpcc_conv_f32's fused epilogue) instead of three MinkowskiEngine ops.  BatchNorm is not available (every in-scope config
 uses bn=False).
 """
-from typing import Callable, Optional, Union
+import functools
+import math
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
+import torch
 from torch import nn
 
 from . import engine as ME
@@ -130,3 +133,94 @@ class NNSequentialWithConvTransBlockArgs(NNSequentialWithArgs):
 
 class NNSequentialWithConvBlockArgs(NNSequentialWithArgs):
     target_block_class = ConvBlock
+
+
+# ---- sparse-tensor <-> plain-tensor adapters (lib/minkowski_sparse_conv_layers.py:252-400) -------------------------------------
+def minkowski_tensor_wrapped_op(x, operation: Callable[[torch.Tensor], Any], needs_recover: bool = True,
+                                add_batch_dim: bool = False):
+    """apply `operation` to the feature matrix of a sparse tensor (or to a plain tensor as is); tensor results are wrapped
+    back onto x's coordinate map when needs_recover, or get a leading batch dimension when add_batch_dim"""
+    if needs_recover and add_batch_dim:
+        raise ValueError('needs_recover and add_batch_dim exclude each other')
+    if isinstance(x, torch.Tensor):
+        return operation(x)
+    ret = operation(x.F)
+    items = list(ret) if isinstance(ret, tuple) else [ret]
+    for i, r in enumerate(items):
+        if isinstance(r, torch.Tensor):
+            if needs_recover:
+                items[i] = ME.SparseTensor(r, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+            elif add_batch_dim:
+                items[i] = r[None]
+    return items[0] if len(items) == 1 else tuple(items)
+
+
+def get_minkowski_tensor_coords_tuple(x):
+    try:
+        return x.coordinate_map_key, x.coordinate_manager
+    except AttributeError:
+        return None
+
+
+def minkowski_tensor_wrapped_fn(inout_mapping_dict: Optional[Dict[Union[int, str], Union[int, List[int], None]]] = None,
+                                add_batch_dim: bool = True):
+    """Decorator for functions written on plain tensors.  `{arg: out}`: if argument `arg` (position or keyword) is a
+    SparseTensor its features are passed instead ([1, N, C] when add_batch_dim) and result number `out` (or each of a
+    list) is wrapped back onto its coordinate map; an argument may also be a (CoordinateMapKey, CoordinateManager) pair
+    that only names the map; a key '<del>name' removes that argument before the call."""
+    mapping = inout_mapping_dict or {}
+
+    def decorate(func):
+        @functools.wraps(func)
+        def wrapped(*args, **kwargs):
+            args = list(args)
+            onto: Dict[int, Tuple] = {}
+            for in_key, outs in mapping.items():
+                drop = False
+                if isinstance(in_key, str) and in_key.startswith('<'):
+                    flag, in_key = in_key[1:].split('>', 1)
+                    if flag != 'del':
+                        raise NotImplementedError(flag)
+                    drop = True
+                if isinstance(in_key, str) and in_key.lstrip('-').isdigit():
+                    in_key = int(in_key)
+                bag = args if isinstance(in_key, int) else kwargs
+                try:
+                    obj = bag[in_key]
+                except (IndexError, KeyError):
+                    continue
+                where = None
+                if isinstance(obj, ME.SparseTensor):
+                    bag[in_key] = obj.F[None] if add_batch_dim else obj.F
+                    where = (obj.coordinate_map_key, obj.coordinate_manager)
+                elif isinstance(obj, (tuple, list)) and len(obj) == 2 and isinstance(obj[0], ME.CoordinateMapKey):
+                    where = tuple(obj)
+                if where is not None and outs is not None:
+                    for o in (outs if isinstance(outs, list) else [outs]):
+                        onto[o] = where
+                if drop:
+                    del bag[in_key]
+            ret = func(*args, **kwargs)
+            if not onto:
+                return ret
+            items = list(ret) if isinstance(ret, tuple) else [ret]
+            for o, (key, cm) in onto.items():
+                f = items[o]
+                items[o] = ME.SparseTensor(f[0] if add_batch_dim else f, coordinate_map_key=key, coordinate_manager=cm)
+            return items[0] if len(items) == 1 else tuple(items)
+        return wrapped
+    return decorate
+
+
+def minkowski_tensor_split(x, split_size: Union[int, List[int]]) -> List:
+    """channel split of a sparse tensor: by a list of widths, or into blocks of `split_size` channels"""
+    width = x.F.shape[1]
+    if isinstance(split_size, list):
+        ends = list(torch.cumsum(torch.tensor(split_size), 0).tolist())
+    else:
+        if math.ceil(width / split_size) < 2:
+            raise ValueError('a split needs at least two blocks')
+        ends = list(range(split_size, width, split_size)) + [width]
+    starts = [0] + ends[:-1]
+    return [ME.SparseTensor(x.F[:, a:b], coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+            for a, b in zip(starts, ends)]

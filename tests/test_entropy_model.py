@@ -129,3 +129,19 @@ def test_bad_arguments():
         EM.make_parameters(4, 10, (2, 3, 1))
     with pytest.raises(ValueError):
         EM.NoisyDeepFactorizedEntropyModel(torch.Size([4]), 2, lower_bound=3, upper_bound=3)
+
+
+def test_sparse_tensor_adapters_without_gpu():
+    """minkowski_tensor_wrapped_fn / _op on plain tensors and on objects that only look like sparse tensors are identities
+    (the SparseTensor round trip itself needs the device and is in tests/test_gpu_codec_v2.py)"""
+    from fastpcc_amd.sparse_conv_layers import get_minkowski_tensor_coords_tuple, minkowski_tensor_wrapped_fn, \
+        minkowski_tensor_wrapped_op
+
+    @minkowski_tensor_wrapped_fn({1: 0, '<del>tag': None})
+    def f(self, x, scale=2.0, **kw):
+        assert 'tag' not in kw
+        return x * scale, 'aux'
+    y, aux = f(None, torch.ones(3), tag='dropped')
+    assert torch.equal(y, torch.full((3,), 2.0)) and aux == 'aux'
+    assert torch.equal(minkowski_tensor_wrapped_op(torch.ones(2), lambda t: t + 1), torch.full((2,), 2.0))
+    assert get_minkowski_tensor_coords_tuple(torch.ones(1)) is None

@@ -214,3 +214,32 @@ def test_test_forward_reports_rate_and_d1(setup):
     assert info['compressed_bytes'] == len(ret['compressed_bytes']) and info['output_points_num'] == ret['pred'].shape[0]
     mean = model.evaluator.show(None)
     assert mean['samples_num'] == 1 and 'mseF,PSNR (p2point)(mean)' in mean
+
+
+def test_entropy_model_takes_sparse_tensors(setup):
+    """the reference's models hand ME.SparseTensors to the entropy bottleneck through minkowski_tensor_wrapped_fn
+    (continuous_batched.py:52,77,116): features go in as [1, N, C], results come back on the same coordinate map"""
+    from fastpcc_amd import engine as ME
+    cfg, model, weights, ops = setup
+    xyz, coords = _cloud(8, 32, 3000)
+    cm = ME.CoordinateManager(D=3)
+    st = ME.SparseTensor(torch.randn((len(xyz), 1), device='cuda') * 3, coordinates=torch.from_numpy(coords).to(torch.int32).cuda(),
+                         coordinate_manager=cm)
+    em = model.em_lossless_based.bottom_fea_entropy_model
+    em.train()
+    try:
+        y, loss = em(st)
+    finally:
+        em.eval()
+    assert isinstance(y, ME.SparseTensor) and y.coordinate_map_key == st.coordinate_map_key and y.F.shape == st.F.shape
+    assert float(loss['bits_loss'].detach()) > 0
+    strings, shape, deq = em.compress(st)
+    assert isinstance(deq, ME.SparseTensor) and len(strings) == 1
+    back = em.decompress(strings, shape, st.F.device, sparse_tensor_coords_tuple=(st.coordinate_map_key, cm))
+    assert isinstance(back, ME.SparseTensor) and torch.equal(back.F, deq.F)
+    from fastpcc_amd.sparse_conv_layers import minkowski_tensor_split, minkowski_tensor_wrapped_op
+    wide = ME.SparseTensor(torch.randn((len(xyz), 6), device='cuda'), coordinate_map_key=st.coordinate_map_key, coordinate_manager=cm)
+    a, b = minkowski_tensor_split(wide, [2, 4])
+    assert a.F.shape[1] == 2 and b.F.shape[1] == 4 and torch.equal(torch.cat((a.F, b.F), 1), wide.F)
+    doubled = minkowski_tensor_wrapped_op(wide, lambda t: t * 2)
+    assert isinstance(doubled, ME.SparseTensor) and torch.equal(doubled.F, wide.F * 2)
