@@ -50,14 +50,27 @@ def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     raise ValueError(s.kind)
 
 
+def _wide(call, wt: torch.Tensor, width: int, rows: int, device) -> torch.Tensor:
+    """a convolution with more than 128 output columns (the input gradient of a layer that read a 256-channel
+    concatenation) as 128-column launches of the MFMA kernel into one output matrix"""
+    if width <= 128 or width % 128:
+        return call(wt, width, None)
+    out = torch.empty((rows, width), dtype=torch.float32, device=device)
+    for lo in range(0, width, 128):
+        call(wt[..., lo: lo + 128].contiguous(), 128, out[:, lo: lo + 128])
+    return out
+
+
 def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     c_in, c_out = w.shape[-2], w.shape[-1]
     if s.kind == 'k1':
-        return ops.conv_f32(dy, w.reshape(c_in, c_out).t().contiguous(), c_in, s.n_in)
+        return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out),
+                     w.reshape(c_in, c_out).t().contiguous(), c_in, s.n_in, dy.device)
     if s.kind == 'k3':
         wt = w.flip(0).transpose(1, 2).contiguous()                       # W'[k] = W[26-k]^T
-        return ops.conv_f32(dy, wt, c_in, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
-                            row_order=s.row_order if _mfma(c_out, c_in) else None)
+        return _wide(lambda wk, c, out: ops.conv_f32(dy, wk, c, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
+                                                     row_order=s.row_order if _mfma(c_out, c) else None, out=out),
+                     wt, c_in, s.n_in, dy.device)
     wt = w.reshape(8, c_in, c_out).transpose(1, 2).contiguous()             # [8][c_out][c_in]
     if s.kind == 'k2s2':                                                   # children <- parents: transposed form
         return ops.conv_f32(dy, wt, c_in, s.n_out, groups=8, out_map=s.table, om_os=8, om_gs=1, out_rows=s.n_in)

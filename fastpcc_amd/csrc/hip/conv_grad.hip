@@ -21,6 +21,7 @@ namespace fpcc {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
     const float *x; int c_in; int ldx;
@@ -77,6 +78,55 @@ __global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma(WgradArgs a) {
     }
 }
 
+// C_in a multiple of 128: one workgroup covers 128 input channels x all output columns.  Wave w owns column block w and
+// FOUR accumulator blocks; lane i of the A operand carries channels 4i .. 4i+3 (one 16-byte load per row), block q holding
+// channel 4i + q -- a permutation of the channel <-> M-index assignment that costs nothing at the store.  Every X row is
+// read once per wave (L1-shared by the workgroup's waves) and every dY row once per workgroup: an eighth of the L2 traffic
+// of the per-block kernel above.
+template <int NBT>
+__global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma128(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int s = blockIdx.x, kg = blockIdx.y, cg = blockIdx.z;
+    const int g = kg / a.n_off, k = kg % a.n_off;
+    const int64_t begin = (int64_t)s * a.rows_per_split;
+    const int64_t end = min(begin + a.rows_per_split, a.n);
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+    for (int64_t base = begin; base < end; base += 32) {
+        f32x4 av[16];
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int64_t in_row, out_row;
+            row_pair(a, k, g, base + 2 * j + lh, end, in_row, out_row);
+            const float *px = in_row >= 0 ? a.x + in_row * a.ldx + 128 * cg + 4 * li : g_wgrad_zero + 4 * li;
+            const float *pd = out_row >= 0 ? a.dy + out_row * a.ldy + 32 * wave + li : g_wgrad_zero + li;
+            av[j] = *reinterpret_cast<const f32x4 *>(px);
+            bv[j] = *pd;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j], acc[3], 0, 0, 0);
+        }
+    }
+    float *dst = a.partial + (((int64_t)s * a.groups * a.n_off + kg) * a.c_in + 128 * cg) * a.c_out + 32 * wave + li;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = (reg & 3) + 8 * (reg >> 2) + 4 * lh;            // M index of the accumulator row
+            dst[(int64_t)(4 * m + q) * a.c_out] = acc[q][reg];
+        }
+}
+
 // any channel counts: thread = a few (ci, co) pairs, rows walked serially (row maps are wave-uniform scalar loads)
 __global__ __launch_bounds__(256) void k_wgrad_valu(WgradArgs a) {
     const int s = blockIdx.x, kg = blockIdx.y;
@@ -111,6 +161,62 @@ __global__ __launch_bounds__(256) void k_wgrad_valu(WgradArgs a) {
     }
 }
 
+// few (ci, co) pairs (<= 128: one-channel heads, the first layers, the decoder's classifier): every thread walks its own
+// rows with ALL pairs in registers, then the block adds the 256 private sums (wave shuffles, then LDS)
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void k_wgrad_small(WgradArgs a) {
+    constexpr int P = CI * CO;
+    const int s = blockIdx.x, kg = blockIdx.y;
+    const int g = kg / a.n_off, k = kg % a.n_off;
+    const int64_t begin = (int64_t)s * a.rows_per_split;
+    const int64_t end = min(begin + a.rows_per_split, a.n);
+    float acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+    for (int64_t r = begin + threadIdx.x; r < end; r += 256) {
+        int64_t in_row, out_row;
+        row_pair(a, k, g, r, end, in_row, out_row);
+        if (in_row < 0) continue;
+        const float *px = a.x + in_row * a.ldx;
+        const float *pd = a.dy + out_row * a.ldy;
+        float d[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) d[co] = pd[co];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const float xv = px[ci];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[ci * CO + co] = fmaf(xv, d[co], acc[ci * CO + co]);
+        }
+    }
+    __shared__ float part[4][P];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float v = acc[p];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) part[wave][p] = v;
+    }
+    __syncthreads();
+    float *dst = a.partial + ((int64_t)s * a.groups * a.n_off + kg) * P;
+    for (int p = threadIdx.x; p < P; p += 256) dst[p] = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
+}
+
+template <int CI, int CO>
+bool try_small(const WgradArgs &a, int splits, int kg, hipStream_t s) {
+    if (a.c_in != CI || a.c_out != CO) return false;
+    hipLaunchKernelGGL((k_wgrad_small<CI, CO>), dim3(splits, kg), dim3(256), 0, s, a);
+    return true;
+}
+
+bool launch_small(const WgradArgs &a, int splits, int kg, hipStream_t s) {
+    return try_small<1, 1>(a, splits, kg, s) || try_small<1, 16>(a, splits, kg, s) || try_small<1, 64>(a, splits, kg, s) ||
+           try_small<8, 1>(a, splits, kg, s) || try_small<16, 8>(a, splits, kg, s) || try_small<16, 1>(a, splits, kg, s) ||
+           try_small<32, 1>(a, splits, kg, s) || try_small<64, 1>(a, splits, kg, s) || try_small<128, 1>(a, splits, kg, s) ||
+           try_small<4, 16>(a, splits, kg, s) || try_small<1, 32>(a, splits, kg, s) || try_small<1, 8>(a, splits, kg, s);
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int splits, int64_t count,
                                                       float *__restrict__ dw, int accumulate) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,13 +228,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 
 // row splits: enough workgroups to fill the chip ~3x, at least 256 rows each, at most 512 splits
 int pick_splits(int c_in, int c_out, int kg, int64_t n, bool mfma) {
-    const int64_t per_split_items = mfma ? (int64_t)kg * (c_in / 32) : kg;
+    const int64_t per_split_items = mfma ? (int64_t)kg * (c_in % 128 == 0 ? c_in / 128 : c_in / 32) : kg;
     int64_t want = (3 * 256 + per_split_items - 1) / per_split_items;
     want = std::min<int64_t>(want, (n + 255) / 256);
     want = std::max<int64_t>(1, std::min<int64_t>(want, 512));
     (void)c_out;
     return (int)want;
 }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool wgrad_mfma_ok(int c_in, int c_out) { return c_in % 32 == 0 && (c_out == 32 || c_out == 64 || c_out == 128); }
 
@@ -167,12 +275,17 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
     const int64_t rows_per_split = ((n + splits - 1) / splits + 31) / 32 * 32;
     WgradArgs a{x, c_in, ldx, dy, c_out, ldy, nbr, n_offsets, nbr_ks, nbr_os, out_map, om_os, om_gs, groups, n,
                 rows_per_split, splits, static_cast<float *>(ws)};
-    if (mfma) {
+    if (mfma && c_in % 128 == 0 && aligned16(x) && ldx % 4 == 0) {
+        const dim3 grid(splits, kg, c_in / 128);
+        if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma128<4>), grid, dim3(256), 0, s, a);
+        else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma128<2>), grid, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_wgrad_mfma128<1>), grid, dim3(64), 0, s, a);
+    } else if (mfma) {
         const dim3 grid(splits, kg, c_in / 32);
         if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma<4>), grid, dim3(256), 0, s, a);
         else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma<2>), grid, dim3(128), 0, s, a);
         else hipLaunchKernelGGL((k_wgrad_mfma<1>), grid, dim3(64), 0, s, a);
-    } else {
+    } else if (!launch_small(a, splits, kg, s)) {
         hipLaunchKernelGGL(k_wgrad_valu, dim3(splits, kg), dim3(256), 0, s, a);
     }
     if (int rc = check_hip(hipGetLastError(), "k_wgrad")) return rc;
