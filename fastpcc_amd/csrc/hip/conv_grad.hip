@@ -78,52 +78,50 @@ __global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma(WgradArgs a) {
     }
 }
 
-// C_in a multiple of 128: one workgroup covers 128 input channels x all output columns.  Wave w owns column block w and
-// FOUR accumulator blocks; lane i of the A operand carries channels 4i .. 4i+3 (one 16-byte load per row), block q holding
-// channel 4i + q -- a permutation of the channel <-> M-index assignment that costs nothing at the store.  Every X row is
-// read once per wave (L1-shared by the workgroup's waves) and every dY row once per workgroup: an eighth of the L2 traffic
-// of the per-block kernel above.
-template <int NBT>
-__global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma128(WgradArgs a) {
+// C_in a multiple of 32*CB (CB = 4 or 2): one workgroup covers 32*CB input channels x all output columns.  Wave w owns
+// column block w and CB accumulator blocks; lane i of the A operand carries channels CB*i .. CB*i+CB-1 (one 16- or 8-byte
+// load per row), block q holding channel CB*i + q -- a permutation of the channel <-> M-index assignment that costs
+// nothing at the store.  Every X row is read once per wave (L1-shared by the workgroup's waves) and every dY row once per
+// workgroup: 1/(2*CB) of the L2 traffic of the per-block kernel above.
+template <int NBT, int CB>
+__global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma_wide(WgradArgs a) {
+    typedef float fvec __attribute__((ext_vector_type(CB)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int s = blockIdx.x, kg = blockIdx.y, cg = blockIdx.z;
     const int g = kg / a.n_off, k = kg % a.n_off;
     const int64_t begin = (int64_t)s * a.rows_per_split;
     const int64_t end = min(begin + a.rows_per_split, a.n);
-    f32x16 acc[4];
+    f32x16 acc[CB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < CB; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
     for (int64_t base = begin; base < end; base += 32) {
-        f32x4 av[16];
+        fvec av[16];
         float bv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             int64_t in_row, out_row;
             row_pair(a, k, g, base + 2 * j + lh, end, in_row, out_row);
-            const float *px = in_row >= 0 ? a.x + in_row * a.ldx + 128 * cg + 4 * li : g_wgrad_zero + 4 * li;
+            const float *px = in_row >= 0 ? a.x + in_row * a.ldx + 32 * CB * cg + CB * li : g_wgrad_zero + CB * li;
             const float *pd = out_row >= 0 ? a.dy + out_row * a.ldy + 32 * wave + li : g_wgrad_zero + li;
-            av[j] = *reinterpret_cast<const f32x4 *>(px);
+            av[j] = *reinterpret_cast<const fvec *>(px);
             bv[j] = *pd;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j], acc[3], 0, 0, 0);
-        }
-    }
-    float *dst = a.partial + (((int64_t)s * a.groups * a.n_off + kg) * a.c_in + 128 * cg) * a.c_out + 32 * wave + li;
+        for (int j = 0; j < 16; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < CB; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][q], bv[j], acc[q], 0, 0, 0);
+    }
+    float *dst = a.partial + (((int64_t)s * a.groups * a.n_off + kg) * a.c_in + 32 * CB * cg) * a.c_out + 32 * wave + li;
+#pragma unroll
+    for (int q = 0; q < CB; ++q)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int m = (reg & 3) + 8 * (reg >> 2) + 4 * lh;            // M index of the accumulator row
-            dst[(int64_t)(4 * m + q) * a.c_out] = acc[q][reg];
+            dst[(int64_t)(CB * m + q) * a.c_out] = acc[q][reg];
         }
 }
 
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 
 // row splits: enough workgroups to fill the chip ~3x, at least 256 rows each, at most 512 splits
 int pick_splits(int c_in, int c_out, int kg, int64_t n, bool mfma) {
-    const int64_t per_split_items = mfma ? (int64_t)kg * (c_in % 128 == 0 ? c_in / 128 : c_in / 32) : kg;
+    const int64_t per_split_items = mfma ? (int64_t)kg * (c_in % 128 == 0 ? c_in / 128 : c_in % 64 == 0 ? c_in / 64 : c_in / 32) : kg;
     int64_t want = (3 * 256 + per_split_items - 1) / per_split_items;
     want = std::min<int64_t>(want, (n + 255) / 256);
     want = std::max<int64_t>(1, std::min<int64_t>(want, 512));
@@ -277,9 +275,14 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
                 rows_per_split, splits, static_cast<float *>(ws)};
     if (mfma && c_in % 128 == 0 && aligned16(x) && ldx % 4 == 0) {
         const dim3 grid(splits, kg, c_in / 128);
-        if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma128<4>), grid, dim3(256), 0, s, a);
-        else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma128<2>), grid, dim3(128), 0, s, a);
-        else hipLaunchKernelGGL((k_wgrad_mfma128<1>), grid, dim3(64), 0, s, a);
+        if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma_wide<4, 4>), grid, dim3(256), 0, s, a);
+        else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma_wide<2, 4>), grid, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_wgrad_mfma_wide<1, 4>), grid, dim3(64), 0, s, a);
+    } else if (mfma && c_in % 64 == 0 && aligned16(x) && ldx % 4 == 0) {
+        const dim3 grid(splits, kg, c_in / 64);
+        if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma_wide<4, 2>), grid, dim3(256), 0, s, a);
+        else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma_wide<2, 2>), grid, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_wgrad_mfma_wide<1, 2>), grid, dim3(64), 0, s, a);
     } else if (mfma) {
         const dim3 grid(splits, kg, c_in / 32);
         if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma<4>), grid, dim3(256), 0, s, a);
