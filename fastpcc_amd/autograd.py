@@ -120,6 +120,60 @@ def sparse_conv(x: torch.Tensor, w: torch.Tensor, spec: ConvSpec) -> torch.Tenso
     return SparseConvFn.apply(x, w, spec)
 
 
+class SparseConvActFn(torch.autograd.Function):
+    """convolution + bias + (P)ReLU as ONE node: the forward is the fused inference launch, the backward recovers
+    dL/d(pre-activation), dbias and dslope from the saved OUTPUT (fpcc_epilogue_bwd_f32; needs a PReLU slope > 0) and
+    feeds the two gradient convolutions"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope, spec: ConvSpec, act: int):
+        x = x.contiguous()
+        w = w.contiguous()
+        c_in, c_out = w.shape[-2], w.shape[-1]
+        b = None if bias is None else bias.reshape(-1)
+        kw = dict(bias=b, act=act, slope=slope)
+        if spec.kind == 'k1':
+            y = ops.conv_f32(x, w.reshape(c_in, c_out), c_out, spec.n_in, **kw)
+        elif spec.kind == 'k3':
+            y = ops.conv_f32(x, w, c_out, spec.n_in, nbr=spec.table, n_offsets=27, nbr_ks=spec.n_in, nbr_os=1,
+                             row_order=spec.row_order if _mfma(c_in, c_out) else None, **kw)
+        elif spec.kind == 'k2s2':
+            y = ops.conv_f32(x, w, c_out, spec.n_out, nbr=spec.table, n_offsets=8, nbr_ks=1, nbr_os=8, **kw)
+        elif spec.kind == 'k2s2T':
+            y = ops.conv_f32(x, w, c_out, spec.n_in, groups=8, out_map=spec.table, om_os=8, om_gs=1, out_rows=spec.n_out, **kw)
+        elif spec.kind == 'gen':
+            y = ops.conv_f32(x, w, c_out, spec.n_in, groups=8, **kw)
+        else:
+            raise ValueError(spec.kind)
+        ctx.save_for_backward(x, w, y, slope if slope is not None else x.new_empty(0))
+        ctx.spec, ctx.act, ctx.has_bias, ctx.has_slope = spec, act, bias is not None, slope is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, slope = ctx.saved_tensors
+        s = ctx.spec
+        dy = dy.contiguous()
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_s = ctx.has_slope and ctx.needs_input_grad[3]
+        if ctx.act == ops.ACT_NONE and not want_b:
+            g, dbias, dslope = dy, None, None
+        else:
+            g, dbias, dslope = ops.epilogue_bwd(y, dy, ctx.act, slope if ctx.has_slope else None, want_b, want_s)
+        dx = _input_grad(g, w, s) if ctx.needs_input_grad[0] else None
+        dw = _weight_grad(x, g, w, s) if ctx.needs_input_grad[1] else None
+        if dbias is not None:
+            dbias = dbias.view(ctx.bias_shape)
+        if dslope is not None:
+            dslope = dslope.view(slope.shape)
+        return dx, dw, dbias, dslope, None, None
+
+
+def sparse_conv_act(x, w, bias, slope, spec: ConvSpec, act: int) -> torch.Tensor:
+    return SparseConvActFn.apply(x, w, bias, slope, spec, act)
+
+
 class BoundFunction(torch.autograd.Function):
     """clamp to [-bound, bound]; the gradient is replaced by +1 / -1 where the value left the interval
     (/root/reference/models/convolutional/lossy_coord_v2/layers.py:13-25)"""

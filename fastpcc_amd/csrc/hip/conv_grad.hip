@@ -296,3 +296,97 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
                        count, dw, accumulate);
     return check_hip(hipGetLastError(), "k_wgrad_reduce");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of fpcc_conv_f32's fused epilogue  y = act(pre + bias)  (act: none | ReLU | PReLU with ONE slope > 0), computed
+// from the layer's OUTPUT: for slope > 0, pre < 0 <=> y < 0 and pre = y / slope there, so nothing but y has to be kept
+// from the forward pass.       g = dy * act'(pre)      dbias[c] = sum_rows g[., c]      dslope = sum dy * pre [pre < 0]
+// In the reference these are three autograd nodes (bias add, MinkowskiPReLU, their reductions) per layer
+// (lib/minkowski_sparse_conv_layers.py:85-91).  Row blocks write partial sums, reduced in ascending block order.
+namespace fpcc {
+namespace {
+constexpr int kEpiRows = 256;        // rows per workgroup
+
+__global__ __launch_bounds__(256) void k_epilogue_bwd(const float *__restrict__ y, int ldy, const float *__restrict__ dy, int lddy,
+                                                      int64_t n, int c, int cpad, int act, const float *__restrict__ slope,
+                                                      float *__restrict__ g, int ldg, float *__restrict__ partial) {
+    __shared__ float s_col[256];
+    __shared__ float s_slope[256];
+    const int col = threadIdx.x % cpad, grp = threadIdx.x / cpad, groups = 256 / cpad;
+    const int64_t r0 = (int64_t)blockIdx.x * kEpiRows;
+    const int64_t r1 = min(r0 + kEpiRows, n);
+    const float sl = (act == FPCC_ACT_PRELU) ? slope[0] : 0.0f;
+    float *dst = partial + (int64_t)blockIdx.x * (c + 1);
+    for (int c0 = 0; c0 < c; c0 += cpad) {            // cpad < c only when c > 256
+        const int cc = c0 + col;
+        float sum_g = 0.0f, sum_s = 0.0f;
+        if (cc < c) {
+            for (int64_t r = r0 + grp; r < r1; r += groups) {
+                const float yv = y[r * ldy + cc], d = dy[r * lddy + cc];
+                float gv = d;
+                if (act != FPCC_ACT_NONE && !(yv > 0.0f)) {       // pre <= 0 (torch's convention at 0: the negative branch)
+                    gv = d * sl;                                 // sl == 0 for ReLU
+                    if (act == FPCC_ACT_PRELU) sum_s = fmaf(d, yv / sl, sum_s);
+                }
+                g[r * ldg + cc] = gv;
+                sum_g += gv;
+            }
+        }
+        s_col[threadIdx.x] = sum_g;
+        s_slope[threadIdx.x] = sum_s;
+        __syncthreads();
+        if (grp == 0 && cc < c) {
+            float t = 0.0f;
+            for (int q = 0; q < groups; ++q) t += s_col[q * cpad + col];
+            dst[cc] = t;
+        }
+        if (threadIdx.x == 0) {
+            float t = c0 == 0 ? 0.0f : dst[c];
+            for (int q = 0; q < 256; ++q) t += s_slope[q];
+            dst[c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_epilogue_bwd_reduce(const float *__restrict__ partial, int64_t blocks, int c,
+                                                             float *__restrict__ dbias, float *__restrict__ dslope) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc > c) return;
+    float t = 0.0f;
+    for (int64_t b = 0; b < blocks; ++b) t += partial[b * (c + 1) + cc];
+    if (cc < c) { if (dbias) dbias[cc] = t; }
+    else if (dslope) dslope[0] = t;
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int64_t fpcc_epilogue_bwd_ws_bytes(int64_t n, int c) {
+    if (n < 0 || c < 1) return FPCC_E_ARG;
+    return ((n + kEpiRows - 1) / kEpiRows) * (int64_t)(c + 1) * 4;
+}
+
+extern "C" int fpcc_epilogue_bwd_f32(const float *y, int ldy, const float *dy, int lddy, int64_t n, int c, int act,
+                                     const float *slope, float *g, int ldg, float *dbias, float *dslope, void *ws,
+                                     int64_t ws_bytes, void *stream) {
+    if (n < 0 || c < 1 || ldy < c || lddy < c || ldg < c) return fail_arg("epilogue_bwd: sizes out of range");
+    if (act != FPCC_ACT_NONE && act != FPCC_ACT_PRELU && act != FPCC_ACT_RELU) return fail_arg("epilogue_bwd: unknown activation");
+    if (act == FPCC_ACT_PRELU && !slope) return fail_arg("epilogue_bwd: PReLU needs its slope");
+    hipStream_t s = as_stream(stream);
+    if (n == 0) {
+        if (dbias) if (int rc = check_hip(hipMemsetAsync(dbias, 0, (size_t)c * 4, s), "hipMemsetAsync")) return rc;
+        if (dslope) if (int rc = check_hip(hipMemsetAsync(dslope, 0, 4, s), "hipMemsetAsync")) return rc;
+        return FPCC_OK;
+    }
+    if (!y || !dy || !g) return fail_arg("epilogue_bwd: null pointer");
+    const int64_t blocks = (n + kEpiRows - 1) / kEpiRows;
+    if (!ws || ws_bytes < blocks * (int64_t)(c + 1) * 4) return fail_arg("epilogue_bwd: workspace of fpcc_epilogue_bwd_ws_bytes() bytes required");
+    int cpad = 1;
+    while (cpad < c && cpad < 256) cpad <<= 1;
+    hipLaunchKernelGGL(k_epilogue_bwd, dim3((unsigned)blocks), dim3(256), 0, s, y, ldy, dy, lddy, n, c, cpad, act, slope, g, ldg,
+                       static_cast<float *>(ws));
+    if (int rc = check_hip(hipGetLastError(), "k_epilogue_bwd")) return rc;
+    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3(blocks_for(c + 1, 256)), dim3(256), 0, s, static_cast<const float *>(ws), blocks, c,
+                       dbias, dslope);
+    return check_hip(hipGetLastError(), "k_epilogue_bwd_reduce");
+}

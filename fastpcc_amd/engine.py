@@ -590,7 +590,12 @@ class _ConvBase(nn.Module):
             if src.generated:
                 raise NotImplementedError('stride-2 convolution of a generated set')
             spec = ConvSpec('k2s2', src.n, dst.n, src.child_row)
-        out = _finish_autograd(sparse_conv(feats, self.kernel, spec), self.bias, act, clip)
+        if _fusable_in_training(act):
+            from .autograd import sparse_conv_act
+            out = sparse_conv_act(feats, self.kernel, self.bias, act.param if act.kind == ops.ACT_PRELU else None, spec, act.kind)
+            out = _finish_autograd(out, None, _Act(), clip)
+        else:
+            out = _finish_autograd(sparse_conv(feats, self.kernel, spec), self.bias, act, clip)
         return SparseTensor(out, coordinate_map_key=dst.key, coordinate_manager=cm)
 
     def reset_parameters(self):
@@ -687,6 +692,29 @@ class MinkowskiConvolution(_ConvBase):
     pass
 
 
+def _fusable_in_training(act: _Act) -> bool:
+    """the fused training node recovers the activation's derivative from the layer output, which needs a PReLU slope > 0
+    (true of every trained checkpoint; the slope starts at 0.25).  The sign is read from a host-side cache that
+    fastpcc_amd.train.Trainer refreshes after every optimiser step; without a cache it is fetched (one sync)."""
+    if act.kind != ops.ACT_PRELU:
+        return True
+    if act.param is None:
+        return False
+    cached = getattr(act.param, '_fpcc_host_value', None)
+    if cached is None:
+        cached = float(act.param.detach().reshape(-1)[0].item())
+        act.param._fpcc_host_value = cached
+    return cached > 0
+
+
+def refresh_prelu_cache(model: nn.Module) -> None:
+    """one device->host transfer of all single-slope PReLU parameters (call after the optimiser changed them)"""
+    ps = [m.module.weight for m in model.modules() if isinstance(m, MinkowskiPReLU) and m.module.weight.numel() == 1]
+    if ps:
+        for p, v in zip(ps, torch.cat([p.detach().reshape(1) for p in ps]).tolist()):
+            p._fpcc_host_value = v
+
+
 def _finish_autograd(out: torch.Tensor, bias: Optional[torch.Tensor], act: _Act, clip: float) -> torch.Tensor:
     """bias, activation and clamp of the training path as differentiable tensor ops (inference fuses them into the kernel)"""
     if bias is not None:
@@ -728,8 +756,13 @@ class MinkowskiLinear(nn.Module):
         if torch.is_grad_enabled() and (self.linear.weight.requires_grad or any(p.requires_grad for p in x.parts)):
             from .autograd import ConvSpec, sparse_conv
             n = x.parts[0].shape[0]
-            out = sparse_conv(x.F, self.linear.weight.t(), ConvSpec('k1', n, n))
-            out = _finish_autograd(out, self.linear.bias, act, clip)
+            if _fusable_in_training(act):
+                from .autograd import sparse_conv_act
+                out = sparse_conv_act(x.F, self.linear.weight.t(), self.linear.bias,
+                                      act.param if act.kind == ops.ACT_PRELU else None, ConvSpec('k1', n, n), act.kind)
+                out = _finish_autograd(out, None, _Act(), clip)
+            else:
+                out = _finish_autograd(sparse_conv(x.F, self.linear.weight.t(), ConvSpec('k1', n, n)), self.linear.bias, act, clip)
             return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         parts = x.parts
         b = self.linear.bias

@@ -33,6 +33,8 @@ _SIGS = {
     'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _i32,
                                    _vp, _i64, _vp]),
+    'fpcc_epilogue_bwd_ws_bytes': (_i64, [_i64, _i32]),
+    'fpcc_epilogue_bwd_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
@@ -331,6 +333,26 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, *, nbr: Optional[torch
                               _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, groups, n, out.data_ptr(),
                               int(accumulate), ws.data_ptr(), need, _stream()))
     return out
+
+
+def epilogue_bwd(y: torch.Tensor, dy: torch.Tensor, act: int, slope: Optional[torch.Tensor], want_bias: bool,
+                 want_slope: bool):
+    """-> (g, dbias [c] | None, dslope [1] | None): backward of conv_f32's fused bias + activation from the output y"""
+    py, c, ldy = _rows2d(y, 'y')
+    pd, c2, lddy = _rows2d(dy, 'dy')
+    if c2 != c or y.shape[0] != dy.shape[0]:
+        raise ValueError('y and dy must have one shape')
+    n = y.shape[0]
+    g = torch.empty((n, c), dtype=torch.float32, device=y.device)
+    dbias = torch.empty(c, dtype=torch.float32, device=y.device) if want_bias else None
+    dslope = torch.empty(1, dtype=torch.float32, device=y.device) if want_slope else None
+    L = lib()
+    need = _ok(L.fpcc_epilogue_bwd_ws_bytes(n, c))
+    ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=y.device)
+    _ok(L.fpcc_epilogue_bwd_f32(py, ldy, pd, lddy, n, c, act, _dev(slope, torch.float32, 'slope', True), g.data_ptr(), c,
+                                None if dbias is None else dbias.data_ptr(), None if dslope is None else dslope.data_ptr(),
+                                ws.data_ptr(), need, _stream()))
+    return g, dbias, dslope
 
 
 def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13) -> torch.Tensor:

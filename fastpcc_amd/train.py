@@ -22,6 +22,7 @@ import torch.distributed as dist
 from torch.nn.parallel import DistributedDataParallel as DDP
 
 from . import replicas
+from .engine import refresh_prelu_cache
 from .data import PCData
 
 _EXTRA_STATE_SUFFIX = '_extra_state'
@@ -119,6 +120,7 @@ class Trainer:
             for opt in self.optimizers:
                 if opt is not None:
                     opt.zero_grad(set_to_none=True)
+            refresh_prelu_cache(unwrap(self.model))       # host copy of the PReLU slopes' signs for the fused training node
         self.micro_step += 1
         out = dict(out)
         out['loss'] = float(out['loss'].detach())

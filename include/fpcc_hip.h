@@ -159,6 +159,16 @@ int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int 
                         const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
                         float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream);
 
+/* Backward of fpcc_conv_f32's fused epilogue y = act(pre + bias) from the layer OUTPUT y (act: none | ReLU | PReLU with one
+ * slope > 0, for which pre < 0 <=> y < 0 and pre = y / slope there):
+ *     g = dy * act'(pre),   dbias[c] = sum_rows g[., c] (NULL: skipped),   dslope[0] = sum dy * pre over pre < 0 (NULL: skipped).
+ * g feeds the input / weight gradients above.  Replaces the bias-add and MinkowskiPReLU autograd nodes of
+ * lib/minkowski_sparse_conv_layers.py:85-91.  ws: fpcc_epilogue_bwd_ws_bytes() bytes of per-row-block partial sums,
+ * reduced in ascending block order (reproducible).  g may alias dy. */
+int64_t fpcc_epilogue_bwd_ws_bytes(int64_t n, int c);
+int fpcc_epilogue_bwd_f32(const float *y, int ldy, const float *dy, int lddy, int64_t n, int c, int act, const float *slope,
+                          float *g, int ldg, float *dbias, float *dslope, void *ws, int64_t ws_bytes, void *stream);
+
 /* out[o] = act( sum_k y[nbr[k*nbr_ks + o*nbr_os]][k] + bias[0] ): the gather half of a 3x3x3 convolution with ONE output
  * channel, whose per-offset dot products y = X @ [w_0 | ... | w_26] (padded to 32 columns) were computed per input row
  * by fpcc_conv_f32.  Together they replace MinkowskiConvolution(C, 1, kernel_size=3) (occupancy / residual heads,

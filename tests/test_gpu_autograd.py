@@ -145,3 +145,28 @@ def loss_of_nograd(net, x):
         h = net[3](h, x.coordinate_map_key)
         h = net[4](h)
         return (h.F ** 2).mean()
+
+
+@pytest.mark.parametrize('c', [1, 8, 64, 128, 300])
+@pytest.mark.parametrize('act', ['none', 'relu', 'prelu'])
+def test_fused_epilogue_backward_matches_torch(c, act):
+    """fpcc_epilogue_bwd_f32 (dL/dpre, dbias, dslope from the layer OUTPUT) against torch autograd of bias add + (P)ReLU"""
+    from fastpcc_amd import hipops as ops
+    g = torch.Generator().manual_seed(c)
+    n = 5000 + c
+    pre = torch.randn((n, c), generator=g).cuda().double().requires_grad_()
+    bias = torch.randn(c, generator=g).cuda().double().requires_grad_()
+    slope = torch.tensor([0.3], device='cuda', dtype=torch.float64, requires_grad=True)
+    z = pre + bias
+    y = z if act == 'none' else torch.relu(z) if act == 'relu' else torch.nn.functional.prelu(z, slope)
+    dy = torch.randn((n, c), generator=g).cuda()
+    y.backward(dy.double())
+    kind = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'prelu': ops.ACT_PRELU}[act]
+    got_g, got_b, got_s = ops.epilogue_bwd(y.detach().float().contiguous(), dy, kind, slope.detach().float() if act == 'prelu' else None,
+                                           True, act == 'prelu')
+    _close(got_g, pre.grad, 'g')
+    _close(got_b, bias.grad, 'dbias')
+    if act == 'prelu':
+        _close(got_s, slope.grad, 'dslope')
+    again = ops.epilogue_bwd(y.detach().float().contiguous(), dy, kind, slope.detach().float() if act == 'prelu' else None, True, False)
+    assert torch.equal(again[0], got_g) and torch.equal(again[1], got_b)
