@@ -349,14 +349,23 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd(const float *__restrict__ 
     }
 }
 
+// one workgroup per column (column c = the slope term): threads stride over the row blocks, then a fixed LDS tree
 __global__ __launch_bounds__(256) void k_epilogue_bwd_reduce(const float *__restrict__ partial, int64_t blocks, int c,
                                                              float *__restrict__ dbias, float *__restrict__ dslope) {
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc > c) return;
+    __shared__ float s[256];
+    const int cc = blockIdx.x;
     float t = 0.0f;
-    for (int64_t b = 0; b < blocks; ++b) t += partial[b * (c + 1) + cc];
-    if (cc < c) { if (dbias) dbias[cc] = t; }
-    else if (dslope) dslope[0] = t;
+    for (int64_t b = threadIdx.x; b < blocks; b += 256) t += partial[b * (c + 1) + cc];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (cc < c) { if (dbias) dbias[cc] = s[0]; }
+        else if (dslope) dslope[0] = s[0];
+    }
 }
 }  // namespace
 }  // namespace fpcc
@@ -386,7 +395,7 @@ extern "C" int fpcc_epilogue_bwd_f32(const float *y, int ldy, const float *dy, i
     hipLaunchKernelGGL(k_epilogue_bwd, dim3((unsigned)blocks), dim3(256), 0, s, y, ldy, dy, lddy, n, c, cpad, act, slope, g, ldg,
                        static_cast<float *>(ws));
     if (int rc = check_hip(hipGetLastError(), "k_epilogue_bwd")) return rc;
-    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3(blocks_for(c + 1, 256)), dim3(256), 0, s, static_cast<const float *>(ws), blocks, c,
+    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3(c + 1), dim3(256), 0, s, static_cast<const float *>(ws), blocks, c,
                        dbias, dslope);
     return check_hip(hipGetLastError(), "k_epilogue_bwd_reduce");
 }
