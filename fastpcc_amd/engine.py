@@ -14,6 +14,7 @@ Modules hold ordinary nn.Parameters (state_dict keys equal the reference's).  Wi
 run through fastpcc_amd/autograd.py (same kernels; bias / activation as differentiable tensor ops); under
 torch.no_grad() they take the fused inference path.
 """
+import functools
 import math
 import os
 from enum import Enum
@@ -444,9 +445,14 @@ def _act_of(module: Optional[nn.Module]) -> _Act:
     if module is None:
         return _Act()
     if isinstance(module, MinkowskiPReLU):
-        if module.module.weight.numel() != 1:
-            raise NotImplementedError('per-channel PReLU')
-        return _Act(ops.ACT_PRELU, module.module.weight.detach(), module.module.weight)
+        w = module.module.weight
+        cached = module.__dict__.get('_fpcc_act')
+        if cached is None or cached[0] != w.data_ptr():      # the detached view shares storage: in-place updates show through
+            if w.numel() != 1:
+                raise NotImplementedError('per-channel PReLU')
+            cached = (w.data_ptr(), _Act(ops.ACT_PRELU, w.detach(), w))
+            module.__dict__['_fpcc_act'] = cached
+        return cached[1]
     if isinstance(module, MinkowskiReLU):
         return _Act(ops.ACT_RELU)
     raise NotImplementedError(f'cannot fuse {type(module).__name__}')
@@ -462,6 +468,7 @@ def _split_k3_ok(c_in: int, c2: int, c_out: int) -> bool:
     return c_out == 1 and c2 == 0 and c_in % 16 == 0
 
 
+@functools.lru_cache(maxsize=4096)
 def _pad_plan(c1: int, c2: int, c_out: int, n_out: int):
     """Shapes the MFMA kernel does not take as they are (C_in not a multiple of 16, C_out not 32/64/128) but that are big
     enough to matter are zero-padded to the next MFMA shape: -> (c1p, c2p, c_outp) or None.  Zero channels add exact
@@ -525,7 +532,7 @@ class _ConvBase(nn.Module):
         if self._packed_tag != tag:
             k = self.kernel.detach()
             b = None if self.bias is None else self.bias.detach().view(-1)
-            d = {}
+            d = {'w': k, 'b': b}
             if self.GENERATIVE and _packed_gen_ok(self.in_channels, self.out_channels):
                 w_all = k.permute(1, 0, 2).reshape(self.in_channels, 8 * self.out_channels).contiguous()
                 d['gen_w'] = [w_all] if w_all.shape[1] <= 128 else [w_all[:, :128].contiguous(), w_all[:, 128:].contiguous()]
@@ -618,9 +625,9 @@ class _ConvBase(nn.Module):
         parts = x.parts
         x1 = parts[0]
         x2 = parts[1] if len(parts) > 1 else None
-        kw = dict(x2=x2, bias=None if self.bias is None else self.bias.detach().view(-1), act=act.kind, slope=act.slope,
-                  clip=clip)
-        w = self.kernel.detach()
+        derived = self._derived()
+        kw = dict(x2=x2, bias=derived['b'], act=act.kind, slope=act.slope, clip=clip)
+        w = derived['w']
         c_out = self.out_channels
         if self.GENERATIVE:
             dst = cm._generated(src)

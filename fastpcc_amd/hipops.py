@@ -5,6 +5,7 @@ passes raw pointers plus the current HIP stream, and raises on a non-zero status
 there is no alternative implementation: without the library or a GPU these functions raise.
 """
 import ctypes as C
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -364,6 +365,7 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
     return sort_keys(keys, 32 + max(1, (n >> window_log2).bit_length()))[1]
 
 
+@functools.lru_cache(maxsize=8192)
 def conv_order(c1: int, c2: int, c_out: int, n_offsets: int = 1, groups: int = 1, n_out: int = 0) -> int:
     return lib().fpcc_conv_f32_order_ex(c1, c2, c_out, n_offsets, groups, n_out)
 
