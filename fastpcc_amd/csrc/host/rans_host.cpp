@@ -196,9 +196,11 @@ int64_t binary_encode(const uint8_t *bits, const uint16_t *p1, int64_t n, uint8_
     for (int64_t i = n - 1; i >= 0; --i) {
         const uint32_t p = p1[i];
         if (p == 0) return FPCC_HOST_E_ARG;
-        // ones sit at the top of the interval: [65536 - p, 65536); zeros at [0, 65536 - p)
-        if (bits[i]) w.put<kProbBits>(kProbOne - p, p);
-        else w.put<kProbBits>(0u, kProbOne - p);
+        // ones sit at the top of the interval: [65536 - p, 65536); zeros at [0, 65536 - p).  Selects, not a branch: the
+        // symbol is a coin flip for the branch predictor wherever the model is unsure
+        const uint32_t mask = 0u - uint32_t(bits[i] != 0);
+        const uint32_t split = kProbOne - p;
+        w.put<kProbBits>(split & mask, (p & mask) | (split & ~mask));
     }
     return w.finish();
 }
@@ -293,12 +295,25 @@ int64_t fpcc_rans_binary_encode(const uint8_t *bits, const uint16_t *prob1, int6
 int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
                                 uint8_t *bits_out) {
     if (!stream || !prob1 || !bits_out || n < 0 || stream_len < 4) return FPCC_HOST_E_ARG;
-    FrontReader r(stream, stream_len);
+    // The symbol decision is data dependent (a coin flip for the branch predictor wherever the model is unsure), so it
+    // is computed with selects; only the byte refill -- rare and regular -- stays a branch.
+    const uint8_t *p = stream + 4, *end = stream + stream_len;
+    uint32_t x = uint32_t(stream[0]) | uint32_t(stream[1]) << 8 | uint32_t(stream[2]) << 16 | uint32_t(stream[3]) << 24;
     for (int64_t i = 0; i < n; ++i) {
-        const uint32_t p = prob1[i];
-        const uint32_t split = kProbOne - p;
-        if (r.peek<kProbBits>() < split) { bits_out[i] = 0; r.take<kProbBits>(0u, split); }
-        else { bits_out[i] = 1; r.take<kProbBits>(split, p); }
+        const uint32_t p1 = prob1[i];
+        const uint32_t split = kProbOne - p1;
+        const uint32_t slot = x & (kProbOne - 1u);
+        const uint32_t one = slot >= split;                       // 0 / 1
+        const uint32_t mask = 0u - one;                           // 0 / ~0
+        const uint32_t freq = (p1 & mask) | (split & ~mask);
+        const uint32_t start = split & mask;
+        x = freq * (x >> kProbBits) + slot - start;
+        bits_out[i] = static_cast<uint8_t>(one);
+        while (x < kLow) {
+            const uint32_t b = p < end ? *p : 0u;                 // past the end: zeros (garbage out, never out of bounds)
+            ++p;
+            x = (x << 8) | b;
+        }
     }
     return FPCC_HOST_OK;
 }
