@@ -14,6 +14,7 @@ Sources of truth used:
   entropy_model.json  NoisyDeepFactorizedEntropyModel of /root/reference/lib/entropy_models/continuous_batched.py
                  (imported with lib.entropy_models.rans_coder -> oracle/_ref coder and the MinkowskiEngine wrapper
                  stubbed): seeded parameters, log_prob / prob, quantised CDF tables, compress strings
+  kdtree.json    partition sizes / checksums of lib/data_utils.py:168-234 kd_tree_partition on seeded coordinates
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -264,8 +265,23 @@ def make_entropy_model():
     return out
 
 
+def make_kdtree():
+    # lib/data_utils.py imports plyfile / open3d at module level; neither is used by kd_tree_partition
+    sys.modules.setdefault('plyfile', types.SimpleNamespace(PlyData=None, PlyElement=None))
+    du = _load(os.path.join(REF, 'lib/data_utils.py'), 'ref_data_utils')
+    out = []
+    for seed, n, rng_max, max_num in ((1, 5000, 1000, 700), (2, 4097, 64, 1000), (3, 300, 1 << 16, 1000), (4, 20000, 1024, 2600),
+                                      (5, 9, 4, 2)):
+        rng = np.random.default_rng(seed)
+        coord = rng.integers(0, rng_max, (n, 3)).astype(np.int32)
+        parts = du.kd_tree_partition(coord, max_num)[0]
+        out.append({'seed': seed, 'n': n, 'range': rng_max, 'max_num': max_num, 'sizes': [len(p) for p in parts],
+                    'sha': [hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest()[:16] for p in parts]})
+    return out
+
+
 def main():
-    for name, fn in (('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         data = fn()
         path = os.path.join(HERE, name + '.json')
         with open(path, 'w') as f:
