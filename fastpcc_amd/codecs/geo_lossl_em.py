@@ -337,7 +337,8 @@ class GeoLosslessEntropyModel(nn.Module):
                     tm['dec_wait'] += tb - ta
                     tm['dec_host'] += time.perf_counter() - tb
                 gen_id = logits.coordinate_map_key.get_key()[1]
-                cur_map = cm._refine(cur_map, mask, gen_id + 'pruned')
+                # the decoded mask is on the host: its popcount sizes the new map without a device read-back
+                cur_map = cm._refine(cur_map, mask, gen_id + 'pruned', count_hint=int(np.count_nonzero(bits_t.numpy())))
                 del logits
             target_key = cur_map.key
             fea_pred = self.hyper_decoder_fea[idx](lower, target_key)

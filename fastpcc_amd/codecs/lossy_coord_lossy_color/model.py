@@ -60,8 +60,10 @@ class PCC(nn.Module):
     def get_sparse_pc(self, xyz: torch.Tensor, color: torch.Tensor) -> ME.SparseTensor:
         cm = self.set_global_cm()
         feats = torch.cat((color.to(torch.float32) / 255, torch.full((color.shape[0], 1), 2.0, device=color.device)), 1)
-        return ME.SparseTensor(features=feats, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
-                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+        pc = ME.SparseTensor(features=feats, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
+                             quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+        cm.build_pyramid(pc.coordinate_map_key, len(self.cfg.encoder_channels) - 1 + sum(self.cfg.geo_lossl_if_sample))
+        return pc
 
     @torch.no_grad()
     def compress(self, batched_coord: torch.Tensor, batched_color: torch.Tensor) -> bytes:

@@ -75,8 +75,11 @@ class PCC(nn.Module):
         reference obtains by sorting explicitly before building the tensor (model.py:140-142)."""
         cm = self.set_global_cm()
         ones = torch.ones((xyz.shape[0], 1), dtype=torch.float32, device=xyz.device)
-        return ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
-                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+        pc = ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
+                             quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+        # all coarser maps the encoder + lossless pyramid will ask for, built while the stream is still empty
+        cm.build_pyramid(pc.coordinate_map_key, len(self.cfg.encoder_channels) - 1 + sum(self.cfg.geo_lossl_if_sample))
+        return pc
 
     def train_forward(self, batched_coord: torch.Tensor, training_step: int, batch_size: int) -> dict:
         """rate + distortion objective of one batch (model.py:156-191): returns {'loss': tensor with the autograd graph,

@@ -218,6 +218,16 @@ class CoordinateManager:
             self._register(p, '')
         return m.parent
 
+    def build_pyramid(self, key: CoordinateMapKey, levels: int) -> None:
+        """Create the `levels` next coarser maps of `key` now.  Every coarsening reads its row count back (a blocking
+        device->host transfer); done up front, while the stream is nearly empty, those round trips cost ~0.1 ms each --
+        in the middle of a long enqueue they would stop the host from running ahead of the GPU."""
+        m = self._map(key)
+        for _ in range(levels):
+            if m.bits <= 1:
+                break
+            m = self._ensure_parent(m)
+
     def stride(self, key: CoordinateMapKey, stride) -> CoordinateMapKey:
         """Key of the map `stride` times coarser (ME: cm.stride)."""
         s = _as_stride(stride)[0]
@@ -238,10 +248,11 @@ class CoordinateManager:
             self._register(g, 'gen')
         return m.gen_child
 
-    def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str) -> _Map:
-        """New map = children of `parent` selected by mask[8 * parent.n] (decoder side / pruning of a generated set)."""
+    def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str, count_hint: Optional[int] = None) -> _Map:
+        """New map = children of `parent` selected by mask[8 * parent.n] (decoder side / pruning of a generated set).
+        count_hint: number of set mask entries when the caller already knows it on the host (saves a blocking read-back)."""
         keys, parent_of, child_row, count = ops.refine(parent.keys, mask)
-        n = int(count.item())
+        n = int(count.item()) if count_hint is None else int(count_hint)
         t = _Map(parent.level - 1, parent.bits + 1, n, keys[:n])
         t.parent, t.parent_of, t.child_row = parent, parent_of[:n], child_row
         self._register(t, string_id)
