@@ -37,7 +37,8 @@ def build_host(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, 'host', '*.cpp')))
     deps = srcs + glob.glob(os.path.join(PKG, '..', 'include', '*.h'))
     if force or _stale(HOST_LIB, deps):
-        out = _run(['g++', '-O3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wextra',
+        # x86-64-v3 (AVX2): the symbol searches of the coders are short fixed-length compare loops
+        out = _run(['g++', '-O3', '-march=x86-64-v3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wextra',
                     '-o', HOST_LIB] + srcs)
         if verbose:
             print(out)
