@@ -137,7 +137,7 @@ def main():
         data, rec = step()
     # the decoder keeps the candidates above the (8M - N)-th smallest logit; logits that tie with that threshold are
     # dropped, exactly as in the reference (lossy_coord_v2/layers.py:164-180), so the count can fall short by the ties
-    assert n_points - 16 <= rec.shape[0] <= n_points, (rec.shape[0], n_points)
+    assert n_points - max(16, n_points // 1000) <= rec.shape[0] <= n_points, (rec.shape[0], n_points)
 
     def barrier():
         replicas.barrier(device)

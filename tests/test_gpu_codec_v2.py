@@ -243,3 +243,27 @@ def test_entropy_model_takes_sparse_tensors(setup):
     assert a.F.shape[1] == 2 and b.F.shape[1] == 4 and torch.equal(torch.cat((a.F, b.F), 1), wide.F)
     doubled = minkowski_tensor_wrapped_op(wide, lambda t: t * 2)
     assert isinstance(doubled, ME.SparseTensor) and torch.equal(doubled.F, wide.F * 2)
+
+
+def test_edge_inputs(setup):
+    """one voxel; duplicated input points (the engine de-duplicates like ME.SparseTensor with UNWEIGHTED_AVERAGE, so the
+    stream equals that of the unique cloud); the largest codable offset; an offset that does not fit the 16-bit header"""
+    cfg, model, weights, ops = setup
+    one = torch.tensor([[0, 5, 6, 7]], dtype=torch.int32).cuda()
+    rec = model.decompress(model.compress(one))
+    assert rec.shape == (1, 3)
+    xyz, coords = _cloud(9, 64, 5000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    dup = torch.cat((dev, dev[::3], dev[:100]))
+    assert model.compress(dup[torch.randperm(dup.shape[0], device='cuda')]) == model.compress(dev)
+    far = dev.clone()
+    far[:, 1:] += torch.tensor([65535 - int(dev[:, 1].min()), 100, 7], dtype=torch.int32, device='cuda')
+    data = model.compress(far)
+    assert int.from_bytes(data[0:2], 'little') == 65535
+    back = model.decompress(data)
+    assert int(back[:, 0].min()) >= 65535 and back.shape[0] == len(xyz)
+    far[:, 1] += 1
+    with pytest.raises(OverflowError):
+        model.compress(far)
+    with pytest.raises(RuntimeError):
+        model.compress(dev.cpu())                                    # no CPU path
