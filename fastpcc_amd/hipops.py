@@ -36,6 +36,8 @@ _SIGS = {
                                    _vp, _i64, _vp]),
     'fpcc_epilogue_bwd_ws_bytes': (_i64, [_i64, _i32]),
     'fpcc_epilogue_bwd_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_deep_factorized_ws_bytes': (_i64, [_i64, _i32]),
+    'fpcc_deep_factorized_bits_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
@@ -354,6 +356,28 @@ def epilogue_bwd(y: torch.Tensor, dy: torch.Tensor, act: int, slope: Optional[to
                                 None if dbias is None else dbias.data_ptr(), None if dslope is None else dslope.data_ptr(),
                                 ws.data_ptr(), need, _stream()))
     return g, dbias, dslope
+
+
+def deep_factorized_bits(y: torch.Tensor, weights, biases, factors, half_width: float, want_dy: bool = True):
+    """y [n, c] fp32; parameters as stored by NoisyDeepFactorizedEntropyModel (filters 1-3-3-3-3-1).
+    -> (out [c, 59]: parameter gradients of sum(logp) then sum(logp), dy [n, c] | None)"""
+    py, c, ldy = _rows2d(y, 'y')
+    n = y.shape[0]
+    if len(weights) != 5 or len(biases) != 5 or len(factors) != 4:
+        raise ValueError('the kernel is built for num_filters (1, 3, 3, 3, 3, 1)')
+    shapes = [(c, 3, 1), (c, 3, 3), (c, 3, 3), (c, 3, 3), (c, 1, 3)]
+    for t, sh in zip(weights, shapes):
+        if tuple(t.shape) != sh:
+            raise ValueError(f'weight of shape {tuple(t.shape)}, expected {sh}')
+    ptr = lambda ts: (C.c_void_p * len(ts))(*[_dev(t.detach(), torch.float32, 'parameter') for t in ts])
+    out = torch.empty((c, 59), dtype=torch.float32, device=y.device)
+    dy = torch.empty((n, c), dtype=torch.float32, device=y.device) if want_dy else None
+    L = lib()
+    need = _ok(L.fpcc_deep_factorized_ws_bytes(n, c))
+    ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=y.device)
+    _ok(L.fpcc_deep_factorized_bits_f32(py, n, c, ldy, ptr(weights), ptr(biases), ptr(factors), float(half_width),
+                                        None if dy is None else dy.data_ptr(), c, out.data_ptr(), ws.data_ptr(), need, _stream()))
+    return out, dy
 
 
 def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13) -> torch.Tensor:

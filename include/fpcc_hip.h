@@ -216,6 +216,19 @@ int64_t fpcc_compact_coords(const int64_t *pkeys, int64_t m, const uint8_t *mask
 int64_t fpcc_topk_keep_cells(const float *logit, int64_t m, const int32_t *cell_of_group, int64_t n_cells, int64_t target,
                              uint8_t *keep_out, void *ws, int64_t ws_bytes, void *stream);
 
+/* Rate term of the noisy deep-factorised bottleneck (training): for y [n][c] (row stride ldy) and the per-channel parameters of a
+ * 1-3-3-3-3-1 logit network -- weights[i] [c][f_out][f_in], biases[i] [c][f_out], factors[i] [c][f_out], raw as stored
+ * (softplus / tanh applied inside) --
+ *     logp = log(cdf(y + half_width) - cdf(y - half_width))       (survival functions right of the median)
+ * out [c][59]: per channel the gradients of sum(logp) w.r.t. the 33 weights, 13 biases, 12 factors (layer by layer, row-major)
+ * and, last, sum(logp) itself;  dy (may be NULL) [n][c]: d sum(logp) / dy.  One kernel instead of the ~60 tensor ops (and
+ * their autograd twins) of lib/entropy_models/distributions/deep_factorized.py:24-40 + uniform_noise.py:30-63 behind the
+ * bits loss of continuous_batched.py:62-69.  ws: fpcc_deep_factorized_ws_bytes() bytes; reduction order fixed. */
+int64_t fpcc_deep_factorized_ws_bytes(int64_t n, int c);
+int fpcc_deep_factorized_bits_f32(const float *y, int64_t n, int c, int ldy, const float *const *weights,
+                                  const float *const *biases, const float *const *factors, float half_width,
+                                  float *dy, int lddy, float *out, void *ws, int64_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Geometry distortion (D1, point-to-point)                                                                       */
 /* ------------------------------------------------------------------------------------------------------------ */
