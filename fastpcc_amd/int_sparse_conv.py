@@ -389,6 +389,16 @@ class SparseResBlockIn32W8Out32(nn.Module):
         self.conv2 = SparseConvIn8W8Out32(ch, ch, (3, 3, 3), (1, 1, 1))
         self.prelu = PReLUIn32Out32()
 
+    @torch.no_grad()
+    def import_parameters(self, block):
+        """block: calibrated float residual block (obs, conv, act, obs2, conv2, act2), cuda_ops.py:65-77"""
+        scale, zero_point = block.obs.calculate_qparams()
+        scale2, zero_point2 = block.obs2.calculate_qparams()
+        self.input_requant.import_parameters(scale, zero_point)
+        self.conv_prelu.import_parameters(scale, zero_point, scale2, zero_point2, block.conv, block.act)    # int8 -> int8
+        self.conv2.import_parameters(scale2, zero_point2, block.conv2)                                      # int8 -> Q8.23
+        self.prelu.import_parameters(block.act2)
+
     def forward(self, input: SparseTensor) -> SparseTensor:
         x = SparseTensor(self.input_requant(input.F), input.C, input.stride, input.spatial_range)
         x._caches = input._caches

@@ -280,8 +280,76 @@ def make_kdtree():
     return out
 
 
+def make_ptq_import():
+    """float -> fixed-point parameter conversion of the integer operators (lib/int_sparse_conv/cuda_ops.py:65-77 residual
+    block, :223-301 sparse conv, :473-509 requantiser, :542-607 linear).  The module imports torchsparse (absent here) only
+    for type names; the conversions are plain tensor arithmetic and run on the CPU."""
+    import torch
+    import torch.nn as nn
+    ts = types.ModuleType('torchsparse'); ts_nn = types.ModuleType('torchsparse.nn')
+    ts.SparseTensor = type('SparseTensor', (), {}); ts_nn.Conv3d = type('Conv3d', (), {}); ts.nn = ts_nn
+    sys.modules.setdefault('torchsparse', ts); sys.modules.setdefault('torchsparse.nn', ts_nn)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    co = _load(os.path.join(REF, 'lib/int_sparse_conv/cuda_ops.py'), 'ref_int_cuda_ops')
+    tl = lambda t: t.detach().to(torch.float64 if t.dtype.is_floating_point else torch.int64).flatten().tolist()
+    dump = lambda m: {k: tl(v) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    rnd = lambda *shape, s=1.0: (torch.rand(shape, generator=g) * 2 - 1) * s
+    f32 = lambda v: torch.tensor([v], dtype=torch.float32)
+    i64 = lambda v: torch.tensor([v], dtype=torch.int64)
+    out = {'conv': [], 'linear': [], 'requant': [], 'prelu': [], 'resblock': []}
+    for (cin, cout, ks, prelu, out8, s_in, zp_in, s_out, zp_out) in (
+            (5, 7, (3, 3, 3), True, True, 0.031, 0, 0.017, 0), (5, 7, (3, 3, 3), False, False, 0.2, 0, None, None),
+            (8, 3, (2, 2, 2), True, False, 0.004, 0, None, None), (1, 6, (3, 3, 3), False, False, 1.0, 0, None, None),
+            (4, 4, (3, 3, 3), False, True, 0.011, 9, 0.05, -13), (3, 9, (2, 2, 2), True, True, 0.07, -3, 0.002, 5)):
+        conv = types.SimpleNamespace(kernel=rnd(ks[0] * ks[1] * ks[2], cin, cout, s=0.4), bias=rnd(cout, s=0.3), kernel_size=ks,
+                                     stride=(1, 1, 1) if ks[0] == 3 else (2, 2, 2))
+        act = types.SimpleNamespace(weight=torch.tensor([0.21])) if prelu else None
+        m = co.SparseConvIn8Out8(cin, cout, ks, conv.stride, prelu, out8)
+        m.import_parameters(f32(s_in), i64(zp_in), f32(s_out) if out8 else None, i64(zp_out) if out8 else None, conv, act)
+        out['conv'].append({'cin': cin, 'cout': cout, 'ks': list(ks), 'stride': list(conv.stride), 'prelu': prelu, 'out8': out8,
+                            's_in': s_in, 'zp_in': zp_in, 's_out': s_out, 'zp_out': zp_out, 'kernel': tl(conv.kernel), 'bias': tl(conv.bias),
+                            'slope': 0.21 if prelu else None, 'state': dump(m)})
+    for (cin, cout, prelu, out8, s_in, zp_in, s_out, zp_out) in (
+            (6, 9, True, True, 0.02, 17, 0.013, 0), (12, 5, False, False, 0.3, -40, None, None), (3, 255, False, False, 0.009, 0, None, None),
+            (9, 8, True, False, 0.05, 3, None, None), (4, 4, False, True, 0.6, -1, 0.4, 11)):
+        lin = nn.Linear(cin, cout)
+        with torch.no_grad():
+            lin.weight.copy_(rnd(cout, cin, s=0.7)); lin.bias.copy_(rnd(cout, s=0.5))
+        act = types.SimpleNamespace(weight=torch.tensor([0.4])) if prelu else None
+        m = co.LinearIn8W8(cin, cout, prelu, out8)
+        m.import_parameters(f32(s_in), i64(zp_in), f32(s_out) if out8 else None, i64(zp_out) if out8 else None, lin, act)
+        out['linear'].append({'cin': cin, 'cout': cout, 'prelu': prelu, 'out8': out8, 's_in': s_in, 'zp_in': zp_in, 's_out': s_out,
+                              'zp_out': zp_out, 'weight': tl(lin.weight), 'bias': tl(lin.bias), 'slope': 0.4 if prelu else None,
+                              'state': dump(m)})
+    for s_out, zp_out in ((0.031, 0), (0.5, 0), (0.0007, -12), (3.0, 100), (1e-9, 0)):
+        m = co.RequantFxpToScaledInt8()
+        m.import_parameters(f32(s_out), i64(zp_out))
+        out['requant'].append({'s_out': s_out, 'zp_out': zp_out, 'state': dump(m)})
+    for slope in (0.25, -0.1, 1.0, 3.3333, 1e-4):
+        m = co.PReLUIn32Out32()
+        m.import_parameters(types.SimpleNamespace(weight=torch.tensor([slope])))
+        out['prelu'].append({'slope': slope, 'state': dump(m)})
+    ch = 6
+    blk = types.SimpleNamespace(
+        obs=types.SimpleNamespace(calculate_qparams=lambda: (f32(0.023), i64(0))),
+        obs2=types.SimpleNamespace(calculate_qparams=lambda: (f32(0.041), i64(0))),
+        conv=types.SimpleNamespace(kernel=rnd(27, ch, ch, s=0.3), bias=rnd(ch, s=0.2), kernel_size=(3, 3, 3), stride=(1, 1, 1)),
+        act=types.SimpleNamespace(weight=torch.tensor([0.15])),
+        conv2=types.SimpleNamespace(kernel=rnd(27, ch, ch, s=0.3), bias=rnd(ch, s=0.2), kernel_size=(3, 3, 3), stride=(1, 1, 1)),
+        act2=types.SimpleNamespace(weight=torch.tensor([0.3])))
+    m = co.SparseResBlockIn32W8Out32(ch)
+    m.import_parameters(blk)
+    out['resblock'].append({'ch': ch, 'scale': 0.023, 'scale2': 0.041, 'kernel': tl(blk.conv.kernel), 'bias': tl(blk.conv.bias),
+                            'kernel2': tl(blk.conv2.kernel), 'bias2': tl(blk.conv2.bias), 'slope': 0.15, 'slope2': 0.3, 'state': dump(m)})
+    return out
+
+
 def main():
-    for name, fn in (('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         data = fn()
         path = os.path.join(HERE, name + '.json')
         with open(path, 'w') as f:
