@@ -79,6 +79,11 @@ class OneScalePredictor(nn.Module):
             RequantFxpToScaledInt8(), LinearIn8W8Out32(channels, channels * 8)) if if_upsample else None
         self.register_buffer('_shared_fxp_shift', torch.tensor(SharedFxpShift, dtype=torch.int32), persistent=False)
 
+    @staticmethod
+    def _feat(bits: torch.Tensor) -> torch.Tensor:
+        """occupancy bits as activations: 1.0 in the shared Q8.23 format (the float twin overrides this)"""
+        return bits.to(torch.int32) << SharedFxpShift
+
     def _trunk(self, cur_rec: SparseTensor):
         if cur_rec.F.shape[1] == 1:
             cur_rec = self.dec_init(cur_rec)
@@ -86,7 +91,7 @@ class OneScalePredictor(nn.Module):
         return cur_rec, self.pred(cur_rec).F
 
     def _expand(self, cur_rec: SparseTensor, bits: torch.Tensor, child_coords: torch.Tensor) -> SparseTensor:
-        cur_rec.F = torch.cat((cur_rec.F, bits.to(torch.int32) << SharedFxpShift), 1)
+        cur_rec.F = torch.cat((cur_rec.F, self._feat(bits)), 1)
         up = self.upsample(cur_rec)
         feats = up.F.reshape(up.F.shape[0], 8, up.F.shape[1] // 8)[bits.bool()]
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in up.stride))
@@ -151,6 +156,8 @@ class OneScaleMultiStepPredictor(nn.Module):
                                                   LinearIn8W8Out32(channels, 255)))
         self.register_buffer('_shared_fxp_shift', torch.tensor(SharedFxpShift, dtype=torch.int32), persistent=False)
 
+    _feat = staticmethod(OneScalePredictor._feat)
+
     def _refresh(self, cur_rec: SparseTensor, embed_in: SparseTensor) -> SparseTensor:
         embed_in._caches = cur_rec._caches
         cur_rec.F = torch.cat([cur_rec.F, self.embed(embed_in).F], 1)
@@ -166,13 +173,13 @@ class OneScaleMultiStepPredictor(nn.Module):
             f = cur_pred.F
             f = f.reshape(f.shape[0], 8, f.shape[1] // 8)[masks[i - 1]]
             if i != last:
-                f = torch.cat([f, bits_below[i - 1].to(torch.int32) << SharedFxpShift], 1)
+                f = torch.cat([f, self._feat(bits_below[i - 1])], 1)
             cur_pred.F, cur_pred.C, cur_pred.stride = f, coords[i - 1], strides[i - 1]
             cur_pred = self.pred[i](cur_pred)
         return cur_pred.F
 
     def compress(self, cur_rec: SparseTensor, cur_bins: List[SparseTensor], bin2oct_kernel):
-        embed_in = SparseTensor(cur_bins[1].F << SharedFxpShift, cur_bins[1].C, stride=cur_bins[1].stride)
+        embed_in = SparseTensor(self._feat(cur_bins[1].F), cur_bins[1].C, stride=cur_bins[1].stride)
         cur_rec = self._refresh(cur_rec, embed_in)
         n = len(self.pred)
         masks = [cur_bins[-i].F.bool() for i in range(1, n)]
@@ -190,7 +197,7 @@ class OneScaleMultiStepPredictor(nn.Module):
         top_stride //= 2
         caches = cur_rec._caches
         caches.cmaps[(top_stride,) * 3] = (top_rec, None)
-        embed_in = SparseTensor(cur_bins[-1].to(torch.int32) << SharedFxpShift, caches.cmaps[(top_stride * 2,) * 3][0],
+        embed_in = SparseTensor(self._feat(cur_bins[-1]), caches.cmaps[(top_stride * 2,) * 3][0],
                                 stride=(top_stride * 2,) * 3)
         cur_rec = self._refresh(cur_rec, embed_in)
         n = len(self.pred)
@@ -207,6 +214,8 @@ class OneScaleMultiStepPredictor(nn.Module):
 
 
 class Model(nn.Module):
+    one_scale_cls, multi_step_cls = OneScalePredictor, OneScaleMultiStepPredictor
+
     def __init__(self, cfg: Config, device='cuda'):
         super().__init__()
         self.cfg, self.device = cfg, device
@@ -218,12 +227,12 @@ class Model(nn.Module):
         for idx in range(self.max_downsample_times_wo_recurrent):
             steps = int(np.log2(cfg.fea_stride)) - idx
             if steps < 1:
-                self.blocks_dec.append(OneScalePredictor(cfg.channels, True, False))
+                self.blocks_dec.append(self.one_scale_cls(cfg.channels, True, False))
             elif steps == 1:
-                self.blocks_dec.append(OneScalePredictor(cfg.channels, False, False))
+                self.blocks_dec.append(self.one_scale_cls(cfg.channels, False, False))
             else:
-                self.blocks_dec.append(OneScaleMultiStepPredictor(cfg.channels, steps, cfg.use_more_ch_for_multi_step_pred))
-        self.block_dec_recurrent = OneScalePredictor(cfg.channels, True, True)
+                self.blocks_dec.append(self.multi_step_cls(cfg.channels, steps, cfg.use_more_ch_for_multi_step_pred))
+        self.block_dec_recurrent = self.one_scale_cls(cfg.channels, True, True)
         fold = torch.zeros(8, 8, 1, dtype=torch.int8)
         fold.reshape(8, 8)[...] = torch.eye(8, dtype=torch.int8)
         self.register_buffer('fold2bin_kernel', fold, persistent=False)

@@ -14,11 +14,15 @@ from ._native import host, host_check
 
 class CoderPool:
     def __init__(self, n_threads: int = 4):
-        self._h = host().fpcc_pool_new(int(n_threads))
+        self._n = int(n_threads)
+        self._h = host().fpcc_pool_new(self._n)
         if not self._h:
             raise RuntimeError('libfpcc_host: cannot create the coder pool')
         self._keep: List = []
         self._binary: List[Tuple[np.ndarray, np.ndarray]] = []
+
+    def __deepcopy__(self, memo):                 # native threads are not copyable: a copy owns a fresh pool
+        return CoderPool(self._n)
 
     def close(self):
         if self._h:

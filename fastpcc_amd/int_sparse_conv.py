@@ -11,8 +11,10 @@ Execution differs from the reference, results do not (exact integer arithmetic):
     (cuda_ops.py:132-151) does not exist -- the convolution is output-stationary and reads the table directly;
   * convolution / linear, bias, PReLU and requantisation are ONE launch (fpcc_conv_i8) instead of up to 27 CUTLASS
     launches plus an epilogue kernel;
-  * the float PTQ twin (observers, torchsparse Conv3d) is not part of this path; `import_parameters` takes the float
-    tensors (kernel [K, C_in, C_out], bias, PReLU weight) and applies the reference's conversion formulas.
+  * the float side of post-training quantisation lives here too: `Conv3d` (the float sparse convolution with
+    torchsparse.nn.Conv3d's parameter names and layout, evaluated by fpcc_conv_f32 over the SAME lookup table as its
+    integer counterpart), `make_obs` / `SparseTensorHistogramObserver` / `SparseResBlockWithObs` (cuda_ops.py:20-59);
+    `import_parameters` applies the reference's conversion formulas (pinned by tests/golden/ptq_import.json).
 """
 import math
 from types import SimpleNamespace
@@ -20,6 +22,8 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
+
+from torch.ao.quantization import HistogramObserver
 
 from . import hipops as ops
 
@@ -108,6 +112,123 @@ def sparse_conv_in8w8out32(in_feats: torch.Tensor, weight: torch.Tensor, in_coor
     return out, hashmap_kv, in_out_maps
 
 
+def _conv_on_sparse_tensor(input: 'SparseTensor', kernel_size, stride, run, unique=torch.unique) -> 'SparseTensor':
+    """cache handling shared by the integer and float convolutions (cuda_ops.py:325-366): output coordinates, hash table and
+    lookup table are taken from / stored in the cloud's caches; run(feats, in_coords, out_coords, maps, hashmap, same)
+    -> (out_feats, hashmap, maps)"""
+    caches = input._caches
+    tag = (input.stride, kernel_size, stride)
+    cur = caches.kmaps.get(tag)
+    in_out_maps = cur.get('in_out_maps') if cur is not None else None
+    hashmap_kv = caches.hashmaps.get(input.stride)
+    if stride == (1, 1, 1):
+        output_stride, output_coords, same = input.stride, input.C, True
+    else:
+        same = False
+        output_stride = tuple(a * b for a, b in zip(input.stride, stride))
+        if output_stride in caches.cmaps:
+            output_coords = caches.cmaps[output_stride][0]
+        elif stride[0] & (stride[0] - 1) == 0 and all(stride[0] == v for v in stride[1:]):
+            output_coords = input.C.clone()
+            output_coords[:, 1:] >>= (stride[0].bit_length() - 1)
+            output_coords = unique(output_coords, dim=0)
+        else:
+            raise NotImplementedError((input.stride, stride))
+    out_feats, hashmap_kv, in_out_maps = run(input.F, input.C, output_coords, in_out_maps, hashmap_kv, same)
+    caches.kmaps.setdefault(tag, {}).setdefault('in_out_maps', in_out_maps)
+    caches.hashmaps.setdefault(input.stride, hashmap_kv)
+    caches.cmaps.setdefault(input.stride, (input.C, input.spatial_range))
+    caches.cmaps.setdefault(output_stride, (output_coords, None))
+    ret = SparseTensor(out_feats, output_coords, output_stride, None)
+    ret._caches = caches
+    return ret
+
+
+# ---- float side of post-training quantisation (cuda_ops.py:20-59) ------------------------------------------------------
+class Conv3d(nn.Module):
+    """Float sparse convolution with torchsparse.nn.Conv3d's surface as the reference's float model uses it
+    (models/convolutional/lossl_coord/model.py:31-35,648-650): parameters `kernel` [K, C_in, C_out] ([C_in, C_out] for a
+    1x1x1 kernel) and `bias` [C_out]; attributes in_channels / out_channels / kernel_size / stride.  Offsets are ordered
+    like the integer operator's weight[k], so `import_parameters` is a plain permute (cuda_ops.py:257-260)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size=3, stride=1, padding=0, bias: bool = True):
+        super().__init__()
+        as3 = lambda v: (v,) * 3 if isinstance(v, int) else tuple(v)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = as3(kernel_size), as3(stride)
+        self.kernel_volume = math.prod(self.kernel_size)
+        shape = (self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1 else (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.zeros(shape))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        std = 1.0 / math.sqrt(in_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-std, std)
+            if bias:
+                self.bias.uniform_(-std, std)
+
+    def extra_repr(self):
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}'
+
+    def _run(self, in_feats, in_coords, out_coords, in_out_maps, hashmap_kv, same):
+        if in_out_maps is None:
+            hashmap_kv, in_out_maps = _kernel_table(in_coords, out_coords, self.kernel_size, self.stride, hashmap_kv)
+        nbr = in_out_maps - 1                      # (row + 1 | 0) -> (row | -1)
+        k, n_out = self.kernel_volume, out_coords.shape[0]
+        w = self.kernel.detach().reshape(k, self.in_channels, self.out_channels)
+        x = in_feats.float().contiguous()
+        bias = None if self.bias is None else self.bias.detach()
+        out = None
+        for a in range(0, k, 32):                  # fpcc_conv_f32 takes up to 32 offsets per launch (a 4x4x4 kernel has 64)
+            b = min(a + 32, k)
+            part = ops.conv_f32(x, w[a:b].reshape(1, b - a, self.in_channels, self.out_channels).contiguous(), self.out_channels,
+                                n_out, nbr=nbr if (a, b) == (0, k) else nbr[:, a:b].contiguous(), n_offsets=b - a, nbr_ks=1,
+                                nbr_os=b - a, bias=bias if a == 0 else None)
+            out = part if out is None else out.add_(part)
+        return out, hashmap_kv, in_out_maps
+
+    @torch.no_grad()
+    def forward(self, input: 'SparseTensor') -> 'SparseTensor':
+        return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self._run)
+
+
+class SparseTensorHistogramObserver(HistogramObserver):
+    """torch.ao's histogram observer fed with a sparse tensor's features (cuda_ops.py:20-33)"""
+
+    def forward(self, input):
+        super().forward(input.F if isinstance(input, SparseTensor) else input)
+        return input
+
+    def extra_repr(self):
+        return f'min_val={self.min_val}, max_val={self.max_val}, {self.qscheme}'
+
+
+def make_obs(qscheme=torch.per_tensor_symmetric):
+    return SparseTensorHistogramObserver(bins=2048, dtype=torch.qint8, quant_min=-ActRange, quant_max=ActRange, qscheme=qscheme)
+
+
+class SparseResBlockWithObs(nn.Module):
+    """float residual block with observers in front of both convolutions (cuda_ops.py:41-59)"""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.ch = ch
+        self.obs = make_obs(torch.per_tensor_symmetric)
+        self.conv = Conv3d(ch, ch, 3, 1, 1, bias=True)
+        self.act = nn.PReLU()
+        self.obs2 = make_obs(torch.per_tensor_symmetric)
+        self.conv2 = Conv3d(ch, ch, 3, 1, 1, bias=True)
+        self.act2 = nn.PReLU()
+
+    def forward(self, org: 'SparseTensor') -> 'SparseTensor':
+        org = self.obs(org)
+        x = self.conv(org)
+        x.F = self.act(x.F)
+        x = self.obs2(x)
+        x = self.conv2(x)
+        x.F = self.act2(x.F + org.F)
+        return x
+
+
 def softmax_int32(input: torch.Tensor) -> torch.Tensor:
     return ops.softmax_i32(input.contiguous())
 
@@ -179,10 +300,13 @@ class _RequantParams(LoadSaveUint32RequantMul):
     def _import_common(self, scale_in, zero_point_in, scale_out, zero_point_out, w_float_out_major, bias_float,
                        prelu_weight, fold_zero_point_into_bias: bool):
         """the conversion of cuda_ops.py:223-301 / 542-607; w_float_out_major: [.., C_out, C_in] with C_out at dim -2"""
-        eps = self.eps
+        eps, dev = self.eps, self.weight.device          # observers may have been moved to the host for the parameter search
+        scale_in, zero_point_in = scale_in.to(dev), zero_point_in.to(dev)
+        w_float_out_major, bias_float = w_float_out_major.to(dev), bias_float.to(dev)
         scale_in = scale_in.reshape(1).float().clip(min=eps)
         self.scale_in[:] = scale_in
         if self.out_scaled_int:
+            scale_out, zero_point_out = scale_out.to(dev), zero_point_out.to(dev)
             scale_out = scale_out.reshape(1).float().clip(min=eps)
             self.scale_out[:] = scale_out
         elif scale_out is not None:
@@ -203,7 +327,7 @@ class _RequantParams(LoadSaveUint32RequantMul):
         if self.with_prelu:
             if prelu_weight.numel() != 1:
                 raise ValueError('single-parameter PReLU expected')
-            self.slope[:] = (prelu_weight.reshape(1) * (1 << 25)).round().to(torch.int32)
+            self.slope[:] = (prelu_weight.to(dev).reshape(1) * (1 << 25)).round().to(torch.int32)
         requant = scale_in * scale_weight / scale_out if self.out_scaled_int else scale_in * scale_weight
         shift, mul = _shift_and_mul(requant, self.requant_mul_guard_bits)
         self.requant_shift[:] = shift
@@ -234,7 +358,7 @@ class SparseConvIn8Out8(_RequantParams):
     @torch.no_grad()
     def import_parameters(self, scale_in, zero_point_in, scale_out, zero_point_out, conv, prelu):
         """conv: object with .kernel [K, C_in, C_out] float and .bias; prelu: object with .weight or None"""
-        kernel = conv.kernel.detach().float()
+        kernel = conv.kernel.detach().float().reshape(self.kernel_volume, self.in_ch, self.out_ch)
         zp_in = self._import_common(scale_in, zero_point_in, scale_out, zero_point_out, kernel.permute(0, 2, 1),
                                     conv.bias.detach().float().reshape(-1), None if prelu is None else prelu.weight.detach().float(),
                                     fold_zero_point_into_bias=False)
@@ -261,33 +385,7 @@ class SparseConvIn8Out8(_RequantParams):
         return self.forward_with_coords(*args, **kwargs)
 
     def forward_with_sparse_tensor(self, input: SparseTensor) -> SparseTensor:
-        caches = input._caches
-        tag = (input.stride, self.kernel_size, self.stride)
-        cur = caches.kmaps.get(tag)
-        in_out_maps = cur.get('in_out_maps') if cur is not None else None
-        hashmap_kv = caches.hashmaps.get(input.stride)
-        if self.stride == (1, 1, 1):
-            output_stride, output_coords, same = input.stride, input.C, True
-        else:
-            same = False
-            output_stride = tuple(a * b for a, b in zip(input.stride, self.stride))
-            if output_stride in caches.cmaps:
-                output_coords = caches.cmaps[output_stride][0]
-            elif self.stride[0] & (self.stride[0] - 1) == 0 and all(self.stride[0] == s for s in self.stride[1:]):
-                output_coords = input.C.clone()
-                output_coords[:, 1:] >>= (self.stride[0].bit_length() - 1)
-                output_coords = self.unique(output_coords, dim=0)
-            else:
-                raise NotImplementedError((input.stride, self.stride))
-        out_feats, hashmap_kv, in_out_maps = self.forward_with_coords(input.F, input.C, output_coords, in_out_maps,
-                                                                      hashmap_kv, same)
-        caches.kmaps.setdefault(tag, {}).setdefault('in_out_maps', in_out_maps)
-        caches.hashmaps.setdefault(input.stride, hashmap_kv)
-        caches.cmaps.setdefault(input.stride, (input.C, input.spatial_range))
-        caches.cmaps.setdefault(output_stride, (output_coords, None))
-        ret = SparseTensor(out_feats, output_coords, output_stride, None)
-        ret._caches = caches
-        return ret
+        return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self.forward_with_coords, self.unique)
 
     def forward_with_coords(self, in_feats, in_coords, out_coords, in_out_maps=None, hashmap_kv=None,
                             if_in_coords_equals_out_coords: bool = False):
@@ -358,6 +456,7 @@ class RequantFxpToScaledInt8(LoadSaveUint32RequantMul):
 
     @torch.no_grad()
     def import_parameters(self, scale_out: torch.Tensor, zero_point_out: torch.Tensor):
+        scale_out, zero_point_out = scale_out.to(self.scale_out.device), zero_point_out.to(self.scale_out.device)
         scale_out = scale_out.reshape(1).float().clip(min=self.eps)
         self.scale_out[:] = scale_out
         shift = torch.log2((1 << (32 - self.requant_mul_guard_bits)) * scale_out).floor()

@@ -163,6 +163,11 @@ class RansEncoder:
         if h:
             host().fpcc_simple_enc_free(h)
 
+    def __deepcopy__(self, memo):                 # the native handle is not shareable: a copy gets its own (empty) coder
+        return RansEncoder(self._cap)
+
+    __copy__ = lambda self: self.__deepcopy__({})
+
     def encode(self, cdf_arr: np.ndarray, symbol_arr: np.ndarray) -> int:
         rows = np.ascontiguousarray(cdf_arr, dtype=np.uint16)
         sym = np.ascontiguousarray(symbol_arr, dtype=np.uint16)
@@ -199,6 +204,11 @@ class RansDecoder:
         h, self._h = getattr(self, '_h', None), None
         if h:
             host().fpcc_simple_dec_free(h)
+
+    def __deepcopy__(self, memo):
+        return RansDecoder()
+
+    __copy__ = lambda self: self.__deepcopy__({})
 
     def flush(self, encoded: bytes) -> int:
         if self._h:

@@ -23,6 +23,7 @@ MODEL_MODULES = {
     'models.convolutional.lossy_coord_v2': 'fastpcc_amd.codecs.lossy_coord_v2',
     'models.convolutional.lossy_coord_lossy_color': 'fastpcc_amd.codecs.lossy_coord_lossy_color',
     'models.convolutional.lossl_coord_int': 'fastpcc_amd.codecs.lossl_coord_int',
+    'models.convolutional.lossl_coord': 'fastpcc_amd.codecs.lossl_coord',
 }
 
 
@@ -106,12 +107,16 @@ def main(argv=None):
     if args.results_dir:
         os.makedirs(os.path.join(args.results_dir, 'bin'), exist_ok=True)
     per_file = {}
+    if hasattr(model, 'pre_test_hook'):             # test.py:115-116 (the float LiDAR codec inserts its observers here)
+        model.pre_test_hook()
     for sample in _samples(args):
         sample.results_dir = os.path.join(args.results_dir, 'bin') if args.results_dir else None
         batch = pc_data_collate_fn([sample], int(limit or 0)).to(device)
         with torch.no_grad():
             ret = model(batch)
         per_file[sample.file_path[0]] = {k: v for k, v in ret.items() if isinstance(v, (int, float))}
+    if hasattr(model, 'post_test_hook'):            # test.py:147-148 (... and writes the integer parameters here)
+        model.post_test_hook()
     evaluator = getattr(model, 'evaluator', None)
     mean = evaluator.show(os.path.join(args.results_dir, 'bin') if args.results_dir else None) if evaluator is not None else {}
     print(json.dumps({'files': per_file, 'mean': mean}, indent=1, default=float))
