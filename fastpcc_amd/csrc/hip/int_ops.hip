@@ -11,6 +11,7 @@
 // dependency-bound, not math-bound, so the kernel favours few launches (bias/PReLU/requant fused, raw conv optional)
 // over peak MFMA rate.
 #include "common.h"
+#include <cstdlib>
 
 namespace fpcc {
 namespace {
@@ -125,16 +126,47 @@ struct ConvI8Args {
     const int32_t *zp_comp;                 // [n_off][c_out] or NULL
     const int32_t *bias; const int32_t *slope; const uint32_t *mul; const int64_t *zp; int shift; int out_bits;
     void *out; int ldo; int c_out; int64_t n_out; int out_pad;   // columns [c_out, out_pad) of an int8 output are zeroed
+    const int32_t *row_order;               // tile position -> output row (NULL: identity)
 };
 
-template <int NB>
-__global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p) {
+// Source of every absent operand (missing neighbour, column past c_out, half k-step past the padded row): loads stay
+// unconditional, which lets the compiler keep them in flight across the MFMAs of the previous stage.
+__device__ __attribute__((aligned(16))) int8_t g_zero_i8[64];
+
+constexpr int kI8MaxOffsets = 64;       // 4x4x4 kernels of the embedding convolutions
+
+// One wave = 32 output rows x 32*NB output columns; the four waves of a workgroup are independent (no barrier).
+// A stage = (kernel offset present in the wave's rows, k-step of 32 input channels): one 16-byte A load and NB 16-byte
+// W loads per lane, NB MFMAs.  The operands of stage s+1 are requested before the MFMAs of stage s are issued.
+// SPLIT: blockIdx.z selects ONE kernel offset and the raw int32 sums are added atomically to `acc_out` (integer
+// addition is associative: any order gives the same bits) -- for maps too small to fill the chip with row tiles.
+template <int NB, bool SPLIT>
+__global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p, int32_t *acc_out, int ld_acc) {
+    __shared__ int32_t s_idx[SPLIT ? 1 : 4 * kI8MaxOffsets * 32];      // wave-private slices
+    __shared__ int32_t s_row[4 * 32];                                    // output row of each tile position (-1 past the end)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
     if (row0 >= p.n_out) return;
     const int col0 = blockIdx.y * 32 * NB;
-    const int64_t my_row = row0 + li;
+    const int64_t my_row = row0 + li < p.n_out ? (p.row_order ? (int64_t)p.row_order[row0 + li] : row0 + li) : -1;
+    int32_t *my_rows = s_row + wave * 32;
+    if (lh == 0) my_rows[li] = (int32_t)my_row;
+    const int k_lo = SPLIT ? blockIdx.z : 0;
+    const int n_k = SPLIT ? 1 : p.n_off;
+    int32_t *my_idx = s_idx + (SPLIT ? 0 : wave * kI8MaxOffsets * 32);
+
+    unsigned long long mask = 0ull;
+    int32_t idx_one = -1;
+    for (int k = 0; k < n_k; ++k) {
+        int32_t idx = -1;
+        if (my_row >= 0)
+            idx = p.nbr ? p.nbr[(int64_t)(k_lo + k) * p.nbr_ks + my_row * p.nbr_os] - p.nbr_bias : (int32_t)my_row;
+        if (__ballot(idx >= 0) != 0ull) mask |= 1ull << k;
+        if (SPLIT) idx_one = idx;
+        else if (lh == 0) my_idx[k * 32 + li] = idx;
+    }
+    if (SPLIT && mask == 0ull) return;
 
     i32x16 acc[NB];
 #pragma unroll
@@ -142,42 +174,75 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0;
 
-    const i32x4 zero4 = {0, 0, 0, 0};
-    for (int k = 0; k < p.n_off; ++k) {
-        int64_t idx = -1;
-        if (my_row < p.n_out) idx = p.nbr ? (int64_t)p.nbr[(int64_t)k * p.nbr_ks + my_row * p.nbr_os] - p.nbr_bias : my_row;
-        const unsigned long long present = __ballot(idx >= 0);
-        if (present == 0ull) continue;
-        const int8_t *arow = p.a + (idx >= 0 ? idx : 0) * p.lda + 16 * lh;
-        const int8_t *wk = p.w + (int64_t)k * p.c_out * p.ldw + 16 * lh;
-        for (int s = 0; s < p.k_steps; ++s) {
-            // the second 16-byte half of the last step may lie past the padded row: it is zero by contract when inside,
-            // and skipped when outside
-            const bool in_row = 32 * s + 16 * lh < p.lda;
-            i32x4 av = zero4;
-            if (idx >= 0 && in_row) av = *reinterpret_cast<const i32x4 *>(arow + 32 * s);
+    const int8_t *zero = g_zero_i8;
+    const int8_t *wcol[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int col = col0 + 32 * nb + li;
-                i32x4 bv = zero4;
-                if (col < p.c_out && 32 * s + 16 * lh < p.ldw)
-                    bv = *reinterpret_cast<const i32x4 *>(wk + (int64_t)col * p.ldw + 32 * s);
-                acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[nb], 0, 0, 0);
-            }
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + 32 * nb + li;
+        wcol[nb] = col < p.c_out ? p.w + (int64_t)col * p.ldw : nullptr;
+    }
+    auto fetch = [&](int k, int s, i32x4 &av, i32x4 (&bv)[NB]) {
+        const int32_t idx = SPLIT ? idx_one : my_idx[k * 32 + li];
+        const int koff = 32 * s + 16 * lh;       // the second half of the last k-step may lie past a padded row
+        const int8_t *ap = (idx >= 0 && koff < p.lda) ? p.a + (int64_t)idx * p.lda + koff : zero;
+        av = *reinterpret_cast<const i32x4 *>(ap);
+        const int64_t wk = (int64_t)(k_lo + k) * p.c_out * p.ldw + koff;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int8_t *bp = (wcol[nb] && koff < p.ldw) ? wcol[nb] + wk : zero;
+            bv[nb] = *reinterpret_cast<const i32x4 *>(bp);
         }
-        if (p.zp_comp) {
-            const unsigned rows_present = (unsigned)(present & 0xffffffffull);
+    };
+
+    const int stages = __popcll(mask) * p.k_steps;
+    if (stages > 0) {
+        unsigned long long rest = mask;
+        int k_n = __ffsll((long long)rest) - 1, s_n = 0;
+        i32x4 a_n, b_n[NB];
+        fetch(k_n, 0, a_n, b_n);
+        for (int st = 0; st < stages; ++st) {
+            const i32x4 a_c = a_n;
+            i32x4 b_c[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int col = col0 + 32 * nb + li;
-                const int32_t comp = col < p.c_out ? p.zp_comp[(int64_t)k * p.c_out + col] : 0;
+            for (int nb = 0; nb < NB; ++nb) b_c[nb] = b_n[nb];
+            const int k_c = k_n, s_c = s_n;
+            if (++s_n == p.k_steps) {
+                s_n = 0;
+                rest &= rest - 1;
+                if (rest) k_n = __ffsll((long long)rest) - 1;       // after the last stage: re-read a valid one
+            }
+            fetch(k_n, s_n, a_n, b_n);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if ((rows_present >> rr) & 1u) acc[nb][reg] += comp;
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_c, b_c[nb], acc[nb], 0, 0, 0);
+            if (p.zp_comp && s_c == p.k_steps - 1) {
+                const int32_t idx = SPLIT ? idx_one : my_idx[k_c * 32 + li];
+                const unsigned rows_present = (unsigned)(__ballot(idx >= 0) & 0xffffffffull);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int col = col0 + 32 * nb + li;
+                    const int32_t comp = col < p.c_out ? p.zp_comp[(int64_t)(k_lo + k_c) * p.c_out + col] : 0;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                        if ((rows_present >> rr) & 1u) acc[nb][reg] += comp;
+                    }
                 }
             }
         }
+    }
+
+    if (SPLIT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = col0 + 32 * nb + li;
+            if (col >= p.c_out) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t o = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
+                if (o >= 0 && acc[nb][reg] != 0) atomicAdd(acc_out + o * ld_acc + col, acc[nb][reg]);
+            }
+        }
+        return;
     }
 
     const int32_t slope = p.slope ? p.slope[0] : 0;
@@ -192,8 +257,164 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p) {
         const uint32_t m = (live && p.mul) ? p.mul[col] : 0u;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int64_t o = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (o >= p.n_out) continue;
+            const int64_t o = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
+            if (o < 0) continue;
+            int32_t v = 0;
+            if (live) {
+                if (p.mul) {
+                    int64_t t = (int64_t)acc[nb][reg] + b;
+                    if (p.slope) t = prelu_q625(t, slope);
+                    v = requant(t, m, zp, p.shift, p.out_bits);
+                } else {
+                    v = acc[nb][reg];
+                }
+            }
+            if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
+            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = v;
+        }
+    }
+}
+
+// Workgroup-tiled variant for maps that fill the chip with row tiles: 4 waves = 128 output rows x 32*NB output columns.
+// The wave-per-block kernel above reads W straight from global memory, 16 bytes per lane out of every 256-byte weight
+// row, once per WAVE: one eighth of every cache line fetched is used and the lines do not survive in the vector L1
+// until the next k-step (measured: ~3 us per k-step, L1-refill bound).  Here a stage is (kernel offset, 128 input
+// channels): the workgroup fetches the 32*NB x 128-byte W tile ONCE with whole-line loads into LDS (double buffered, one
+// barrier per stage, 16-byte pieces XOR-swizzled so that the MFMA operand reads are conflict free), every wave gathers
+// its 32 A rows as full 128-byte lines into registers one stage ahead, and issues up to 4*NB MFMAs per stage.  Offsets
+// absent from the whole tile are skipped by the workgroup, offsets absent from a wave's rows by that wave.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
+    constexpr int COLS = 32 * NB;
+    constexpr int W_PIECES = COLS * 8 / 256;                     // 16-byte pieces of one W tile per thread
+    __shared__ i32x4 sB[2][8 * COLS];
+    __shared__ int32_t s_idx[kI8MaxOffsets * 128];
+    __shared__ int32_t s_row[128];
+    __shared__ unsigned long long s_mask[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int col0 = blockIdx.y * COLS;
+
+    if (tid < 128) s_row[tid] = row0 + tid < p.n_out ? (p.row_order ? p.row_order[row0 + tid] : (int32_t)(row0 + tid)) : -1;
+    __syncthreads();
+    for (int e = tid; e < p.n_off * 128; e += 256) {
+        const int k = e >> 7, r = e & 127;
+        const int64_t row = s_row[r];
+        s_idx[e] = row < 0 ? -1 : (p.nbr ? p.nbr[(int64_t)k * p.nbr_ks + row * p.nbr_os] - p.nbr_bias : (int32_t)row);
+    }
+    __syncthreads();
+    const int32_t *my_idx = s_idx + wave * 32 + li;
+    unsigned long long wmask = 0ull;
+    for (int k = 0; k < p.n_off; ++k)
+        if (__ballot(my_idx[k * 128] >= 0) != 0ull) wmask |= 1ull << k;
+    if (lane == 0) s_mask[wave] = wmask;
+    __syncthreads();
+    const unsigned long long tmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    const int n_chunks = (p.k_steps + 3) / 4;
+    const int n_stages = __popcll(tmask) * n_chunks;
+
+    i32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0;
+
+    const int8_t *zero = g_zero_i8;
+    auto fetch_a = [&](int k, int c, i32x4 (&ra)[4]) {
+        const int32_t idx = my_idx[k * 128];
+        const int8_t *arow = p.a + (int64_t)(idx >= 0 ? idx : 0) * p.lda;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int koff = 128 * c + 32 * s4 + 16 * lh;
+            ra[s4] = *reinterpret_cast<const i32x4 *>((idx >= 0 && koff < p.lda) ? arow + koff : zero);
+        }
+    };
+    auto fetch_w = [&](int k, int c, i32x4 (&rw)[W_PIECES]) {
+#pragma unroll
+        for (int j = 0; j < W_PIECES; ++j) {
+            const int piece = tid + 256 * j;
+            const int col = col0 + (piece >> 3), koff = 128 * c + 16 * (piece & 7);
+            rw[j] = *reinterpret_cast<const i32x4 *>((col < p.c_out && koff < p.ldw)
+                                                         ? p.w + ((int64_t)k * p.c_out + col) * p.ldw + koff : zero);
+        }
+    };
+    auto stash_w = [&](int buf, const i32x4 (&rw)[W_PIECES]) {
+#pragma unroll
+        for (int j = 0; j < W_PIECES; ++j) {
+            const int piece = tid + 256 * j;
+            const int col = piece >> 3, part = piece & 7;
+            sB[buf][part * COLS + (col ^ part)] = rw[j];
+        }
+    };
+
+    if (n_stages > 0) {
+        unsigned long long rest = tmask;
+        int k_cur = __ffsll((long long)rest) - 1, c_cur = 0;
+        int k_next = k_cur, c_next = 0;
+        i32x4 ra_cur[4], ra_nxt[4], rw[W_PIECES];
+        fetch_a(k_cur, 0, ra_nxt);
+        fetch_w(k_cur, 0, rw);
+        stash_w(0, rw);
+        __syncthreads();
+        for (int st = 0; st < n_stages; ++st) {
+            if (++c_next == n_chunks) {
+                c_next = 0;
+                rest &= rest - 1;
+                k_next = rest ? __ffsll((long long)rest) - 1 : k_cur;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) ra_cur[s4] = ra_nxt[s4];
+            fetch_a(k_next, c_next, ra_nxt);
+            fetch_w(k_next, c_next, rw);
+            if ((wmask >> k_cur) & 1ull) {
+                const i32x4 *cB = sB[st & 1];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (4 * c_cur + s4 < p.k_steps) {
+                        const int part = 2 * s4 + lh;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra_cur[s4], cB[part * COLS + ((32 * nb + li) ^ part)],
+                                                                           acc[nb], 0, 0, 0);
+                    }
+                }
+                if (p.zp_comp && c_cur == n_chunks - 1) {
+                    const unsigned rows_present = (unsigned)(__ballot(my_idx[k_cur * 128] >= 0) & 0xffffffffull);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int col = col0 + 32 * nb + li;
+                        const int32_t comp = col < p.c_out ? p.zp_comp[(int64_t)k_cur * p.c_out + col] : 0;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            if ((rows_present >> ((reg & 3) + 8 * (reg >> 2) + 4 * lh)) & 1u) acc[nb][reg] += comp;
+                    }
+                }
+            }
+            stash_w((st + 1) & 1, rw);
+            __syncthreads();
+            k_cur = k_next;
+            c_cur = c_next;
+        }
+    }
+
+    const int32_t slope = p.slope ? p.slope[0] : 0;
+    const int64_t zp = p.zp ? p.zp[0] : 0;
+    const int32_t *my_rows = s_row + wave * 32;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + 32 * nb + li;
+        const bool live = col < p.c_out;
+        const bool pad = !live && p.out_bits == 8 && col < p.out_pad;
+        if (!live && !pad) continue;
+        const int32_t b = (live && p.bias) ? p.bias[col] : 0;
+        const uint32_t m = (live && p.mul) ? p.mul[col] : 0u;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t o = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
+            if (o < 0) continue;
             int32_t v = 0;
             if (live) {
                 if (p.mul) {
@@ -416,11 +637,24 @@ extern "C" int fpcc_hash_lookup_keys(const int64_t *table_keys, const int32_t *t
     return FPCC_OK;
 }
 
+// rows up to which multi-offset int8 convolutions are evaluated one workgroup per (row tile, kernel offset)
+constexpr int64_t kI8SplitMaxRows = 8192;
+
+static bool i8_split(const int32_t *nbr, int n_offsets, int64_t n_out) {
+    return nbr && n_offsets >= 8 && n_out <= kI8SplitMaxRows;
+}
+
+extern "C" int64_t fpcc_conv_i8_ws_bytes(int has_nbr, int n_offsets, int has_requant, int c_out, int64_t n_out) {
+    return (has_nbr && n_offsets >= 8 && n_out > 0 && n_out <= kI8SplitMaxRows && has_requant) ? n_out * (int64_t)c_out * 4 : 0;
+}
+
 extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
                             int64_t nbr_os, int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp,
                             const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul, const int64_t *zero_point,
-                            int shift, int out_bits, void *out, int ldo, int out_pad, int c_out, int64_t n_out, void *stream) {
-    if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1) return fail_arg("conv_i8: sizes out of range");
+                            int shift, int out_bits, void *out, int ldo, int out_pad, int c_out, int64_t n_out,
+                            const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream) {
+    if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1 || n_offsets > kI8MaxOffsets)
+        return fail_arg("conv_i8: sizes out of range (n_offsets must be 1..64)");
     if (n_out == 0) return FPCC_OK;
     if (!a || !w || !out) return fail_arg("conv_i8: null pointer");
     if (!nbr && n_offsets != 1) return fail_arg("conv_i8: identity map needs n_offsets == 1");
@@ -431,16 +665,41 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
     if (!requant_mul && out_bits != 32) return fail_arg("conv_i8: raw accumulators are int32");
     if (ldo < c_out || out_pad > ldo) return fail_arg("conv_i8: output row stride too small");
     ConvI8Args p{a, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, (c_in + 31) / 32, zp_comp,
-                 bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad};
+                 bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad, row_order};
     const int width = out_pad > c_out ? out_pad : c_out;
     const unsigned gx = (unsigned)((n_out + 127) / 128);
     hipStream_t s = as_stream(stream);
-    if (width > 64) {
-        hipLaunchKernelGGL((k_conv_i8<4>), dim3(gx, (width + 127) / 128), dim3(256), 0, s, p);
+    if (i8_split(nbr, n_offsets, n_out)) {
+        // raw sums are accumulated atomically: into the caller's workspace when an epilogue follows, else into `out`
+        int32_t *acc = static_cast<int32_t *>(out);
+        int ld_acc = ldo;
+        if (requant_mul) {
+            if (!ws || ws_bytes < n_out * (int64_t)c_out * 4) return fail_arg("conv_i8: this shape needs fpcc_conv_i8_ws_bytes() bytes of workspace");
+            acc = static_cast<int32_t *>(ws);
+            ld_acc = c_out;
+        }
+        if (int rc = check_hip(hipMemsetAsync(acc, 0, (size_t)n_out * ld_acc * 4, s), "conv_i8: memset")) return rc;
+        const dim3 grid(gx, (c_out + 127) / 128, n_offsets);
+        if (c_out > 64) hipLaunchKernelGGL((k_conv_i8<4, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
+        else if (c_out > 32) hipLaunchKernelGGL((k_conv_i8<2, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
+        else hipLaunchKernelGGL((k_conv_i8<1, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
+        FPCC_LAUNCHED(k_conv_i8_split);
+        if (requant_mul) {
+            hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
+                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0);
+            FPCC_LAUNCHED(k_epilogue_i32);
+        }
+        return FPCC_OK;
+    }
+    static const int tiled = [] { const char *e = getenv("FPCC_I8_TILED"); return e ? atoi(e) : 1; }();
+    if (width > 64 && tiled && n_out >= 2048) {
+        hipLaunchKernelGGL((k_conv_i8_tiled<4>), dim3(gx, (width + 127) / 128), dim3(256), 0, s, p);
+    } else if (width > 64) {
+        hipLaunchKernelGGL((k_conv_i8<4, false>), dim3(gx, (width + 127) / 128), dim3(256), 0, s, p, nullptr, 0);
     } else if (width > 32) {
-        hipLaunchKernelGGL((k_conv_i8<2>), dim3(gx, 1), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((k_conv_i8<2, false>), dim3(gx, 1), dim3(256), 0, s, p, nullptr, 0);
     } else {
-        hipLaunchKernelGGL((k_conv_i8<1>), dim3(gx, 1), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((k_conv_i8<1, false>), dim3(gx, 1), dim3(256), 0, s, p, nullptr, 0);
     }
     FPCC_LAUNCHED(k_conv_i8);
     return FPCC_OK;

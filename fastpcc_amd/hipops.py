@@ -56,7 +56,8 @@ _SIGS = {
     'fpcc_hash_insert_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
     'fpcc_hash_lookup_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_conv_i8': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                            _vp, _i32, _i32, _i32, _i64, _vp]),
+                            _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i64, _vp]),
+    'fpcc_conv_i8_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'fpcc_epilogue_i32': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
     'fpcc_prelu_i32': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'fpcc_softmax_i32': (_i32, [_vp, _i64, _i32, _vp, _vp]),
@@ -560,7 +561,8 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
             nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1, nbr_bias: int = 0,
             zp_comp: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
             slope: Optional[torch.Tensor] = None, requant_mul: Optional[torch.Tensor] = None,
-            zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32) -> torch.Tensor:
+            zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32,
+            row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw]."""
     a = _rows_i8(a, 'a')
     if not w_padded.is_cuda:
@@ -570,11 +572,17 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
         raise ValueError('weights must be contiguous int8 [n_offsets, c_out, ldw] with ldw a multiple of 16')
     out = torch.empty((n_out, c_out), dtype=torch.int8 if out_bits == 8 else torch.int32, device=a.device)
     mul = None if requant_mul is None else _mul_u32(requant_mul)
+    ws, ws_bytes = None, 0
+    if nbr is not None and n_offsets >= 8 and n_out <= 8192:
+        ws_bytes = lib().fpcc_conv_i8_ws_bytes(1, n_offsets, int(mul is not None), c_out, n_out)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=a.device)
     _ok(lib().fpcc_conv_i8(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
                            nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
                            _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
                            _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
-                           int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _stream()))
+                           int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _dev(row_order, torch.int32, 'row_order', True),
+                           None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
     return out
 
 

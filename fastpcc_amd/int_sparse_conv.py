@@ -28,6 +28,8 @@ from torch.ao.quantization import HistogramObserver
 from . import hipops as ops
 
 SharedFxpShift = 23               # Q8.23 shared fixed-point activation format
+ROW_ORDER_MIN_ROWS = 8192         # larger 3x3x3 maps are evaluated in neighbour-pattern row order (smaller ones offset-split)
+ROW_ORDER_WINDOW_LOG2 = 17
 WeightRange = (1 << 7) - 1
 ActRange = (1 << 7) - 1
 
@@ -105,10 +107,13 @@ def sparse_conv_in8w8out32(in_feats: torch.Tensor, weight: torch.Tensor, in_coor
     if in_out_maps is None:
         hashmap_kv, in_out_maps = _kernel_table(in_coords, out_coords, kernel_size, stride, hashmap_kv)
     n_out = out_coords.shape[0]
+    if volume == 27 and n_out > ROW_ORDER_MIN_ROWS and not hasattr(in_out_maps, '_fpcc_row_order'):
+        # neighbour-pattern row order, computed once per kernel map and kept with it (the table is the cache object)
+        in_out_maps._fpcc_row_order = ops.conv_row_order(in_out_maps - 1, volume, 1, volume, n_out, ROW_ORDER_WINDOW_LOG2)
     w = weight if weight.shape[-1] % 16 == 0 and weight.is_contiguous() else _pad_weight(weight)
     ep = _epilogue or {}
     out = ops.conv_i8(in_feats, w, in_feats.shape[1], weight.shape[1], n_out, nbr=in_out_maps, n_offsets=volume, nbr_ks=1,
-                      nbr_os=volume, nbr_bias=1, zp_comp=zero_point_comp, **ep)
+                      nbr_os=volume, nbr_bias=1, zp_comp=zero_point_comp, row_order=getattr(in_out_maps, '_fpcc_row_order', None), **ep)
     return out, hashmap_kv, in_out_maps
 
 

@@ -281,11 +281,17 @@ int fpcc_hash_lookup_keys(const int64_t *table_keys, const int32_t *table_vals, 
  *   W        int8 [n_offsets][c_out][ldw] (the reference's [K, C_out, C_in] with rows padded to ldw, multiple of 16);
  *   slope    device int32[1] (Q6.25) or NULL; zero_point device int64[1] or NULL;
  *   out      int8 or int32 [n_out][ldo]; for int8 outputs the columns c_out..out_pad are written as zeros so that the
- *            tensor can feed the next layer as A. */
+ *            tensor can feed the next layer as A;
+ *   row_order  NULL, or a permutation of [0, n_out): tile position p computes output row row_order[p] (see fpcc_conv_row_keys;
+ *            on LiDAR sweeps a 32-row block in Morton order executes 2-4x the offsets its rows have, in pattern order 1.2-1.3x);
+ *   ws       maps of at most 8192 rows with >= 8 kernel offsets are evaluated one workgroup per (row tile, offset), the raw
+ *            sums added atomically (integer addition: any order gives the same bits); with an epilogue this needs
+ *            fpcc_conv_i8_ws_bytes() bytes of device scratch, otherwise ws may be NULL. */
 int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                  int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope,
                  const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
-                 int out_pad, int c_out, int64_t n_out, void *stream);
+                 int out_pad, int c_out, int64_t n_out, const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream);
+int64_t fpcc_conv_i8_ws_bytes(int has_nbr, int n_offsets, int has_requant, int c_out, int64_t n_out);
 
 /* Stand-alone epilogue on an int32 matrix [n][ch] (row stride ldi): requant_to_int{8,32}, bias_requant_*, prelu_requant_*,
  * bias_prelu_requant_* (src/element_wise/*.cu).  mul_per_channel == 0 broadcasts requant_mul[0]
