@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
 // stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
 __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const int32_t *bias, const int32_t *slope,
                                const uint32_t *mul, int mul_stride, const int64_t *zp, int shift, int out_bits,
-                               void *out, int ldo, int64_t n, int ch, int out_pad) {
+                               void *out, int ldo, int64_t n, int ch, int out_pad, const int32_t *row_group) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int width = out_pad > ch ? out_pad : ch;
     if (e >= n * width) return;
@@ -442,9 +442,10 @@ __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const in
     const int c = (int)(e - r * width);
     int32_t v = 0;
     if (c < ch) {
-        int64_t t = (int64_t)in[r * ldi + c] + (bias ? (int64_t)bias[c] : 0);
+        const int64_t pc = (row_group ? (int64_t)row_group[r] * ch : 0) + c;      // parameter column of this element
+        int64_t t = (int64_t)in[r * ldi + c] + (bias ? (int64_t)bias[pc] : 0);
         if (slope) t = prelu_q625(t, slope[0]);
-        v = requant(t, mul[c * mul_stride], zp ? zp[0] : 0, shift, out_bits);
+        v = requant(t, mul[pc * mul_stride], zp ? zp[0] : 0, shift, out_bits);
     }
     if (out_bits == 8) static_cast<int8_t *>(out)[r * ldo + c] = (int8_t)v;
     else if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = v;
@@ -686,7 +687,7 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
         FPCC_LAUNCHED(k_conv_i8_split);
         if (requant_mul) {
             hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
-                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0);
+                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0, nullptr);
             FPCC_LAUNCHED(k_epilogue_i32);
         }
         return FPCC_OK;
@@ -707,7 +708,8 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
 
 extern "C" int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope,
                                  const uint32_t *requant_mul, int mul_per_channel, const int64_t *zero_point, int shift,
-                                 int out_bits, void *out, int ldo, int out_pad, int64_t n, int ch, void *stream) {
+                                 int out_bits, void *out, int ldo, int out_pad, int64_t n, int ch, const int32_t *row_group,
+                                 void *stream) {
     if (n < 0 || ch < 1 || shift < 0) return fail_arg("epilogue_i32: bad sizes or negative shift");
     if (n == 0) return FPCC_OK;
     if (!in || !requant_mul || !out) return fail_arg("epilogue_i32: null pointer");
@@ -717,7 +719,7 @@ extern "C" int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias
     if (ldo < width || ldi < ch) return fail_arg("epilogue_i32: row stride too small");
     hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n * width, kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
                        bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch,
-                       out_bits == 8 ? out_pad : 0);
+                       out_bits == 8 ? out_pad : 0, row_group);
     FPCC_LAUNCHED(k_epilogue_i32);
     return FPCC_OK;
 }

@@ -18,6 +18,9 @@
 #include <new>
 #include <thread>
 #include <vector>
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -357,6 +360,23 @@ static inline void edge_range(const uint16_t *row, int64_t width, uint32_t s, ui
     hi = (int64_t(s) == width - 1) ? kProbOne : row[s];
 }
 
+// number of entries of a non-decreasing uint16 row that are <= target (what std::upper_bound returns as an index).  The
+// decoder meets every row cold (freshly DMA-written pinned memory, 510 bytes each): a binary search walks 3-4 cache
+// lines one after the other, a vector scan asks for all of them at once and has no data-dependent branch.
+static inline int64_t count_le(const uint16_t *row, int64_t width, uint16_t target) {
+    int64_t j = 0, count = 0;
+#if defined(__AVX2__)
+    const __m256i t = _mm256_set1_epi16(static_cast<short>(target));
+    for (; j + 16 <= width; j += 16) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(row + j));
+        const __m256i le = _mm256_cmpeq_epi16(_mm256_min_epu16(v, t), v);
+        count += __builtin_popcount(static_cast<unsigned>(_mm256_movemask_epi8(le))) >> 1;
+    }
+#endif
+    for (; j < width; ++j) count += row[j] <= target;
+    return count;
+}
+
 fpcc_simple_enc *fpcc_simple_enc_new(int64_t buf_bytes) {
     if (buf_bytes < 16) return nullptr;
     return new (std::nothrow) fpcc_simple_enc(buf_bytes);
@@ -414,10 +434,17 @@ void fpcc_simple_dec_free(fpcc_simple_dec *d) { delete d; }
 int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_rows, int64_t width,
                             uint16_t *symbols_out, int64_t n) {
     if (!d || !rows || !symbols_out || width < 1 || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
+    constexpr int64_t kAhead = 6;                       // rows requested ahead of the one being searched
+    const int64_t row_bytes = width * 2;
     for (int64_t i = 0; i < n; ++i) {
         const uint16_t *row = rows + (n_rows == 1 ? 0 : i * width);
+        if (n_rows != 1 && i + kAhead < n) {
+            const char *ahead = reinterpret_cast<const char *>(row + kAhead * width);
+            for (int64_t b = 0; b < row_bytes; b += 64) __builtin_prefetch(ahead + b, 0, 0);
+        }
         const uint32_t target = d->r.peek<kProbBits>();
-        int64_t s = std::upper_bound(row, row + width, static_cast<uint16_t>(target)) - row;
+        int64_t s = width >= 32 ? count_le(row, width, static_cast<uint16_t>(target))
+                                : std::upper_bound(row, row + width, static_cast<uint16_t>(target)) - row;
         s = std::min<int64_t>(s, width - 1);
         uint32_t lo, hi;
         edge_range(row, width, static_cast<uint32_t>(s), lo, hi);

@@ -58,7 +58,7 @@ _SIGS = {
     'fpcc_conv_i8': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                             _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i64, _vp]),
     'fpcc_conv_i8_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
-    'fpcc_epilogue_i32': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    'fpcc_epilogue_i32': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     'fpcc_prelu_i32': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'fpcc_softmax_i32': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_logits_to_cdf16': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
@@ -587,20 +587,25 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
 
 
 def epilogue_i32(x: torch.Tensor, requant_mul: torch.Tensor, zero_point: Optional[torch.Tensor], shift: int, out_bits: int,
-                 *, bias: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 *, bias: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None,
+                 row_group: Optional[torch.Tensor] = None) -> torch.Tensor:
     """requant_to_int8/int32 and their bias / PReLU variants on an int32 matrix [n, ch]"""
     if x.dtype != torch.int32 or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         raise TypeError('input must be a 2-D int32 GPU tensor with unit column stride')
     n, ch = x.shape
     mul = _mul_u32(requant_mul)
     per_channel = 1 if mul.numel() == ch and ch > 1 else (1 if mul.numel() == ch else 0)
-    if mul.numel() not in (1, ch):
+    if row_group is not None:
+        if mul.numel() % ch or (bias is not None and bias.numel() != mul.numel()) or row_group.shape[0] != n:
+            raise ValueError('grouped epilogue: requant_mul / bias hold groups x ch values, row_group one entry per row')
+        per_channel = 1
+    elif mul.numel() not in (1, ch):
         raise ValueError('requant_mul must have 1 or ch entries')
     out = torch.empty((n, ch), dtype=torch.int8 if out_bits == 8 else torch.int32, device=x.device)
     _ok(lib().fpcc_epilogue_i32(x.data_ptr(), x.stride(0) if n > 1 else ch, _dev(bias, torch.int32, 'bias', True),
                                 _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
                                 per_channel, _dev(zero_point, torch.int64, 'zero_point', True), int(shift), out_bits,
-                                out.data_ptr(), ch, 0, n, ch, _stream()))
+                                out.data_ptr(), ch, 0, n, ch, _dev(row_group, torch.int32, 'row_group', True), _stream()))
     return out
 
 

@@ -298,7 +298,10 @@ int64_t fpcc_conv_i8_ws_bytes(int has_nbr, int n_offsets, int has_requant, int c
  * (RequantFxpToScaledInt8, cuda_ops.py:505-509). */
 int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
                       int mul_per_channel, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
-                      int out_pad, int64_t n, int ch, void *stream);
+                      int out_pad, int64_t n, int ch, const int32_t *row_group, void *stream);
+/* row_group (NULL = none): bias / requant_mul hold one set of `ch` values per group and row r uses set row_group[r] --
+ * the epilogue of a linear layer C -> 8*C of which only the occupied octants are evaluated (model.py:66-74: the
+ * reference computes all 8*C columns and indexes the occupied ones afterwards). */
 
 /* out = clamp_i32(prelu_q6.25(a (+ b, wrapping))): `prelu` (src/element_wise/prelu.cu) with the residual add of
  * SparseResBlockIn32W8Out32.forward (cuda_ops.py:90) fused; b may be NULL. */
