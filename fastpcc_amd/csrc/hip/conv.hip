@@ -33,7 +33,6 @@ struct ConvArgs {
     const int32_t *out_map; int64_t om_os; int64_t om_gs; float *out; int ldo; int64_t n_out;
     int act; const float *slope; float clip;
     const int32_t *row_order;  // tile position -> output row (NULL: identity); see fpcc_conv_row_keys
-    unsigned deal;             // row_order given: tile = (blockIdx.x * deal) % tiles, deal coprime to the tile count
     float *ws; int split;      // split != 0: blockIdx.y selects ONE kernel offset; raw partial sums go to ws[offset][row][col]
 };
 
@@ -150,10 +149,11 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WM, wc = wave / WM;
     const int li = lane & 31, lh = lane >> 5;
-    // Morton order: contiguous tile ranges per XCD (shared L2).  Neighbour-pattern order: the tiles are sorted by how
-    // many offsets they hold and the gathers have no locality to keep, so they are dealt out with a stride instead --
-    // every XCD / CU gets a mix of heavy and light tiles (measured: 272 K-row layer 1288 -> 1203 us, 70 K-row 450 -> 422 us)
-    const unsigned tile = a.row_order ? (unsigned)(((uint64_t)blockIdx.x * a.deal) % gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
+    // Morton order: contiguous tile ranges per XCD (shared L2).  With a row order the gathers have no locality to keep and
+    // the tiles come heaviest first (fpcc_conv_tile_keys): they are taken in dispatch order, so consecutive -- equally
+    // heavy -- tiles land on different XCDs and the light tiles fill the tail of the launch (longest-processing-time-first:
+    // 272 K-row layer 1193 -> 1132 us, 70 K-row 429 -> 390 us, 18 K-row 213 -> 200 us against a strided deal).
+    const unsigned tile = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int g = a.split ? 0 : blockIdx.y;
     const int k_base = a.split ? blockIdx.y : 0;           // split: this workgroup evaluates kernel offset k_base only
     const int n_off = a.split ? 1 : a.n_off;
@@ -313,18 +313,10 @@ int mfma_chunk(int c1, int c2, int c_out) {
     return 0;
 }
 
-// stride of the tile deal of neighbour-pattern order: a prime that does not divide the tile count (a bijection)
-unsigned deal_stride(unsigned tiles) {
-    for (unsigned c : {97u, 101u, 103u, 107u, 109u, 113u, 127u})
-        if (tiles % c != 0) return c;
-    return 1u;
-}
-
 template <int NBT, int CH, int WM, int WN>
 int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
     constexpr int TM = 32 * WM;
     const unsigned tiles = (unsigned)((a.n_out + TM - 1) / TM);
-    a.deal = deal_stride(tiles);
     hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN>), dim3(tiles, a.groups), dim3(64 * WM * WN), 0, s, a);
     return check_hip(hipGetLastError(), "k_conv_mfma");
 }
@@ -432,7 +424,7 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
     if (n_out == 0) return FPCC_OK;
 
     ConvArgs a{x1, c1, ld1, x2, c2, ld2, nbr, n_offsets, nbr_ks, nbr_os, w, bias, c_out, groups,
-               out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order, 1u, static_cast<float *>(ws), 0};
+               out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order, static_cast<float *>(ws), 0};
     hipStream_t s = as_stream(stream);
     int ch = mfma_chunk(c1, c2, c_out);
     if (row_order && !ch) return fail_arg("conv_f32: row_order is a feature of the MFMA path (fpcc_conv_f32_order() != 0)");
@@ -483,8 +475,55 @@ __global__ void k_conv_row_keys(const int32_t *__restrict__ nbr, int n_off, int6
     m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
     keys[o] = ((o >> window_log2) << 32) | (int64_t)m;
 }
+
+// one wave per group of `group` (<= 64) consecutive positions of row_order: key = (offsets the group lacks) << 32 | group
+__global__ __launch_bounds__(256) void k_conv_tile_keys(const int32_t *__restrict__ nbr, int n_off, int64_t nbr_ks, int64_t nbr_os,
+                                                        const int32_t *__restrict__ row_order, int64_t n, int group,
+                                                        int64_t n_groups, int64_t *__restrict__ keys) {
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= n_groups) return;
+    const int64_t pos = g * group + lane;
+    const int64_t row = (lane < group && pos < n) ? (row_order ? (int64_t)row_order[pos] : pos) : -1;
+    int present = 0;
+    for (int k = 0; k < n_off; ++k) {
+        const bool has = row >= 0 && nbr[(int64_t)k * nbr_ks + row * nbr_os] >= 0;
+        present += __ballot(has) != 0ull;
+    }
+    if (lane == 0) keys[g] = ((int64_t)(n_off - present) << 32) | g;
+}
+
+__global__ void k_conv_regroup_rows(const int32_t *__restrict__ row_order, const int32_t *__restrict__ group_perm, int64_t n,
+                                    int group, int64_t n_groups, int32_t *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t g = p / group;
+    const int64_t src = g < n_groups ? (int64_t)group_perm[g] * group + (p - g * group) : p;    // the ragged tail stays last
+    out[p] = row_order ? row_order[src] : (int32_t)src;
+}
 }  // namespace
 }  // namespace fpcc
+
+extern "C" int fpcc_conv_tile_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, const int32_t *row_order,
+                                   int64_t n, int group, int64_t *keys_out, void *stream) {
+    if (n < 0 || n_offsets < 1 || n_offsets > 32 || group < 1 || group > 64) return fail_arg("conv_tile_keys: sizes out of range");
+    const int64_t n_groups = n / group;
+    if (n_groups == 0) return FPCC_OK;
+    if (!nbr || !keys_out) return fail_arg("conv_tile_keys: null pointer");
+    hipLaunchKernelGGL(k_conv_tile_keys, dim3(blocks_for(n_groups, 4)), dim3(256), 0, as_stream(stream), nbr, n_offsets, nbr_ks,
+                       nbr_os, row_order, n, group, n_groups, keys_out);
+    return check_hip(hipGetLastError(), "k_conv_tile_keys");
+}
+
+extern "C" int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *group_perm, int64_t n, int group,
+                                      int32_t *row_order_out, void *stream) {
+    if (n < 0 || group < 1) return fail_arg("conv_regroup_rows: sizes out of range");
+    if (n == 0) return FPCC_OK;
+    if (!row_order_out || (n / group > 0 && !group_perm)) return fail_arg("conv_regroup_rows: null pointer");
+    hipLaunchKernelGGL(k_conv_regroup_rows, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), row_order, group_perm, n,
+                       group, n / group, row_order_out);
+    return check_hip(hipGetLastError(), "k_conv_regroup_rows");
+}
 
 extern "C" int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n,
                                   int window_log2, int64_t *keys_out, void *stream) {

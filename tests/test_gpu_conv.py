@@ -211,17 +211,26 @@ def test_row_order_changes_no_result(ops, c1, c2, c_out):
     n = lvl.n - 37                                   # ragged tail tile
     table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
     nbr = _cuda(table)
+    windowed = ops.conv_row_order(nbr, 27, n, 1, n, 11, heaviest_first=False).cpu().numpy()
+    assert sorted(windowed.tolist()) == list(range(n))
+    assert ((windowed >> 11) == (np.arange(n) >> 11)).all()             # rows stay inside their window of 2048
+    # blocks of 32 rows in the new order need fewer (block, offset) products
+    pres = table >= 0
+    def per_block(perm, rows=32):
+        pad = (-len(perm)) % rows
+        p = np.concatenate((pres[:, perm], np.zeros((27, pad), bool)), 1).reshape(27, -1, rows)
+        return p.any(2).sum(0)
+    assert per_block(windowed).sum() < 0.85 * per_block(np.arange(n)).sum()
+    # ... and, tile by tile (64 rows from 32 Ki rows up), the tiles that execute most offsets come first
     order = ops.conv_row_order(nbr, 27, n, 1, n, 11)
     o = order.cpu().numpy()
     assert sorted(o.tolist()) == list(range(n))
-    assert ((o >> 11) == (np.arange(n) >> 11)).all()                    # rows stay inside their window of 2048
-    # blocks of 32 rows in the new order need fewer (block, offset) products
-    pres = table >= 0
-    def blocks(perm):
-        pad = (-n) % 32
-        p = np.concatenate((pres[:, perm], np.zeros((27, pad), bool)), 1).reshape(27, -1, 32)
-        return p.any(2).sum()
-    assert blocks(o) < 0.85 * blocks(np.arange(n))
+    group = 64 if n >= 32 * 1024 else 32
+    full = n // group * group
+    weights = per_block(o[:full], group)
+    assert (np.diff(weights) <= 0).all() and weights[0] > weights[-1]
+    assert sorted(map(tuple, o[:full].reshape(-1, group).tolist())) == sorted(map(tuple, windowed[:full].reshape(-1, group).tolist()))
+    assert (o[full:] == windowed[full:]).all()                         # the ragged tail stays last
     rng = np.random.default_rng(c1 + c_out)
     x1 = rng.normal(size=(lvl.n, c1)).astype(np.float32)
     x2 = rng.normal(size=(lvl.n, c2)).astype(np.float32) if c2 else None

@@ -28,7 +28,18 @@ w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
 pairs = int((nbr >= 0).sum().item())
 def run(row_order):
     return ops.conv_f32(f, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=row_order)
-for name, ro in (('natural', None), ('pattern', order)):
+def lpt(order, group):
+    present = (nbr >= 0)[:, order.long()]
+    pad = (-n) % group
+    w = torch.nn.functional.pad(present, (0, pad)).reshape(27, -1, group).any(2).sum(0)          # offsets per group
+    full = n // group
+    gp = torch.sort(w[:full], descending=True, stable=True)[1]
+    body = order[:full * group].reshape(full, group)[gp].reshape(-1)
+    return torch.cat([body, order[full * group:]]).contiguous()
+cases = [('natural', None), ('pattern', order)]
+if os.environ.get('LPT'):
+    cases.append(('pattern+lpt', lpt(order, int(os.environ['LPT']))))
+for name, ro in cases:
     for _ in range(3):
         run(ro)
     torch.cuda.synchronize(); t0 = time.perf_counter()
