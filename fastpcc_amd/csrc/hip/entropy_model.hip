@@ -227,3 +227,86 @@ extern "C" int fpcc_deep_factorized_bits_f32(const float *y, int64_t n, int c, i
                        c, out);
     return check_hip(hipGetLastError(), "k_dfac_reduce");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rate term of the scale-indexed noisy normal (the Gaussian-conditional bottleneck, training):
+//      s = exp(a + b i),   lp = log( Phi((y + h) / s) - Phi((y - h) / s) ),   out = sum lp,  dy = d lp / dy,  di = d lp / di
+// log Phi in the three segments of distributions/special_math.py:138-258 (x > 5: -Phi(-x); x < -10: asymptotic series of
+// order 3; else log Phi(x)), the difference taken on the survival side right of the median
+// (distributions/uniform_noise.py:36-63).  The derivatives are analytic, in the log domain so that a probability that
+// underflows does not turn them into inf * 0:   d lp / dy = (phi(z+) - phi(z-)) / (s p) = (e^(l+ - lp) - e^(l- - lp)) / s,
+// d lp / ds = -(z+ phi(z+) - z- phi(z-)) / (s p),  l+- = log phi(z+-).
+namespace fpcc {
+namespace {
+
+__device__ __forceinline__ float ndtr_f(float x) {
+    const float h = 0.70710678118654752f;
+    const float w = x * h, z = fabsf(w);
+    const float y = z < h ? 1.0f + erff(w) : (w > 0.0f ? 2.0f - erfcf(z) : erfcf(z));
+    return 0.5f * y;
+}
+
+__device__ __forceinline__ float log_ndtr_f(float x) {
+    if (x > 5.0f) return -ndtr_f(-x);
+    if (x > -10.0f) return logf(ndtr_f(x));
+    const float x2 = x * x;
+    const float series = 1.0f + 3.0f / (x2 * x2) - (1.0f / x2 + 15.0f / (x2 * x2 * x2));
+    return -0.5f * x2 - logf(-x) - 0.91893853320467274f + logf(series);
+}
+
+__global__ __launch_bounds__(256) void k_noisy_normal_bits(const float *__restrict__ y, const float *__restrict__ index, int64_t n,
+                                                          float a, float b, float h, float *__restrict__ dy,
+                                                          float *__restrict__ di, float *__restrict__ partial) {
+    __shared__ float s_part[4];
+    float acc = 0.0f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float yy = y[e];
+        const float s = expf(a + b * index[e]);
+        const float inv = 1.0f / s;
+        const float zp = (yy + h) * inv, zm = (yy - h) * inv;
+        const float logcdf_p = log_ndtr_f(zp), logsf_p = log_ndtr_f(-zp);
+        const bool right = logsf_p < logcdf_p;
+        const float big = right ? log_ndtr_f(-zm) : logcdf_p;
+        const float small = right ? logsf_p : log_ndtr_f(zm);
+        const float lp = big + log1pf(-expf(small - big));
+        acc += lp;
+        const float ep = expf(-0.5f * zp * zp - 0.91893853320467274f - lp);
+        const float em = expf(-0.5f * zm * zm - 0.91893853320467274f - lp);
+        if (dy) dy[e] = (ep - em) * inv;
+        if (di) di[e] = -b * (zp * ep - zm * em);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ void k_sum_partials(const float *__restrict__ partial, int blocks, float *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < blocks; ++i) t += partial[i];
+        out[0] = t;
+    }
+}
+
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int64_t fpcc_noisy_normal_ws_bytes(int64_t n) { return n < 0 ? FPCC_E_ARG : (int64_t)dfac_blocks(n) * 4; }
+
+extern "C" int fpcc_noisy_normal_bits_f32(const float *y, const float *index, int64_t n, float log_scale_offset,
+                                          float log_scale_factor, float half_width, float *dy, float *dindex, float *out,
+                                          void *ws, int64_t ws_bytes, void *stream) {
+    if (n < 0) return fail_arg("noisy_normal_bits: n < 0");
+    if (!out || (n > 0 && (!y || !index))) return fail_arg("noisy_normal_bits: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (n == 0) return check_hip(hipMemsetAsync(out, 0, 4, s), "hipMemsetAsync");
+    const int blocks = dfac_blocks(n);
+    if (!ws || ws_bytes < (int64_t)blocks * 4) return fail_arg("noisy_normal_bits: workspace too small");
+    hipLaunchKernelGGL(k_noisy_normal_bits, dim3(blocks), dim3(256), 0, s, y, index, n, log_scale_offset, log_scale_factor,
+                       half_width, dy, dindex, static_cast<float *>(ws));
+    if (int rc = check_hip(hipGetLastError(), "k_noisy_normal_bits")) return rc;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, static_cast<const float *>(ws), blocks, out);
+    return check_hip(hipGetLastError(), "k_sum_partials");
+}

@@ -188,6 +188,12 @@ class DistributionQuantizedCDFTable(nn.Module):
         self.requires_updating_cdf_table = True
         self.range_coder = IndexedRansCoder(overflow_coding, coding_batch_size)
 
+    def update_base(self, new_base):
+        """swap in a re-parameterised prior of the same shape (continuous_base.py:53-57)"""
+        if type(new_base) is not type(self.base) or new_base.batch_shape != self.base.batch_shape:
+            raise ValueError('the new prior must have the type and batch shape of the old one')
+        self.base = new_base
+
     @property
     def batch_shape(self):
         return self.base.batch_shape

@@ -36,6 +36,8 @@ _SIGS = {
                                    _vp, _i64, _vp]),
     'fpcc_epilogue_bwd_ws_bytes': (_i64, [_i64, _i32]),
     'fpcc_epilogue_bwd_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_noisy_normal_ws_bytes': (_i64, [_i64]),
+    'fpcc_noisy_normal_bits_f32': (_i32, [_vp, _vp, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_deep_factorized_ws_bytes': (_i64, [_i64, _i32]),
     'fpcc_deep_factorized_bits_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_tile_keys': (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
@@ -381,6 +383,25 @@ def deep_factorized_bits(y: torch.Tensor, weights, biases, factors, half_width: 
     _ok(L.fpcc_deep_factorized_bits_f32(py, n, c, ldy, ptr(weights), ptr(biases), ptr(factors), float(half_width),
                                         None if dy is None else dy.data_ptr(), c, out.data_ptr(), ws.data_ptr(), need, _stream()))
     return out, dy
+
+
+def noisy_normal_bits(y: torch.Tensor, index: torch.Tensor, log_scale_offset: float, log_scale_factor: float,
+                      half_width: float = 0.5):
+    """-> (sum of log-probabilities (0-dim), d/dy [n], d/dindex [n]) of y under N(0, exp(offset + factor * index)) + U(-h, h)"""
+    n = y.numel()
+    if index.numel() != n:
+        raise ValueError('one index per value')
+    index = index.to(torch.float32)
+    py, pi = _dev(y, torch.float32, 'y', n == 0), _dev(index, torch.float32, 'index', n == 0)
+    dy = torch.empty(n, dtype=torch.float32, device=y.device)
+    di = torch.empty(n, dtype=torch.float32, device=y.device)
+    out = torch.empty(1, dtype=torch.float32, device=y.device)
+    L = lib()
+    need = _ok(L.fpcc_noisy_normal_ws_bytes(n))
+    ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=y.device)
+    _ok(L.fpcc_noisy_normal_bits_f32(py, pi, n, float(log_scale_offset), float(log_scale_factor), float(half_width),
+                                     dy.data_ptr(), di.data_ptr(), out.data_ptr(), ws.data_ptr(), need, _stream()))
+    return out[0], dy, di
 
 
 def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13,

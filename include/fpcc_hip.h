@@ -239,6 +239,16 @@ int fpcc_deep_factorized_bits_f32(const float *y, int64_t n, int c, int ldy, con
                                   const float *const *biases, const float *const *factors, float half_width,
                                   float *dy, int lddy, float *out, void *ws, int64_t ws_bytes, void *stream);
 
+/* Rate term of the scale-indexed noisy normal (Gaussian-conditional bottleneck, training), element-wise over n values:
+ *     s = exp(log_scale_offset + log_scale_factor * index),   lp = log(Phi((y + h) / s) - Phi((y - h) / s))
+ * out[0] = sum lp (fixed reduction order);  dy / dindex (either may be NULL): its derivatives.  log Phi in the three segments
+ * of lib/entropy_models/distributions/special_math.py:138-258, the survival side right of the median as in
+ * distributions/uniform_noise.py:36-63; behind the bits loss of continuous_indexed.py:145-159 with the parameter functions of
+ * :265-273 (`ScaleNoisyNormalEntropyModel`, hyperprior/noisy_deep_factorized/basic.py:158-203). */
+int64_t fpcc_noisy_normal_ws_bytes(int64_t n);
+int fpcc_noisy_normal_bits_f32(const float *y, const float *index, int64_t n, float log_scale_offset, float log_scale_factor,
+                               float half_width, float *dy, float *dindex, float *out, void *ws, int64_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Geometry distortion (D1, point-to-point)                                                                       */
 /* ------------------------------------------------------------------------------------------------------------ */

@@ -20,6 +20,7 @@ Sources of truth used:
 import hashlib
 import importlib.util
 import json
+import math
 import os
 import re
 import sys
@@ -265,6 +266,65 @@ def make_entropy_model():
     return out
 
 
+def make_entropy_model_indexed():
+    """lib/entropy_models/continuous_indexed.py + distributions/{uniform_noise,special_math}.py, imported with the same two
+    stubs as make_entropy_model: log_ndtr, the noisy normal, index bounding / flattening, the CDF grid of the scale-indexed
+    model, strings of a seeded input and the training rate with its gradients (no noise, so that it is reproducible)."""
+    import torch
+    import rans_ext_cpp as R
+    stub_rc = types.ModuleType('lib.entropy_models.rans_coder')
+    stub_rc.IndexedRansCoder = R.IndexedRansCoder
+    stub_wr = types.ModuleType('lib.minkowski_sparse_conv_layers')
+    stub_wr.minkowski_tensor_wrapped_fn = lambda *a, **k: (lambda f: f)
+    stub_wr.minkowski_tensor_wrapped_op = lambda *a, **k: (lambda f: f)
+    sys.modules['lib.entropy_models.rans_coder'] = stub_rc
+    sys.modules['lib.minkowski_sparse_conv_layers'] = stub_wr
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from lib.entropy_models.continuous_indexed import ContinuousIndexedEntropyModel as RefEM, \
+        noisy_scale_normal_indexed_entropy_model_init as ref_init
+    from lib.entropy_models.distributions.uniform_noise import NoisyNormal as RefNN
+    from lib.entropy_models.distributions import special_math as sm
+    tl = lambda t: t.detach().to(torch.float64).flatten().tolist()
+    out = {}
+    xs = torch.tensor([-40.0, -30.0, -12.0, -10.0001, -10.0, -9.99, -7.5, -5.0, -1.0, -0.3, 0.0, 0.3, 1.0, 4.99, 5.0, 5.01, 8.0, 20.0])
+    out['log_ndtr'] = {'x': tl(xs), 'f32': tl(sm.log_ndtr(xs)), 'f64': tl(sm.log_ndtr(xs.double()))}
+    ys = torch.tensor([-70.0, -20.0, -6.0, -2.0, -1.0, -0.4, 0.0, 0.25, 1.0, 3.0, 9.0, 33.0, 64.0])[:, None]
+    scales = torch.tensor([0.11, 0.5, 1.0, 3.7, 40.0, 256.0])[None]
+    nn_ = RefNN(0, scales)
+    out['noisy_normal'] = {'y': tl(ys), 'scale': tl(scales), 'log_prob': tl(nn_.log_prob(ys)), 'prob': tl(nn_.prob(ys))}
+
+    cases = []
+    for seed, kw in ((1, {}), (2, {'indexes_scaler': 0.5, 'indexes_offset': 2.0}), (3, {'quantize_bottleneck_in_eval': True, 'lower_bound': -20, 'upper_bound': 30})):
+        torch.manual_seed(seed)
+        em = RefEM(RefNN, (64,), ref_init(0.11, 256, 64), coding_ndim=2, bottleneck_process='', **kw)
+        n, c = 120, 5
+        idx = (torch.rand(1, n, c) * 75 - 6) / kw.get('indexes_scaler', 1) - kw.get('indexes_offset', 0)     # some out of range
+        x = torch.randn(1, n, c) * torch.exp(math.log(0.11) + (math.log(256 / 0.11) / 63) * idx.clamp(0, 63) * 0.6)
+        case = {'seed': seed, 'kw': kw, 'n': n, 'c': c, 'x': tl(x), 'indexes': tl(idx)}
+        case['bounded'] = tl(em.bound_indexes(idx))
+        case['flat'] = em.flatten_indexes(em.bound_indexes(idx)).flatten().tolist()
+        em.train()
+        xg, ig = x.clone().requires_grad_(), idx.clone().requires_grad_()
+        y, loss = em(xg, ig)
+        loss['bits_loss'].backward()
+        case['train'] = {'bits': loss['bits_loss'].item(), 'dx': tl(xg.grad), 'di': tl(ig.grad), 'y_equals_x': bool(torch.equal(y.detach(), x))}
+        em.eval()
+        table = em.prior.cdf_list
+        case['table_sha'] = hashlib.sha256(json.dumps([list(map(int, r)) for r in table]).encode()).hexdigest()[:16]
+        case['table_rows'] = {str(i): list(map(int, table[i])) for i in (0, 17, 63)}
+        case['offsets'] = list(map(int, em.prior.cdf_offset_list))
+        strings, deq, est = em.compress(x.clone(), idx, estimate_bits=True)
+        case['strings'] = [b.hex() for b in strings]
+        case['estimated_bits'] = est.item()
+        rec = em.decompress(strings, idx, torch.device('cpu'))
+        case['roundtrip'] = bool(torch.equal(rec, deq))
+        case['decoded'] = tl(rec)
+        cases.append(case)
+    out['models'] = cases
+    return out
+
+
 def make_kdtree():
     # lib/data_utils.py imports plyfile / open3d at module level; neither is used by kd_tree_partition
     sys.modules.setdefault('plyfile', types.SimpleNamespace(PlyData=None, PlyElement=None))
@@ -347,7 +407,7 @@ def make_ptq_import():
 
 
 def main():
-    for name, fn in (('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

@@ -82,3 +82,58 @@ def test_rejects_other_networks():
         ops.deep_factorized_bits(y, em.prior_weights[:4], em.prior_biases, em.prior_factors, 0.5)
     with pytest.raises((FpccError, ValueError)):
         ops.deep_factorized_bits(y, [w.cpu() for w in em.prior_weights], em.prior_biases, em.prior_factors, 0.5)
+
+
+# ---- scale-indexed noisy normal (Gaussian-conditional) ---------------------------------------------------------------
+def _indexed(**kw):
+    from fastpcc_amd.entropy_models_indexed import ContinuousIndexedEntropyModel, NoisyNormal, \
+        noisy_scale_normal_indexed_entropy_model_init
+    return ContinuousIndexedEntropyModel(NoisyNormal, (64,), noisy_scale_normal_indexed_entropy_model_init(0.11, 256, 64),
+                                         coding_ndim=2, **kw).cuda()
+
+
+@pytest.mark.parametrize('n,spread', [(1, 1.0), (1000, 1.0), (70001, 3.0), (5000, 12.0)])
+def test_noisy_normal_rate_kernel_against_tensor_ops(n, spread):
+    """values from well inside the density to far in its tails (|y| up to ~12 scales: every segment of log Phi)"""
+    from fastpcc_amd.entropy_models_indexed import NoisyNormal, _NoisyNormalBits
+    a, b = math.log(0.11), math.log(256 / 0.11) / 63
+    torch.manual_seed(n)
+    idx = (torch.rand(n, device='cuda') * 63).requires_grad_()
+    y = (torch.randn(n, device='cuda') * torch.exp(a + b * idx.detach()) * spread).requires_grad_()
+    want = NoisyNormal(0, torch.exp(a + b * idx)).log_prob(y).sum()
+    wy, wi = torch.autograd.grad(want, [y, idx])
+    got = _NoisyNormalBits.apply(y, idx, a, b)
+    gy, gi = torch.autograd.grad(got, [y, idx])
+    assert torch.isfinite(got) and abs(got.item() - want.item()) <= 3e-5 * abs(want.item()) + 1e-4
+    for name, g, w in (('dy', gy, wy), ('di', gi, wi)):
+        assert torch.isfinite(g).all(), name
+        err = (g - w).abs()
+        assert (err <= 2e-3 * w.abs() + 2e-4 * w.abs().max()).all(), (name, err.max().item(), w.abs().max().item())
+
+
+def test_indexed_model_training_forward_uses_the_kernel():
+    em = _indexed(bottleneck_process='')
+    em.train()
+    x = (torch.randn(1, 3000, 4, device='cuda') * 5).requires_grad_()
+    idx = (torch.rand(1, 3000, 4, device='cuda') * 70 - 3).requires_grad_()          # some outside [0, 63]: bounded first
+    y, loss = em(x, idx)
+    assert 'NoisyNormalBits' in type(loss['bits_loss'].grad_fn).__name__ or 'NoisyNormalBits' in str(loss['bits_loss'].grad_fn.next_functions)
+    gx, gi = torch.autograd.grad(loss['bits_loss'], [x, idx])
+    bounded = em.bound_indexes(idx)
+    want = em.make_prior(bounded).log_prob(x).sum() / (-math.log(2))
+    wx, wi = torch.autograd.grad(want, [x, idx])
+    assert abs(loss['bits_loss'].item() - want.item()) <= 3e-5 * want.item()
+    for g, w in ((gx, wx), (gi, wi)):          # far tails: the autograd of the segment approximations vs analytic derivatives
+        assert ((g - w).abs() <= 2e-3 * w.abs() + 2e-4 * w.abs().max()).all()
+    outside = (idx < 0) | (idx > 63)
+    assert ((gi[outside] == 0) == (wi[outside] == 0)).all()                          # the bound's gradient rule applies to both
+
+
+def test_indexed_model_codes_on_the_gpu():
+    em = _indexed().eval()
+    torch.manual_seed(0)
+    idx = torch.rand(1, 2000, 8, device='cuda') * 63
+    x = torch.randn(1, 2000, 8, device='cuda') * torch.exp(math.log(0.11) + math.log(256 / 0.11) / 63 * idx) * 0.5
+    rec, strings = em(x, idx)
+    assert torch.equal(rec, x.round().clamp(-64 - 1e9, 64 + 1e9)) or (rec - x).abs().max() <= 0.5 + 1e-6
+    assert sum(len(s) for s in strings) > 0
