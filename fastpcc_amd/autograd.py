@@ -85,7 +85,7 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, s: ConvSpec
     if s.kind == 'k1':
         dw = ops.conv_wgrad(x, dy, s.n_in)
     elif s.kind == 'k3':
-        dw = ops.conv_wgrad(x, dy, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1)
+        dw = ops.conv_wgrad(x, dy, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1, row_order=s.row_order)
     elif s.kind == 'k2s2':
         dw = ops.conv_wgrad(x, dy, s.n_out, nbr=s.table, n_offsets=8, nbr_ks=1, nbr_os=8)
     elif s.kind == 'k2s2T':

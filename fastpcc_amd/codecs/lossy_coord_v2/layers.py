@@ -123,20 +123,16 @@ class Decoder(nn.Module):
         if not gen.generated or len(self.upsample_blocks) != 1:
             raise NotImplementedError('training-time pruning supports one generative stage (decoder_channels of length 1)')
         logits = pred.F.view(-1, 8)
-        not_max = logits != logits.max(1, keepdim=True).values
         if points_num_list is None:
-            keep = logits > 0
-        else:
-            targets = points_num_list.pop()
-            edges = cm.batch_offsets(gen.parent)
-            keep = torch.zeros_like(not_max)
-            for tgt, a, b in zip(targets, edges[:-1], edges[1:]):
-                sample, nm = logits[a:b], not_max[a:b]
-                if not sample.numel() > tgt:
-                    raise ValueError('fewer candidates than points to keep')
-                thr = torch.kthvalue(sample[nm], sample.numel() - tgt).values
-                keep[a:b] = sample > thr
-        return (keep | ~not_max).view(-1)
+            return ((logits > 0) | (logits == logits.max(1, keepdim=True).values)).view(-1)
+        targets = points_num_list.pop()
+        edges = cm.batch_offsets(gen.parent)
+        keep = torch.empty(logits.numel(), dtype=torch.uint8, device=logits.device)
+        for tgt, a, b in zip(targets, edges[:-1], edges[1:]):
+            if not (b - a) * 8 > tgt:
+                raise ValueError('fewer candidates than points to keep')
+            keep[8 * a: 8 * b] = ops.topk_keep(logits[a:b].reshape(-1), int(tgt))      # the sample's own k-th value
+        return keep.bool()
 
     @torch.no_grad()
     def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None) -> torch.Tensor:

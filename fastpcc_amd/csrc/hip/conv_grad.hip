@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace fpcc {
 namespace {
@@ -121,6 +122,105 @@ __global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma_wide(WgradArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int m = (reg & 3) + 8 * (reg >> 2) + 4 * lh;            // M index of the accumulator row
+            dst[(int64_t)(CB * m + q) * a.c_out] = acc[q][reg];
+        }
+}
+
+// 3x3x3-style maps given in neighbour-pattern row order (fpcc_conv_row_keys): the rows that have kernel offset k are
+// clustered, so the reduction over rows is walked in blocks of 32 positions and a block none of whose rows has the offset
+// is skipped -- a 27-bit mask per block, computed by k_wgrad_blockmask.  On voxelised surfaces each row has ~13 of the 27
+// offsets: in natural order nearly every block has every offset and half of the MFMAs multiply the zero row, in pattern
+// order ~1.1x the useful work is executed.  Operands are fetched one half block (16 rows) ahead of the MFMAs that use
+// them and the row indices (row_order -> nbr) one active block ahead, so the two dependent loads and the gather hide
+// behind 32 MFMAs each.  Geometry as k_wgrad_mfma_wide: 32*CB input channels x all output columns per workgroup.
+__global__ __launch_bounds__(256) void k_wgrad_blockmask(const int32_t *__restrict__ nbr, int n_off, int64_t nbr_ks, int64_t nbr_os,
+                                                         const int32_t *__restrict__ row_order, int64_t n, int64_t n_blocks,
+                                                         uint32_t *__restrict__ masks) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= n_blocks) return;
+    const int64_t pos = b * 32 + lane;
+    const int64_t row = (lane < 32 && pos < n) ? (int64_t)row_order[pos] : -1;
+    uint32_t m = 0;
+    for (int k = 0; k < n_off; ++k) {
+        const bool has = row >= 0 && nbr[(int64_t)k * nbr_ks + row * nbr_os] >= 0;
+        m |= (__ballot(has) != 0ull ? 1u : 0u) << k;
+    }
+    if (lane == 0) masks[b] = m;
+}
+
+template <int NBT, int CB>
+__global__ __launch_bounds__(64 * NBT, 2) void k_wgrad_rows(WgradArgs a, const uint32_t *__restrict__ masks,
+                                                            const int32_t *__restrict__ row_order) {
+    typedef float fvec __attribute__((ext_vector_type(CB)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int s = blockIdx.x, k = blockIdx.y, cg = blockIdx.z;
+    // row split s takes blocks s, s + splits, ...: in pattern order the rows that have an offset are clustered, a
+    // contiguous range per split would give some workgroups all of an offset's blocks and others none
+    const int64_t b_begin = s, b_end = (a.n + 31) / 32, b_step = a.splits;
+    f32x16 acc[CB];
+#pragma unroll
+    for (int q = 0; q < CB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+    auto next_active = [&](int64_t b) {
+        while (b < b_end && !((masks[b] >> k) & 1u)) b += b_step;
+        return b;
+    };
+    // lane l (and l + 32) holds the rows of position 32 b + l: (input row of offset k, output row), -1 when absent
+    auto load_rows = [&](int64_t b, int32_t &in_row, int32_t &out_row) {
+        const int64_t pos = b * 32 + li;
+        out_row = pos < a.n ? row_order[pos] : -1;
+        in_row = out_row >= 0 ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)out_row * a.nbr_os] : -1;
+        if (in_row < 0) out_row = -1;
+    };
+    auto load_half = [&](int half, int32_t in_row, int32_t out_row, fvec (&av)[8], float (&bv)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int src = 16 * half + 2 * j + lh;
+            const int32_t ir = __shfl(in_row, src), orow = __shfl(out_row, src);
+            const float *px = ir >= 0 ? a.x + (int64_t)ir * a.ldx + 32 * CB * cg + CB * li : g_wgrad_zero + CB * li;
+            const float *pd = orow >= 0 ? a.dy + (int64_t)orow * a.ldy + 32 * wave + li : g_wgrad_zero + li;
+            av[j] = *reinterpret_cast<const fvec *>(px);
+            bv[j] = *pd;
+        }
+    };
+    auto mma_half = [&](const fvec (&av)[8], const float (&bv)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < CB; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][q], bv[j], acc[q], 0, 0, 0);
+    };
+
+    int64_t b = next_active(b_begin);
+    if (b < b_end) {
+        int32_t in_row, out_row, in_next, out_next;
+        fvec av0[8], av1[8];
+        float bv0[8], bv1[8];
+        load_rows(b, in_row, out_row);
+        load_half(0, in_row, out_row, av0, bv0);
+        for (;;) {
+            const int64_t bn = next_active(b + b_step);
+            const bool more = bn < b_end;
+            load_rows(more ? bn : b, in_next, out_next);           // unconditional: the last round re-reads its own block
+            load_half(1, in_row, out_row, av1, bv1);
+            mma_half(av0, bv0);
+            load_half(0, in_next, out_next, av0, bv0);
+            mma_half(av1, bv1);
+            if (!more) break;
+            b = bn;
+            in_row = in_next;
+            out_row = out_next;
+        }
+    }
+    float *dst = a.partial + (((int64_t)s * a.n_off + k) * a.c_in + 32 * CB * cg) * a.c_out + 32 * wave + li;
+#pragma unroll
+    for (int q = 0; q < CB; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             dst[(int64_t)(CB * m + q) * a.c_out] = acc[q][reg];
         }
 }
@@ -247,13 +347,14 @@ extern "C" int64_t fpcc_conv_wgrad_ws_bytes(int c_in, int c_out, int n_offsets, 
     if (c_in < 1 || c_out < 1 || n_offsets < 1 || groups < 1 || n < 0) return FPCC_E_ARG;
     const int kg = n_offsets * groups;
     const int splits = pick_splits(c_in, c_out, kg, n, wgrad_mfma_ok(c_in, c_out));
-    return (int64_t)splits * kg * c_in * c_out * 4;
+    return (int64_t)splits * kg * c_in * c_out * 4 + ((n + 31) / 32 + 4) * 4;      // partial sums + one mask per 32 rows
 }
 
 extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int c_out, int ldy,
                                    const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                                    const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
-                                   float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream) {
+                                   const int32_t *row_order, float *dw, int accumulate, void *ws, int64_t ws_bytes,
+                                   void *stream) {
     if (c_in < 1 || c_out < 1 || n_offsets < 1 || groups < 1 || n < 0) return fail_arg("conv_wgrad: sizes out of range");
     if (!dw) return fail_arg("conv_wgrad: null pointer");
     if (!nbr && n_offsets != 1) return fail_arg("conv_wgrad: identity map needs n_offsets == 1");
@@ -268,12 +369,29 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
     if (!x || !dy) return fail_arg("conv_wgrad: null pointer");
     const bool mfma = wgrad_mfma_ok(c_in, c_out);
     const int splits = pick_splits(c_in, c_out, kg, n, mfma);
-    const int64_t need = (int64_t)splits * count * 4;
+    const int64_t need = (int64_t)splits * count * 4 + ((n + 31) / 32 + 4) * 4;
     if (!ws || ws_bytes < need) return fail_arg("conv_wgrad: workspace of fpcc_conv_wgrad_ws_bytes() bytes required");
     const int64_t rows_per_split = ((n + splits - 1) / splits + 31) / 32 * 32;
     WgradArgs a{x, c_in, ldx, dy, c_out, ldy, nbr, n_offsets, nbr_ks, nbr_os, out_map, om_os, om_gs, groups, n,
                 rows_per_split, splits, static_cast<float *>(ws)};
-    if (mfma && c_in % 128 == 0 && aligned16(x) && ldx % 4 == 0) {
+    static const int skip_rows = [] { const char *e = getenv("FPCC_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+    if (skip_rows && mfma && row_order && nbr && !out_map && groups == 1 && n_offsets <= 32 && c_in % 64 == 0 && aligned16(x) &&
+        ldx % 4 == 0 && (c_out == 128 || c_out == 64)) {
+        uint32_t *masks = reinterpret_cast<uint32_t *>(static_cast<float *>(ws) + (int64_t)splits * count);
+        const int64_t n_blocks = (n + 31) / 32;
+        hipLaunchKernelGGL(k_wgrad_blockmask, dim3(blocks_for(n_blocks, 4)), dim3(256), 0, s, nbr, n_offsets, nbr_ks, nbr_os,
+                           row_order, n, n_blocks, masks);
+        if (int rc = check_hip(hipGetLastError(), "k_wgrad_blockmask")) return rc;
+        if (c_in % 128 == 0) {
+            const dim3 grid(splits, kg, c_in / 128);
+            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 4>), grid, dim3(256), 0, s, a, masks, row_order);
+            else hipLaunchKernelGGL((k_wgrad_rows<2, 4>), grid, dim3(128), 0, s, a, masks, row_order);
+        } else {
+            const dim3 grid(splits, kg, c_in / 64);
+            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 2>), grid, dim3(256), 0, s, a, masks, row_order);
+            else hipLaunchKernelGGL((k_wgrad_rows<2, 2>), grid, dim3(128), 0, s, a, masks, row_order);
+        }
+    } else if (mfma && c_in % 128 == 0 && aligned16(x) && ldx % 4 == 0) {
         const dim3 grid(splits, kg, c_in / 128);
         if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma_wide<4, 4>), grid, dim3(256), 0, s, a);
         else if (c_out == 64) hipLaunchKernelGGL((k_wgrad_mfma_wide<2, 4>), grid, dim3(128), 0, s, a);

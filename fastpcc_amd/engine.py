@@ -283,12 +283,14 @@ class CoordinateManager:
     ROW_ORDER_MIN_ROWS = 8192
     ROW_ORDER_WINDOW_LOG2 = int(os.environ.get('FPCC_ROW_WINDOW_LOG2', '17'))
 
-    def _row_order(self, m: _Map) -> Optional[torch.Tensor]:
+    ROW_ORDER_MIN_ROWS_TRAINING = 512         # the weight gradient skips absent (row block, offset) pairs on any map
+
+    def _row_order(self, m: _Map, training: bool = False) -> Optional[torch.Tensor]:
         """permutation of m's rows that groups like neighbour patterns into the same 32-row MFMA block; cached per map and
         shared by every 3x3x3 layer on it"""
-        if m.row_order is False:
+        if m.row_order is False or (m.row_order is None and training and m.n > self.ROW_ORDER_MIN_ROWS_TRAINING):
             m.row_order = None
-            if m.n > self.ROW_ORDER_MIN_ROWS:
+            if m.n > (self.ROW_ORDER_MIN_ROWS_TRAINING if training else self.ROW_ORDER_MIN_ROWS):
                 m.row_order = ops.conv_row_order(self._nbr27(m), 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2)
         return m.row_order
 
@@ -602,7 +604,7 @@ class _ConvBase(nn.Module):
             dst = src
             if coordinates is not None and cm._map(coordinates) is not src:
                 raise NotImplementedError('stride-1 convolution onto a different coordinate map')
-            spec = ConvSpec('k3', src.n, src.n, cm._nbr27(src), cm._row_order(src))
+            spec = ConvSpec('k3', src.n, src.n, cm._nbr27(src), cm._row_order(src, training=True))
         else:
             dst = cm._ensure_parent(src)
             if src.generated:

@@ -32,8 +32,8 @@ _SIGS = {
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
-    'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _i32,
-                                   _vp, _i64, _vp]),
+    'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _vp,
+                                   _i32, _vp, _i64, _vp]),
     'fpcc_epilogue_bwd_ws_bytes': (_i64, [_i64, _i32]),
     'fpcc_epilogue_bwd_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_noisy_normal_ws_bytes': (_i64, [_i64]),
@@ -323,7 +323,8 @@ def sum_i64(values: torch.Tensor) -> torch.Tensor:
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, *, nbr: Optional[torch.Tensor] = None, n_offsets: int = 1,
                nbr_ks: int = 0, nbr_os: int = 1, out_map: Optional[torch.Tensor] = None, om_os: int = 0, om_gs: int = 1,
-               groups: int = 1, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+               groups: int = 1, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+               row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW [groups, n_offsets, c_in, c_out] of the convolution whose forward used these row maps; see fpcc_conv_wgrad_f32"""
     px, c_in, ldx = _rows2d(x, 'x')
     pd, c_out, ldy = _rows2d(dy, 'dy')
@@ -338,8 +339,9 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, *, nbr: Optional[torch
     if om_os == 0:
         om_os = groups
     _ok(L.fpcc_conv_wgrad_f32(px, c_in, ldx, pd, c_out, ldy, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
-                              _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, groups, n, out.data_ptr(),
-                              int(accumulate), ws.data_ptr(), need, _stream()))
+                              _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, groups, n,
+                              _dev(row_order, torch.int32, 'row_order', True), out.data_ptr(), int(accumulate), ws.data_ptr(), need,
+                              _stream()))
     return out
 
 

@@ -167,7 +167,10 @@ int64_t fpcc_conv_wgrad_ws_bytes(int c_in, int c_out, int n_offsets, int groups,
 int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int c_out, int ldy,
                         const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                         const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
-                        float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream);
+                        const int32_t *row_order, float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream);
+/* row_order (NULL = none): the neighbour-pattern permutation of fpcc_conv_row_keys for this nbr table.  Multi-offset maps are
+ * then reduced in that order, in blocks of 32 rows, and a block none of whose rows has the offset is skipped (on surfaces
+ * half of the (row, offset) pairs do not exist); row splits are interleaved.  Same sums in another -- still fixed -- order. */
 
 /* Backward of fpcc_conv_f32's fused epilogue y = act(pre + bias) from the layer OUTPUT y (act: none | ReLU | PReLU with one
  * slope > 0, for which pre < 0 <=> y < 0 and pre = y / slope there):

@@ -170,3 +170,36 @@ def test_fused_epilogue_backward_matches_torch(c, act):
         _close(got_s, slope.grad, 'dslope')
     again = ops.epilogue_bwd(y.detach().float().contiguous(), dy, kind, slope.detach().float() if act == 'prelu' else None, True, False)
     assert torch.equal(again[0], got_g) and torch.equal(again[1], got_b)
+
+
+@pytest.mark.parametrize('c_in,c_out', [(128, 128), (64, 128), (128, 64), (192, 64)])
+def test_weight_gradient_in_pattern_row_order(c_in, c_out):
+    """fpcc_conv_wgrad_f32 with a row order: blocks of 32 rows without the offset are skipped, row splits interleave --
+    the same sums as without it (another association) and as a float64 evaluation"""
+    from fastpcc_amd import hipops as ops
+    xyz = surface_cloud(41, 128, 60000)
+    lvl = oc.Level(batched(xyz), 1)
+    n = lvl.n - 13                                                   # ragged last block
+    table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
+    table[table >= n] = -1                                           # inputs restricted to the first n rows too
+    nbr = torch.from_numpy(table).cuda()
+    order = ops.conv_row_order(nbr, 27, n, 1, n, 13)
+    g = torch.Generator().manual_seed(c_in + c_out)
+    x = torch.randn(n, c_in, generator=g).cuda()
+    dy = torch.randn(n, c_out, generator=g).cuda()
+    plain = ops.conv_wgrad(x, dy, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1)
+    got = ops.conv_wgrad(x, dy, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=order)
+    again = ops.conv_wgrad(x, dy, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=order)
+    assert torch.equal(got, again)                                   # fixed association
+    want = torch.zeros(27, c_in, c_out, dtype=torch.float64, device='cuda')
+    xd, dd = x.double(), dy.double()
+    for k in range(27):
+        rows = (nbr[k] >= 0).nonzero().flatten()
+        want[k] = xd[nbr[k][rows].long()].t() @ dd[rows]
+    scale = want.abs().max().item()
+    assert (got.view(27, c_in, c_out).double() - want).abs().max().item() <= 2e-5 * scale
+    assert (plain.view(27, c_in, c_out).double() - want).abs().max().item() <= 2e-5 * scale
+    # accumulate into an existing gradient
+    base = torch.ones_like(got)
+    ops.conv_wgrad(x, dy, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=order, out=base, accumulate=True)
+    assert torch.allclose(base, got + 1, rtol=0, atol=1e-4 * scale)
