@@ -34,10 +34,27 @@ def _mfma(c_in: int, c_out: int) -> bool:
     return ops.conv_order(c_in, 0, c_out) != 0
 
 
+def _k3_one_channel(x: torch.Tensor, w: torch.Tensor, s: ConvSpec, **epilogue) -> torch.Tensor:
+    """3x3x3 convolution to ONE output channel as in inference (engine.py, 'k3_w'): the dot product of every input row with
+    all 27 offset kernels on the MFMA kernel (a pointwise GEMM to 27 -> 32 columns), then 27 gathered scalars per output
+    row -- instead of 27 gathered rows per output row on the VALU kernel"""
+    c_in = w.shape[-2]
+    wt = torch.zeros((c_in, 32), dtype=w.dtype, device=w.device)
+    wt[:, :27] = w.detach().reshape(27, c_in).t()
+    y = ops.conv_f32(x, wt, 32, s.n_in)
+    return ops.gather_sum(y, s.table, 27, s.n_in, 1, s.n_in, **epilogue)
+
+
+def _one_channel_ok(c_in: int, c_out: int) -> bool:
+    return c_out == 1 and c_in % 32 == 0
+
+
 def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     c_in, c_out = w.shape[-2], w.shape[-1]
     if s.kind == 'k1':
         return ops.conv_f32(x, w.reshape(c_in, c_out), c_out, s.n_in)
+    if s.kind == 'k3' and _one_channel_ok(c_in, c_out):
+        return _k3_one_channel(x, w, s)
     if s.kind == 'k3':
         return ops.conv_f32(x, w, c_out, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
                             row_order=s.row_order if _mfma(c_in, c_out) else None)
@@ -134,6 +151,8 @@ class SparseConvActFn(torch.autograd.Function):
         kw = dict(bias=b, act=act, slope=slope)
         if spec.kind == 'k1':
             y = ops.conv_f32(x, w.reshape(c_in, c_out), c_out, spec.n_in, **kw)
+        elif spec.kind == 'k3' and _one_channel_ok(c_in, c_out):
+            y = _k3_one_channel(x, w, spec, **kw)
         elif spec.kind == 'k3':
             y = ops.conv_f32(x, w, c_out, spec.n_in, nbr=spec.table, n_offsets=27, nbr_ks=spec.n_in, nbr_os=1,
                              row_order=spec.row_order if _mfma(c_in, c_out) else None, **kw)
