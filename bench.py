@@ -31,7 +31,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--resolution', type=int, default=1024, help='1024 -> ~1M voxels (cfg#2)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
-    ap.add_argument('--cpu-resolution', type=int, default=256, help='resolution of the bounded CPU sample')
+    ap.add_argument('--cpu-resolution', type=int, default=512, help='resolution of the bounded CPU sample')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
 
