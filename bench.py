@@ -31,7 +31,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--resolution', type=int, default=1024, help='1024 -> ~1M voxels (cfg#2)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
-    ap.add_argument('--cpu-resolution', type=int, default=512, help='resolution of the bounded CPU sample')
+    ap.add_argument('--cpu-resolution', type=int, default=1024, help='resolution of the CPU sample (1024 = the benchmarked frame itself)')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
 
@@ -74,9 +74,9 @@ def cpu_baseline(cfg, weights, resolution):
     import oracle
     from oracle.codec_v2 import OracleV2
     from fastpcc_amd.engine import summation_order as ME_order
-    from fastpcc_amd.synthetic import batched, body_cloud
+    from fastpcc_amd.synthetic import SCALE, batched, body_cloud
     oracle.build()
-    xyz = body_cloud(resolution, 1.0)
+    xyz = body_cloud(resolution, SCALE.get(resolution, 1.0), seed=2)       # at the default 1024: rank 0's benchmarked frame
     coords = batched(xyz).astype(np.int64)
     o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     o.compress(batched(xyz[: min(len(xyz), 2000)]).astype(np.int64))      # warm-up (library load, thread pool)
@@ -85,7 +85,7 @@ def cpu_baseline(cfg, weights, resolution):
     t1 = time.perf_counter()
     rec = o.decompress(data)
     t2 = time.perf_counter()
-    assert rec.shape[0] == len(xyz)
+    assert len(xyz) - max(16, len(xyz) // 1000) <= rec.shape[0] <= len(xyz)      # ties at the pruning threshold, as on the GPU
     return {'value': round(len(xyz) / (t2 - t0) / 1e6, 5), 'unit': 'Mpoints/s', 'cores': os.cpu_count(), 'kind': 'port',
             'sample': f'same generator at {resolution}^3: {len(xyz)} voxels, 1 encode + 1 decode, '
                       f'enc {t1 - t0:.2f}s dec {t2 - t1:.2f}s, oracle/sparse_conv.c with OpenMP'}
