@@ -466,31 +466,30 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
 namespace fpcc {
 namespace {
 __global__ void k_conv_row_keys(const int32_t *__restrict__ nbr, int n_off, int64_t nbr_ks, int64_t nbr_os, int64_t n,
-                                int window_log2, int64_t *__restrict__ keys) {
+                                int window_log2, int64_t *__restrict__ keys, uint32_t *__restrict__ masks) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n) return;
     uint32_t m = 0;
     for (int k = 0; k < n_off; ++k) m |= (nbr[(int64_t)k * nbr_ks + o * nbr_os] >= 0 ? 1u : 0u) << k;
+    if (masks) masks[o] = m;
     // rank of m in the binary-reflected Gray sequence
     m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
     keys[o] = ((o >> window_log2) << 32) | (int64_t)m;
 }
 
 // one wave per group of `group` (<= 64) consecutive positions of row_order: key = (offsets the group lacks) << 32 | group
-__global__ __launch_bounds__(256) void k_conv_tile_keys(const int32_t *__restrict__ nbr, int n_off, int64_t nbr_ks, int64_t nbr_os,
+__global__ __launch_bounds__(256) void k_conv_tile_keys(const uint32_t *__restrict__ row_masks, int n_off,
                                                         const int32_t *__restrict__ row_order, int64_t n, int group,
                                                         int64_t n_groups, int64_t *__restrict__ keys) {
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (g >= n_groups) return;
     const int64_t pos = g * group + lane;
-    const int64_t row = (lane < group && pos < n) ? (row_order ? (int64_t)row_order[pos] : pos) : -1;
-    int present = 0;
-    for (int k = 0; k < n_off; ++k) {
-        const bool has = row >= 0 && nbr[(int64_t)k * nbr_ks + row * nbr_os] >= 0;
-        present += __ballot(has) != 0ull;
-    }
-    if (lane == 0) keys[g] = ((int64_t)(n_off - present) << 32) | g;
+    uint32_t m = 0;
+    if (lane < group && pos < n) m = row_masks[row_order ? (int64_t)row_order[pos] : pos];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+    if (lane == 0) keys[g] = ((int64_t)(n_off - __popc(m)) << 32) | g;
 }
 
 __global__ void k_conv_regroup_rows(const int32_t *__restrict__ row_order, const int32_t *__restrict__ group_perm, int64_t n,
@@ -504,14 +503,14 @@ __global__ void k_conv_regroup_rows(const int32_t *__restrict__ row_order, const
 }  // namespace
 }  // namespace fpcc
 
-extern "C" int fpcc_conv_tile_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, const int32_t *row_order,
-                                   int64_t n, int group, int64_t *keys_out, void *stream) {
+extern "C" int fpcc_conv_tile_keys(const uint32_t *row_masks, int n_offsets, const int32_t *row_order, int64_t n, int group,
+                                   int64_t *keys_out, void *stream) {
     if (n < 0 || n_offsets < 1 || n_offsets > 32 || group < 1 || group > 64) return fail_arg("conv_tile_keys: sizes out of range");
     const int64_t n_groups = n / group;
     if (n_groups == 0) return FPCC_OK;
-    if (!nbr || !keys_out) return fail_arg("conv_tile_keys: null pointer");
-    hipLaunchKernelGGL(k_conv_tile_keys, dim3(blocks_for(n_groups, 4)), dim3(256), 0, as_stream(stream), nbr, n_offsets, nbr_ks,
-                       nbr_os, row_order, n, group, n_groups, keys_out);
+    if (!row_masks || !keys_out) return fail_arg("conv_tile_keys: null pointer");
+    hipLaunchKernelGGL(k_conv_tile_keys, dim3(blocks_for(n_groups, 4)), dim3(256), 0, as_stream(stream), row_masks, n_offsets,
+                       row_order, n, group, n_groups, keys_out);
     return check_hip(hipGetLastError(), "k_conv_tile_keys");
 }
 
@@ -526,13 +525,13 @@ extern "C" int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *g
 }
 
 extern "C" int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n,
-                                  int window_log2, int64_t *keys_out, void *stream) {
+                                  int window_log2, int64_t *keys_out, uint32_t *masks_out, void *stream) {
     if (n < 0 || n_offsets < 1 || n_offsets > 32 || window_log2 < 5 || window_log2 > 30)
         return fail_arg("conv_row_keys: sizes out of range");
     if (n == 0) return FPCC_OK;
     if (!nbr || !keys_out) return fail_arg("conv_row_keys: null pointer");
     hipLaunchKernelGGL(k_conv_row_keys, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), nbr, n_offsets, nbr_ks,
-                       nbr_os, n, window_log2, keys_out);
+                       nbr_os, n, window_log2, keys_out, masks_out);
     return check_hip(hipGetLastError(), "k_conv_row_keys");
 }
 

@@ -40,9 +40,9 @@ _SIGS = {
     'fpcc_noisy_normal_bits_f32': (_i32, [_vp, _vp, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_deep_factorized_ws_bytes': (_i64, [_i64, _i32]),
     'fpcc_deep_factorized_bits_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _vp]),
-    'fpcc_conv_tile_keys': (_i32, [_vp, _i32, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
+    'fpcc_conv_tile_keys': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     'fpcc_conv_regroup_rows': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
-    'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
+    'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
     'fpcc_conv_f32_order_ex': (_i32, [_i32, _i32, _i32, _i32, _i32, _i64]),
@@ -413,19 +413,25 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
     conv_f32(row_order=...) / conv_i8(row_order=...)"""
     L = lib()
     keys = torch.empty(n, dtype=torch.int64, device=nbr.device)
-    pn = _dev(nbr, torch.int32, 'nbr')
-    _ok(L.fpcc_conv_row_keys(pn, n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(), _stream()))
-    order = sort_keys(keys, 32 + max(1, (n >> window_log2).bit_length()))[1]
     group = 64 if n >= 32 * 1024 else 32              # the tile heights fpcc_conv_f32 uses for these map sizes
     n_groups = n // group
-    if not heaviest_first or n_groups < 2:
+    # with tens of thousands of tiles the launch has no tail worth shaping: heaviest-first pays up to ~8 K tiles
+    heaviest_first = heaviest_first and 2 <= n_groups <= LPT_MAX_GROUPS
+    masks = torch.empty(n, dtype=torch.int32, device=nbr.device) if heaviest_first else None
+    _ok(L.fpcc_conv_row_keys(_dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(),
+                             None if masks is None else masks.data_ptr(), _stream()))
+    order = sort_keys(keys, 32 + max(1, (n >> window_log2).bit_length()))[1]
+    if not heaviest_first:
         return order
     gkeys = torch.empty(n_groups, dtype=torch.int64, device=nbr.device)
-    _ok(L.fpcc_conv_tile_keys(pn, n_offsets, nbr_ks, nbr_os, order.data_ptr(), n, group, gkeys.data_ptr(), _stream()))
+    _ok(L.fpcc_conv_tile_keys(masks.data_ptr(), n_offsets, order.data_ptr(), n, group, gkeys.data_ptr(), _stream()))
     gperm = sort_keys(gkeys, 32 + 6)[1]
     out = torch.empty_like(order)
     _ok(L.fpcc_conv_regroup_rows(order.data_ptr(), gperm.data_ptr(), n, group, out.data_ptr(), _stream()))
     return out
+
+
+LPT_MAX_GROUPS = 8192
 
 
 @functools.lru_cache(maxsize=8192)

@@ -133,15 +133,16 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
  * fpcc_sort_keys (end_bit 63) yields a row_order with like patterns adjacent: on voxelised surfaces ~15 instead of ~24
  * of the 27 offsets per block.  The reference has no counterpart (MinkowskiEngine scatters per offset). */
 int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n, int window_log2,
-                       int64_t *keys_out, void *stream);
+                       int64_t *keys_out, uint32_t *masks_out, void *stream);
+/* masks_out (may be NULL): per row, bit k set iff the row has kernel offset k. */
 /* Heaviest tiles first.  fpcc_conv_tile_keys writes, per group of `group` (<= 64) consecutive positions of row_order
- * (NULL = identity), the key (kernel offsets the group's rows lack) << 32 | group index; sorting the keys (fpcc_sort_keys) gives a
+ * (NULL = identity), from the row masks of fpcc_conv_row_keys, the key (kernel offsets the group's rows lack) << 32 | group index; sorting the keys (fpcc_sort_keys) gives a
  * group permutation with the groups that execute most offsets first, and fpcc_conv_regroup_rows applies it:
  *     out[g * group + r] = row_order[group_perm[g] * group + r]      (the ragged tail of n % group rows stays last).
  * fpcc_conv_f32 takes the tiles of a row order in dispatch order, so with `group` = the tile height (64 rows from 32 Ki rows
  * up, 32 below) the launch ends with its lightest tiles instead of whichever came last. */
-int fpcc_conv_tile_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, const int32_t *row_order, int64_t n,
-                        int group, int64_t *keys_out, void *stream);
+int fpcc_conv_tile_keys(const uint32_t *row_masks, int n_offsets, const int32_t *row_order, int64_t n, int group,
+                        int64_t *keys_out, void *stream);
 int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *group_perm, int64_t n, int group, int32_t *row_order_out,
                            void *stream);
 /* Workspace the shape needs (0 for most).  Multi-offset convolutions (8 <= n_offsets <= 27, groups == 1, C_out in
