@@ -113,6 +113,35 @@ def pc_data_collate_fn(data_list: List[PCData], kd_tree_partition_max_points_num
     return out
 
 
+# ---- LiDAR sweeps (lib/datasets/KITTIOdometry/dataset.py:66-130) -----------------------------------------------------------
+def read_kitti_bin(file_path: str) -> np.ndarray:
+    """KITTI Odometry velodyne sweep: little-endian float32 (x, y, z, reflectance) records -> xyz float32 [n, 3]"""
+    return np.fromfile(file_path, '<f4').reshape(-1, 4)[:, :3].copy()
+
+
+def voxelize_points(xyz, scale: float, device=None):
+    """Float points -> unique voxels on a grid of `scale` cells per unit, the reference's test-time voxelisation
+    (dataset.py:96-101): subtract the per-axis minimum, multiply by `scale` in float32, round half to even, drop duplicates.
+    Runs where the points are (or on `device`): elementwise float32 arithmetic and an integer row-unique give the same voxels
+    as the NumPy original on any device.  -> (int32 [m, 3] sorted lexicographically like np.unique(axis=0), origin float32 [3])"""
+    t = torch.as_tensor(xyz, dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    origin = t.amin(0)
+    grid = ((t - origin) * torch.tensor(scale, dtype=torch.float32, device=t.device)).round().to(torch.int32)
+    return torch.unique(grid, dim=0), origin
+
+
+def kitti_odometry_sample(file_path: str, resolution: float = 4096, device=None) -> PCData:
+    """one test sample as KITTIOdometry.__getitem__ builds it for a .bin sweep (400 m range mapped onto `resolution` cells,
+    inv_transform = (origin, metres per cell), peak value 59.70 + 1 for the distortion metric)"""
+    raw = read_kitti_bin(file_path)
+    scale, inv_scale = (resolution - 1) / 400, 400 / (resolution - 1)
+    vox, origin = voxelize_points(raw, scale, device)
+    inv = torch.cat([origin.cpu().reshape(-1), torch.tensor([inv_scale], dtype=torch.float32)]).to(torch.float32)
+    return PCData(xyz=vox, file_path=[file_path], org_points_num=[raw.shape[0]], resolution=[59.70 + 1], inv_transform=[inv])
+
+
 # ---- PLY ----------------------------------------------------------------------------------------------------------------
 _PLY_TYPES = {'char': 'i1', 'int8': 'i1', 'uchar': 'u1', 'uint8': 'u1', 'short': 'i2', 'int16': 'i2', 'ushort': 'u2',
               'uint16': 'u2', 'int': 'i4', 'int32': 'i4', 'uint': 'u4', 'uint32': 'u4', 'float': 'f4', 'float32': 'f4',

@@ -16,7 +16,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .data import PCData, pc_data_collate_fn, read_ply_file
+from .data import PCData, kitti_odometry_sample, pc_data_collate_fn, read_ply_file
 
 # module path of the reference -> the module of this package that replaces it
 MODEL_MODULES = {
@@ -64,7 +64,7 @@ def build_model(config_path: Optional[str], weights: Optional[str], device: torc
     return model.to(device).eval(), sections
 
 
-def _samples(args) -> List[PCData]:
+def _samples(args, sections: dict) -> List[PCData]:
     out = []
     for path in args.ply or []:
         xyz, rgb = read_ply_file(path)
@@ -72,6 +72,9 @@ def _samples(args) -> List[PCData]:
         res = args.resolution or 1 << int(np.ceil(np.log2(max(int(xyz.max()) + 1, 2))))
         out.append(PCData(xyz=torch.from_numpy(xyz), color=None if rgb is None else torch.from_numpy(rgb.astype(np.float32)),
                           resolution=[res], file_path=[os.path.basename(path)], org_points_num=[len(xyz)]))
+    for path in args.kitti or []:
+        grid = ((sections.get('test') or {}).get('dataset') or {}).get('resolution', 4096)
+        out.append(kitti_odometry_sample(path, args.resolution or grid))
     for spec in args.synthetic or []:
         from .synthetic import SCALE, body_cloud, lidar_cloud
         kind, _, arg = spec.partition(':')
@@ -85,7 +88,7 @@ def _samples(args) -> List[PCData]:
         out.append(PCData(xyz=torch.from_numpy(xyz.astype(np.int32)), resolution=[res], file_path=[f'{spec}.ply'],
                           org_points_num=[len(xyz)]))
     if not out:
-        raise SystemExit('give --ply files or --synthetic frames')
+        raise SystemExit('give --ply files, --kitti sweeps or --synthetic frames')
     return out
 
 
@@ -94,6 +97,7 @@ def main(argv=None):
     ap.add_argument('--config', help="a YAML file of the reference's format (model_module_path / model / test sections)")
     ap.add_argument('--weights', help='checkpoint with state_dict / ema_state_dict')
     ap.add_argument('--ply', nargs='*')
+    ap.add_argument('--kitti', nargs='*', help='KITTI Odometry velodyne sweeps (.bin), voxelised as the reference dataset does')
     ap.add_argument('--synthetic', nargs='*')
     ap.add_argument('--resolution', type=int, default=0)
     ap.add_argument('--results-dir')
@@ -109,7 +113,7 @@ def main(argv=None):
     per_file = {}
     if hasattr(model, 'pre_test_hook'):             # test.py:115-116 (the float LiDAR codec inserts its observers here)
         model.pre_test_hook()
-    for sample in _samples(args):
+    for sample in _samples(args, sections):
         sample.results_dir = os.path.join(args.results_dir, 'bin') if args.results_dir else None
         batch = pc_data_collate_fn([sample], int(limit or 0)).to(device)
         with torch.no_grad():

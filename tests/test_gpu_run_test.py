@@ -53,3 +53,32 @@ def test_driver_on_ply_files(tmp_path, capsys):
         at += 3 + int.from_bytes(data[at:at + 3], 'little')
         parts += 1
     assert at == len(data) and parts >= 2
+
+
+def test_driver_on_a_kitti_sweep_with_the_integer_codec(tmp_path, capsys):
+    """velodyne .bin -> voxelisation of the reference dataset -> lossl_coord_int -> points back in metres: every decoded point is
+    the centre of the voxel of some input point (error <= half a cell per axis)"""
+    from fastpcc_amd.codecs.lossl_coord_int import Config, Model
+    from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+    from fastpcc_amd.data import kitti_odometry_sample, pc_data_collate_fn
+    rng = np.random.default_rng(3)
+    n = 20000
+    r, az = rng.uniform(3, 70, n), rng.uniform(0, 2 * np.pi, n)
+    pts = np.stack([r * np.cos(az), r * np.sin(az), rng.normal(-1.6, 0.3, n), rng.uniform(0, 1, n)], 1).astype('<f4')
+    path = tmp_path / '000001.bin'
+    pts.tofile(path)
+    model = Model(Config(channels=32), 'cuda')
+    randomize_(model, 4)
+    model = model.cuda().eval()
+    sample = kitti_odometry_sample(str(path), 4096, device='cuda')
+    batch = pc_data_collate_fn([PC for PC in [sample]]).to('cuda')
+    out = model(batch)
+    rec = out['pred'].cpu().numpy()                                   # metres, via inv_transform
+    assert rec.shape == (sample.xyz.shape[0], 3)
+    inv = sample.inv_transform[0].numpy()
+    want = sample.xyz.cpu().numpy().astype(np.float32) * inv[3] + inv[:3]
+    assert np.allclose(np.sort(rec.view([('', rec.dtype)] * 3), axis=0).view(rec.dtype).reshape(-1, 3),
+                       np.sort(want.view([('', want.dtype)] * 3), axis=0).view(want.dtype).reshape(-1, 3), atol=1e-4)
+    # the first 16 bytes of the stream carry the transform (model.py: inv_transform prepended for the evaluator)
+    assert out['compressed_bytes'][:16] == sample.inv_transform[0].numpy().astype('<f4').tobytes()
+    assert out['bpp'] > 0
