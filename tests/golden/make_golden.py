@@ -325,6 +325,69 @@ def make_entropy_model_indexed():
     return out
 
 
+def make_entropy_model_hyperprior():
+    """lib/entropy_models/hyperprior/noisy_deep_factorized/basic.py on plain tensors with linear hyper networks: the reference
+    model's state dict (tensors) is stored, so that the same parameters can be loaded; strings, decoded values, estimated
+    bits and the training losses (no noise) are the expected outputs."""
+    import torch
+    import torch.nn as nn
+    import rans_ext_cpp as R
+    stub_rc = types.ModuleType('lib.entropy_models.rans_coder'); stub_rc.IndexedRansCoder = R.IndexedRansCoder
+    stub_wr = types.ModuleType('lib.minkowski_sparse_conv_layers')
+    stub_wr.minkowski_tensor_wrapped_fn = lambda *a, **k: (lambda f: f)
+    stub_wr.minkowski_tensor_wrapped_op = lambda x, op, **k: op(x)
+    stub_wr.get_minkowski_tensor_coords_tuple = lambda x: None
+    stub_tu = types.ModuleType('lib.torch_utils')
+    def concat_loss_dicts(a, b, f=lambda x: x, t=lambda x: x):
+        for k in b:
+            a[f(k)] = a[f(k)] + t(b[k]) if f(k) in a else t(b[k])
+        return a
+    stub_tu.concat_loss_dicts = concat_loss_dicts
+    sys.modules['lib.entropy_models.rans_coder'] = stub_rc
+    sys.modules['lib.minkowski_sparse_conv_layers'] = stub_wr
+    sys.modules['lib.torch_utils'] = stub_tu
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # the reference's decompress passes sparse_tensor_coords_tuple to functions whose decorator (stubbed away here) removes it
+    import lib.entropy_models.continuous_batched as cb, lib.entropy_models.continuous_indexed as ci
+    for cls in (cb.NoisyDeepFactorizedEntropyModel, ci.ContinuousIndexedEntropyModel):
+        plain = cls.decompress
+        cls.decompress = (lambda f: lambda self, *a, sparse_tensor_coords_tuple=None, **k: f(self, *a, **k))(plain)
+    from lib.entropy_models.hyperprior.noisy_deep_factorized import basic as B
+    tl = lambda t: t.detach().to(torch.float64).flatten().tolist()
+    out = []
+    for name in ('scale_normal', 'deep_factorized_transform'):
+        torch.manual_seed(5)
+        c, ch, n = 6, 3, 90
+        if name == 'scale_normal':
+            em = B.ScaleNoisyNormalEntropyModel(nn.Linear(c, ch), nn.Linear(ch, c), torch.Size([ch]), 2, num_scales=32,
+                                                scale_min=0.2, scale_max=40, bottleneck_process='')
+        else:
+            em = B.NoisyDeepFactorizedEntropyModel(nn.Linear(c, ch), nn.Linear(ch, c * 3), torch.Size([ch]), 2,
+                                                   index_ranges=(4, 4, 4), parameter_fns_type='transform',
+                                                   parameter_fns_factory=lambda i, o: nn.Linear(i, o), num_filters=(1, 2, 1),
+                                                   bottleneck_process='')
+        with torch.no_grad():
+            em.hyper_decoder.weight.mul_(3.0)
+        y = torch.randn(1, n, c) * 4
+        state = {k: (tl(v), list(v.shape)) for k, v in em.state_dict().items() if isinstance(v, torch.Tensor)}
+        em.train()
+        yg = y.clone().requires_grad_()
+        y_tilde, loss = em(yg)
+        (loss['bits_loss'] + loss['hyper_bits_loss']).backward()
+        case = {'name': name, 'c': c, 'ch': ch, 'n': n, 'y': tl(y), 'state': state,
+                'train': {'bits_loss': loss['bits_loss'].item(), 'hyper_bits_loss': loss['hyper_bits_loss'].item(), 'dy': tl(yg.grad)}}
+        em.eval()
+        strings, shape, deq, bits = em.compress(y.clone(), estimate_bits=True)
+        case['strings'] = [b.hex() for b in strings]
+        case['coding_batch_shape'] = list(shape)
+        case['estimated_bits'] = bits.item()
+        rec = em.decompress(strings, shape, torch.device('cpu'))
+        case['decoded'] = tl(rec)
+        out.append(case)
+    return out
+
+
 def make_kdtree():
     # lib/data_utils.py imports plyfile / open3d at module level; neither is used by kd_tree_partition
     sys.modules.setdefault('plyfile', types.SimpleNamespace(PlyData=None, PlyElement=None))
@@ -407,7 +470,7 @@ def make_ptq_import():
 
 
 def main():
-    for name, fn in (('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()
