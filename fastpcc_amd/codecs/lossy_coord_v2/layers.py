@@ -160,9 +160,9 @@ class Decoder(nn.Module):
             raise NotImplementedError('get_keep expects the candidates of a generative upsampling')
         logits = pred.F.view(-1)
         if points_num_list is None:
-            # fixed threshold 0: same kernel with a target that makes the k-th value irrelevant is not possible,
-            # so threshold through the general path with k = number of non-positive candidates
-            raise NotImplementedError('adaptive_pruning=False is not part of the in-scope configurations')
+            # adaptive_pruning = False (layers.py:176-180): fixed threshold 0, plus the maximum of every 2x2x2 cell
+            cells = pred.F.view(-1, 8)
+            return ((cells > 0) | (cells == cells.max(1, keepdim=True).values)).view(-1).to(torch.uint8)
         target = points_num_list.pop()
         if len(target) != 1:
             raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')

@@ -267,3 +267,24 @@ def test_edge_inputs(setup):
         model.compress(far)
     with pytest.raises(RuntimeError):
         model.compress(dev.cpu())                                    # no CPU path
+
+
+def test_fixed_threshold_pruning(setup):
+    """adaptive_pruning = False (layers.py:176-180): no point counts in the header, a candidate is kept when its logit is
+    positive or the largest of its 2x2x2 cell -- every parent cell keeps at least one child"""
+    import dataclasses
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    cfg, model, weights, _ = setup
+    fixed = Model(dataclasses.replace(cfg, adaptive_pruning=False))
+    fixed.load_state_dict(model.state_dict(), strict=False)
+    fixed = fixed.cuda().eval()
+    xyz, coords = _cloud(61, 128, 20000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    a, b = model.compress(dev), fixed.compress(dev)
+    assert len(a) - len(b) == 3 * (len(model.encoder.blocks) - 1) and a[6 + 3 * (len(model.encoder.blocks) - 1):] == b[6:]
+    rec = fixed.decompress(b).cpu().numpy()
+    assert rec.shape[1] == 3 and len(rec) > 0
+    parents_in = {tuple(p) for p in (xyz >> 1).tolist()}
+    parents_out = {tuple(p) for p in (rec >> 1).tolist()}
+    assert parents_out == parents_in                      # the lossless part is exact; each of its cells keeps its maximum
+    assert len(np.unique(rec, axis=0)) == len(rec)
