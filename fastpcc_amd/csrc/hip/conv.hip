@@ -440,6 +440,11 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
         if (c_out == 64) return launch_split<2, 32>(a, s);
         return launch_split<1, 32>(a, s);
     }
+    // Narrow layers with 48 input channels (3 chunks of 16: 8 MFMAs between two barriers) on large maps are bound by the
+    // gathers and the barriers: one stage per kernel offset (CH = 48) has a third as many.  Same per-element chain (the
+    // chunks were walked in sequence anyway).  With 64 input channels (2 chunks of 32) the same change loses 2-15 %.
+    if (ch == 16 && c2 == 0 && c1 == 48 && c_out <= 64 && n_out * (int64_t)groups >= 32 * 1024)
+        return c_out == 64 ? launch_mfma_cfg<2, 48, 4, 1>(a, s) : launch_mfma_cfg<1, 48, 4, 1>(a, s);
     if (ch == 32) {
         if (c_out == 128) return launch_mfma<4, 32>(a, s);
         if (c_out == 64) return launch_mfma<2, 32>(a, s);

@@ -202,7 +202,7 @@ def test_engine_layers_match_oracle_orders(ops, scene):
             assert (_bits(out.F.cpu().numpy()) == _bits(want)).all(), c_in
 
 
-@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (64, 0, 64), (16, 0, 64)])
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (64, 0, 64), (16, 0, 64), (48, 0, 32), (48, 0, 64)])
 def test_row_order_changes_no_result(ops, c1, c2, c_out):
     """neighbour-pattern row order (fpcc_conv_row_keys + sort): a permutation, windows respected, and the convolution in
     that order is bit-identical to the natural order and to the oracle chain"""
