@@ -693,13 +693,14 @@ class _ConvBase(nn.Module):
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
                                    nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
-                                   clip=clip, row_order=cm._row_order(src))[:, :c_out]
+                                   clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
             else:
                 mfma = ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out) != 0
                 out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1,
-                                   row_order=cm._row_order(src) if mfma else None, **kw)
+                                   # 16 input channels: one 64-byte gather per neighbour -- Morton locality beats block skipping
+                                   row_order=cm._row_order(src) if mfma and x1.shape[1] + (0 if x2 is None else x2.shape[1]) > 16 else None, **kw)
         else:   # kernel 2, stride 2
             dst = cm._ensure_parent(src)
             if src.generated:
