@@ -134,6 +134,46 @@ def test_standalone_epilogues(ops):
     assert (got == oi.prelu_i32(s, int(slope[0]))).all()
 
 
+def test_grouped_epilogue_and_occupied_octant_linear(ops):
+    """epilogue with one parameter set per row group, and the linear layer C -> 8C evaluated for the occupied (row, octant)
+    pairs only (an 8-offset gather convolution with one table entry per output row) against the dense evaluation"""
+    rng = np.random.default_rng(11)
+    n, c_in, ch = 3000, 64, 48
+    x = rng.integers(-127, 128, (n, c_in)).astype(np.int8)
+    w = rng.integers(-127, 128, (8 * ch, c_in)).astype(np.int8)
+    bias = rng.integers(-30000, 30000, 8 * ch).astype(np.int32)
+    mul = rng.integers(1 << 8, 1 << 20, 8 * ch).astype(np.int64)
+    bits = rng.random((n, 8)) < 0.3
+    bits[np.arange(n), rng.integers(0, 8, n)] = True
+    dense = oi.epilogue(oi.conv_i8(x, None, w[None], None), bias, None, mul, 0, 9, 32).reshape(n, 8, ch)[bits]
+    rows, octs = np.nonzero(bits)
+    m = len(rows)
+    table = np.zeros(((m + 127) // 128 * 128, 8), np.int32)
+    table[np.arange(m), octs] = rows + 1
+    from fastpcc_amd.int_sparse_conv import _pad_weight
+    wd = _pad_weight(_cuda(w.reshape(8, ch, c_in)))
+    raw = ops.conv_i8(_cuda(x), wd, c_in, ch, m, nbr=_cuda(table), n_offsets=8, nbr_ks=1, nbr_os=8, nbr_bias=1)
+    got = ops.epilogue_i32(raw, _cuda(mul), _cuda(np.array([0], np.int64)), 9, 32, bias=_cuda(bias),
+                           row_group=_cuda(octs.astype(np.int32)))
+    assert (got.cpu().numpy() == dense).all()
+    with pytest.raises(ValueError):
+        ops.epilogue_i32(raw, _cuda(mul[:ch + 1]), None, 9, 32, row_group=_cuda(octs.astype(np.int32)))
+
+
+def test_conv_i8_row_order_changes_nothing(ops, cloud):
+    rng = np.random.default_rng(5)
+    n = len(cloud)
+    a = _cuda(rng.integers(-127, 128, (n, 64)).astype(np.int8))
+    from fastpcc_amd.int_sparse_conv import _pad_weight
+    w = _pad_weight(_cuda(rng.integers(-127, 128, (27, 128, 64)).astype(np.int8)))
+    _, _, t = _table_gpu(ops, cloud, cloud, (3, 3, 3), (1, 1, 1))
+    order = ops.conv_row_order((t - 1).contiguous(), 27, 1, 27, n, 17)
+    assert sorted(order.cpu().tolist()) == list(range(n))
+    kw = dict(nbr=t, n_offsets=27, nbr_ks=1, nbr_os=27, nbr_bias=1)
+    plain = ops.conv_i8(a, w, 64, 128, n, **kw)
+    assert torch.equal(ops.conv_i8(a, w, 64, 128, n, row_order=order, **kw), plain)
+
+
 @pytest.mark.parametrize('c', [255, 256, 2, 17])
 def test_softmax_and_cdf(ops, c):
     rng = np.random.default_rng(c)
