@@ -303,3 +303,14 @@ def test_offset_split_needs_its_workspace(ops):
     rc = L.fpcc_conv_f32(x.data_ptr(), 128, 128, None, 0, 0, nbr.data_ptr(), 27, 64, 1, w.data_ptr(), None, 128, 1, None, 1, 1,
                          out.data_ptr(), 128, 64, 0, None, 0.0, None, None, 0, None)
     assert rc != 0 and b'workspace' in L.fpcc_last_error()
+
+
+@pytest.mark.parametrize('n', [1, 31, 64, 65, 200])
+def test_row_order_on_tiny_maps(ops, n):
+    """fewer rows than one or two tile groups: the heaviest-first regrouping degenerates gracefully"""
+    xyz = surface_cloud(36, 32, 2000)
+    lvl = oc.Level(batched(xyz), 1)
+    table = oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)[:, :n].copy()
+    table[table >= n] = -1
+    order = ops.conv_row_order(_cuda(table), 27, n, 1, n, 5)
+    assert sorted(order.cpu().tolist()) == list(range(n))

@@ -137,3 +137,15 @@ def test_indexed_model_codes_on_the_gpu():
     rec, strings = em(x, idx)
     assert torch.equal(rec, x.round().clamp(-64 - 1e9, 64 + 1e9)) or (rec - x).abs().max() <= 0.5 + 1e-6
     assert sum(len(s) for s in strings) > 0
+
+
+def test_rate_kernels_on_empty_and_tiny_inputs():
+    from fastpcc_amd import hipops as ops
+    em = _model(4, seed=1)
+    out, dy = ops.deep_factorized_bits(torch.empty(0, 4, device='cuda'), em.prior_weights, em.prior_biases, em.prior_factors, 0.5)
+    assert out.shape == (4, 59) and float(out.abs().sum()) == 0 and dy.shape == (0, 4)
+    total, dy, di = ops.noisy_normal_bits(torch.empty(0, device='cuda'), torch.empty(0, device='cuda'), -2.0, 0.1)
+    assert float(total) == 0 and dy.numel() == 0 and di.numel() == 0
+    total, dy, di = ops.noisy_normal_bits(torch.tensor([0.0], device='cuda'), torch.tensor([0.0], device='cuda'), 0.0, 0.0)
+    want = math.log(math.erf(0.5 / math.sqrt(2)))                      # P(|N(0,1)| < 0.5)
+    assert abs(float(total) - want) < 1e-6 and abs(float(dy[0])) < 1e-6
