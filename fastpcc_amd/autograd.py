@@ -82,13 +82,13 @@ def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     c_in, c_out = w.shape[-2], w.shape[-1]
     if s.kind == 'k1':
         return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out),
-                     w.reshape(c_in, c_out).t().contiguous(), c_in, s.n_in, dy.device)
+                     ops.transpose_weights(w, 1, c_in, c_out, flip=False).view(c_out, c_in), c_in, s.n_in, dy.device)
     if s.kind == 'k3':
-        wt = w.flip(0).transpose(1, 2).contiguous()                       # W'[k] = W[26-k]^T
+        wt = ops.transpose_weights(w, 27, c_in, c_out, flip=True)         # W'[k] = W[26-k]^T
         return _wide(lambda wk, c, out: ops.conv_f32(dy, wk, c, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
                                                      row_order=s.row_order if _mfma(c_out, c) else None, out=out),
                      wt, c_in, s.n_in, dy.device)
-    wt = w.reshape(8, c_in, c_out).transpose(1, 2).contiguous()             # [8][c_out][c_in]
+    wt = ops.transpose_weights(w, 8, c_in, c_out, flip=False)               # [8][c_out][c_in]
     if s.kind == 'k2s2':                                                   # children <- parents: transposed form
         return ops.conv_f32(dy, wt, c_in, s.n_out, groups=8, out_map=s.table, om_os=8, om_gs=1, out_rows=s.n_in)
     if s.kind == 'k2s2T':                                                  # parents <- children: strided form
@@ -205,7 +205,5 @@ class BoundFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, bound = ctx.saved_tensors
-        g = g.clone()
-        g[x > bound] = 1
-        g[x < -bound] = -1
-        return g, None
+        one = torch.ones((), dtype=g.dtype, device=g.device)
+        return torch.where(x > bound, one, torch.where(x < -bound, -one, g)), None      # no mask indexing: that would synchronise

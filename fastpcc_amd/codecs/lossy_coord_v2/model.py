@@ -83,7 +83,9 @@ class PCC(nn.Module):
 
     def train_forward(self, batched_coord: torch.Tensor, training_step: int, batch_size: int) -> dict:
         """rate + distortion objective of one batch (model.py:156-191): returns {'loss': tensor with the autograd graph,
-        every other term as a float}"""
+        every other term detached}.  The reference converts the other terms to floats right here (`.item()`, one device
+        synchronisation per term BEFORE the backward pass is queued); they stay 0-dim device tensors and whoever logs them
+        (fastpcc_amd.train.Trainer.step) reads them after the update has been enqueued."""
         sparse_pc = self.get_sparse_pc(batched_coord)
         feature, points_num_list = self.encoder(sparse_pc)
         bottleneck_feature, loss_dict = self.em_lossless_based(feature, batch_size)
@@ -103,7 +105,7 @@ class PCC(nn.Module):
         loss_dict['loss'] = sum(loss_dict.values())
         for key in loss_dict:
             if key != 'loss':
-                loss_dict[key] = loss_dict[key].item()
+                loss_dict[key] = loss_dict[key].detach()
         return loss_dict
 
     # ---------------------------------------------------------------------------------------------------------------

@@ -517,3 +517,29 @@ extern "C" int fpcc_epilogue_bwd_f32(const float *y, int ldy, const float *dy, i
                        dbias, dslope);
     return check_hip(hipGetLastError(), "k_epilogue_bwd_reduce");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weights of the input-gradient convolution: wt[k][co][ci] = w[flip ? K-1-k : k][ci][co] (the mirrored offset's kernel,
+// transposed) in one pass -- two tensor ops (flip + transposed copy) per layer and step otherwise.
+namespace fpcc {
+namespace {
+__global__ void k_transpose_weights(const float *__restrict__ w, int K, int c_in, int c_out, int flip, float *__restrict__ wt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)c_in * c_out;
+    if (e >= K * per) return;
+    const int k = (int)(e / per);
+    const int r = (int)(e - k * per);
+    const int co = r / c_in, ci = r - co * c_in;
+    wt[e] = w[(int64_t)(flip ? K - 1 - k : k) * per + (int64_t)ci * c_out + co];
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int fpcc_transpose_weights_f32(const float *w, int n_offsets, int c_in, int c_out, int flip, float *wt, void *stream) {
+    if (n_offsets < 1 || c_in < 1 || c_out < 1) return fail_arg("transpose_weights: sizes out of range");
+    if (!w || !wt) return fail_arg("transpose_weights: null pointer");
+    const int64_t total = (int64_t)n_offsets * c_in * c_out;
+    hipLaunchKernelGGL(k_transpose_weights, dim3(blocks_for(total, 256)), dim3(256), 0, as_stream(stream), w, n_offsets, c_in,
+                       c_out, flip, wt);
+    return check_hip(hipGetLastError(), "k_transpose_weights");
+}

@@ -746,7 +746,8 @@ def _finish_autograd(out: torch.Tensor, bias: Optional[torch.Tensor], act: _Act,
         out = torch.relu(out)
     if clip > 0:
         from .autograd import BoundFunction
-        out = BoundFunction.apply(out, torch.tensor(float(clip), device=out.device))
+        from .entropy_models import scalar_tensor
+        out = BoundFunction.apply(out, scalar_tensor(float(clip), torch.float32, out.device).view(()))
     return out
 
 

@@ -12,6 +12,7 @@ is a restatement, not a copy: the density is evaluated by one function over stac
 Distribution class hierarchy.  Pinned against golden values produced by the reference (tests/golden/entropy_model.json).
 """
 import io
+import functools
 import math
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -40,8 +41,15 @@ class _Bound(torch.autograd.Function):
         return ok * g, None, None
 
 
+@functools.lru_cache(maxsize=256)
+def scalar_tensor(value: float, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """a 1-element constant on `device`, made once: torch.tensor(..., device=cuda) is a host-to-device copy from pageable
+    memory, which waits for the stream -- inside a training step that is a stall per call"""
+    return torch.tensor([value], dtype=dtype, device=device)
+
+
 def _as_bound(x, bound):
-    return bound if isinstance(bound, torch.Tensor) else torch.tensor([bound], dtype=x.dtype, device=x.device)
+    return bound if isinstance(bound, torch.Tensor) else scalar_tensor(float(bound), x.dtype, x.device)
 
 
 def lower_bound(x: torch.Tensor, bound, gradient: str = 'identity_if_towards') -> torch.Tensor:
@@ -77,7 +85,7 @@ def grad_scaler(x: torch.Tensor, scaler) -> torch.Tensor:
     if not isinstance(scaler, torch.Tensor):
         if scaler == 1.0:
             return x
-        scaler = torch.tensor([scaler], dtype=x.dtype, device=x.device)
+        scaler = scalar_tensor(float(scaler), x.dtype, x.device)
     return _GradScale.apply(x.clone(), scaler)
 
 

@@ -31,6 +31,7 @@ _SIGS = {
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
+    'fpcc_transpose_weights_f32': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _vp,
                                    _i32, _vp, _i64, _vp]),
@@ -343,6 +344,16 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, *, nbr: Optional[torch
                               _dev(row_order, torch.int32, 'row_order', True), out.data_ptr(), int(accumulate), ws.data_ptr(), need,
                               _stream()))
     return out
+
+
+def transpose_weights(w: torch.Tensor, n_offsets: int, c_in: int, c_out: int, flip: bool) -> torch.Tensor:
+    """[n_offsets, c_in, c_out] -> [n_offsets, c_out, c_in] with the offsets mirrored when `flip` (input-gradient kernels)"""
+    w = w.detach()
+    if w.numel() != n_offsets * c_in * c_out or not w.is_contiguous():
+        raise ValueError('weights must be contiguous [n_offsets, c_in, c_out]')
+    wt = torch.empty((n_offsets, c_out, c_in), dtype=torch.float32, device=w.device)
+    _ok(lib().fpcc_transpose_weights_f32(_dev(w, torch.float32, 'w'), n_offsets, c_in, c_out, int(flip), wt.data_ptr(), _stream()))
+    return wt
 
 
 def epilogue_bwd(y: torch.Tensor, dy: torch.Tensor, act: int, slope: Optional[torch.Tensor], want_bias: bool,

@@ -122,9 +122,11 @@ class Trainer:
                     opt.zero_grad(set_to_none=True)
             refresh_prelu_cache(unwrap(self.model))       # host copy of the PReLU slopes' signs for the fused training node
         self.micro_step += 1
-        out = dict(out)
-        out['loss'] = float(out['loss'].detach())
-        return out
+        # one read-back for every logged term, after the whole step has been queued
+        keys = list(out)
+        vals = torch.stack([out[k].detach().reshape(()).float() if isinstance(out[k], torch.Tensor) else torch.tensor(float(out[k]))
+                            .to(out['loss'].device) for k in keys]).tolist()
+        return dict(zip(keys, vals))
 
     def end_epoch(self):
         for s in self.schedulers:

@@ -169,6 +169,8 @@ int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int 
                         const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                         const int32_t *out_map, int64_t om_os, int64_t om_gs, int groups, int64_t n,
                         const int32_t *row_order, float *dw, int accumulate, void *ws, int64_t ws_bytes, void *stream);
+/* Kernel of the input-gradient convolution: wt[k][co][ci] = w[flip ? n_offsets-1-k : k][ci][co] (fastpcc_amd/autograd.py). */
+int fpcc_transpose_weights_f32(const float *w, int n_offsets, int c_in, int c_out, int flip, float *wt, void *stream);
 /* row_order (NULL = none): the neighbour-pattern permutation of fpcc_conv_row_keys for this nbr table.  Multi-offset maps are
  * then reduced in that order, in blocks of 32 rows, and a block none of whose rows has the offset is skipped (on surfaces
  * half of the (row, offset) pairs do not exist); row splits are interleaved.  Same sums in another -- still fixed -- order. */

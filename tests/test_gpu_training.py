@@ -42,8 +42,10 @@ def test_loss_terms_and_gradients(setup):
     assert 'fea_bottom_bits_loss' in keys and 'coord_0_recon_loss' in keys
     assert sum(k.startswith('coord_') and k.endswith('bits_loss') for k in keys) == 6
     assert sum(k.startswith('fea_') and k.endswith('bits_loss') for k in keys) == 11
-    assert all(isinstance(out[k], float) and np.isfinite(out[k]) for k in keys)
-    assert float(out['loss'].detach()) == pytest.approx(sum(out[k] for k in keys), rel=1e-5)
+    # the other terms: detached 0-dim device tensors (read back by the trainer after the step is queued)
+    assert all(isinstance(out[k], torch.Tensor) and not out[k].requires_grad and out[k].dim() == 0 for k in keys)
+    assert all(np.isfinite(float(out[k])) for k in keys)
+    assert float(out['loss'].detach()) == pytest.approx(sum(float(out[k]) for k in keys), rel=1e-5)
     out['loss'].backward()
     missing = [n for n, p in model.named_parameters() if p.grad is None]
     assert not missing, missing
@@ -52,8 +54,8 @@ def test_loss_terms_and_gradients(setup):
     # warm-up weighting of the feature-rate terms (model.py:169-184)
     late = _loss(model, coords, step=cfg.warmup_fea_loss_steps + 1)
     ratio = cfg.bits_loss_factor / cfg.warmup_fea_loss_factor
-    assert late['fea_bottom_bits_loss'] == pytest.approx(out['fea_bottom_bits_loss'] * ratio, rel=1e-4)
-    assert late['coord_0_recon_loss'] == pytest.approx(out['coord_0_recon_loss'], rel=1e-5)
+    assert float(late['fea_bottom_bits_loss']) == pytest.approx(float(out['fea_bottom_bits_loss']) * ratio, rel=1e-4)
+    assert float(late['coord_0_recon_loss']) == pytest.approx(float(out['coord_0_recon_loss']), rel=1e-5)
 
 
 @pytest.mark.parametrize('name', ['encoder.blocks.1.1.conv.kernel',
