@@ -168,7 +168,9 @@ class Model(int_model.Model):
         rows = self._to_host_u16(self.batch_quantize_pmf_torch(logits))
         out = np.empty(rows.shape[0], dtype=np.uint16)
         self.rans_decoder.decode(rows, out)
-        return torch.from_numpy(out.astype(np.int16)).to(logits.device)
+        symbols = torch.from_numpy(out.astype(np.int16)).to(logits.device)
+        symbols._fpcc_children = int_model._children_count(out)
+        return symbols
 
     def _ones(self, n: int, device) -> torch.Tensor:
         return torch.ones((n, 1), dtype=torch.int8 if self.converted else torch.float32, device=device)

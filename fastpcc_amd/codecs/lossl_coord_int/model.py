@@ -49,7 +49,15 @@ class SparseSequential(nn.Sequential):
         return x
 
 
-def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tensor) -> torch.Tensor:
+def _pairs_of(mask: torch.Tensor, count: Optional[int] = None) -> torch.Tensor:
+    """(row, octant) of the set bits of an [n, 8] mask, row-major.  With the number of set bits known on the host (the next level's row
+    count in the encoder, the popcount of the decoded symbols in the decoder) the device is not synchronised."""
+    if count is None:
+        count = getattr(mask, '_fpcc_count', None)
+    return mask.nonzero() if count is None else torch.nonzero_static(mask, size=int(count))
+
+
+def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tensor, count: Optional[int] = None) -> torch.Tensor:
     """seq(x).F.reshape(n, 8, C)[mask] for a sequence that ends in a linear layer C_in -> 8*C (model.py:66-74,169-175): the
     reference evaluates all 8*C columns of every row and keeps the occupied octants; here the last layer is evaluated for the
     occupied (row, octant) pairs only -- an 8-"offset" gather convolution whose table has one entry per output row, followed by
@@ -58,7 +66,8 @@ def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tens
     last = seq[len(seq) - 1] if len(seq) else None
     if not isinstance(last, LinearIn8W8Out32) or last.out_ch % 8:
         f = seq(x).F
-        return f.reshape(f.shape[0], 8, f.shape[1] // 8)[mask]
+        pairs = _pairs_of(mask, count)
+        return f.reshape(f.shape[0], 8, f.shape[1] // 8)[pairs[:, 0], pairs[:, 1]]
     y = SparseTensor(x.F, x.C, x.stride, x.spatial_range)
     y._caches = x._caches
     for module in list(seq)[:-1]:
@@ -66,7 +75,7 @@ def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tens
             y.F = module(y.F)
         else:
             y = module(y)
-    pairs = mask.nonzero()                                             # (row, octant) of every occupied child, row-major
+    pairs = _pairs_of(mask, count)                                     # (row, octant) of every occupied child, row-major
     n_child, ch = pairs.shape[0], last.out_ch // 8
     octant = pairs[:, 1].to(torch.int32)
     table = torch.zeros(((n_child + 127) // 128 * 128, 8), dtype=torch.int32, device=mask.device)
@@ -81,9 +90,18 @@ def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tens
 
 def _children_of(coords: torch.Tensor, unfold_kernel: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """[N, 4] level-l coordinates + [N, 8] bool occupancy -> coordinates of the occupied children at level l-1"""
-    c = coords[:, None].clone()
-    c[..., 1:] <<= 1
-    return (c + unfold_kernel)[mask]
+    pairs = _pairs_of(mask)
+    c = coords[pairs[:, 0]]
+    c[:, 1:] <<= 1
+    return c + unfold_kernel[0][pairs[:, 1]]
+
+
+_POPCOUNT8 = np.array([bin(v).count('1') for v in range(256)], dtype=np.int64)
+
+
+def _children_count(symbols: np.ndarray) -> int:
+    """occupied children of the decoded symbols (symbol + 1 = the 8 occupancy bits), counted on the host"""
+    return int(_POPCOUNT8[(symbols.astype(np.int64) + 1) & 0xff].sum())
 
 
 def _symbols_of(bits: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
@@ -92,7 +110,9 @@ def _symbols_of(bits: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
 
 
 def _bits_of(symbols: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
-    return ((symbols[:, None].to(torch.int32) + 1) >> bin2oct).bitwise_and_(1).bool()
+    mask = ((symbols[:, None].to(torch.int32) + 1) >> bin2oct).bitwise_and_(1).bool()
+    mask._fpcc_count = getattr(symbols, '_fpcc_children', None)          # set where the symbols came from the host decoder
+    return mask
 
 
 class OneScalePredictor(nn.Module):
@@ -122,7 +142,7 @@ class OneScalePredictor(nn.Module):
 
     def _expand(self, cur_rec: SparseTensor, bits: torch.Tensor, child_coords: torch.Tensor) -> SparseTensor:
         cur_rec.F = torch.cat((cur_rec.F, self._feat(bits)), 1)
-        feats = _occupied_outputs(self.upsample, cur_rec, bits.bool())
+        feats = _occupied_outputs(self.upsample, cur_rec, bits.bool(), child_coords.shape[0])
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in cur_rec.stride))
 
     def compress(self, cur_rec, up_ref: SparseTensor, cur_bin, bin2oct_kernel, if_upsample):
@@ -198,7 +218,7 @@ class OneScaleMultiStepPredictor(nn.Module):
         step i, bits_below[i] (absent for the last step) are the occupancy bits appended as extra channels."""
         cur, last = cur_rec, len(self.pred) - 1
         for i in range(1, last + 1):
-            f = _occupied_outputs(self.pred[i - 1], cur, masks[i - 1].bool())
+            f = _occupied_outputs(self.pred[i - 1], cur, masks[i - 1].bool(), coords[i - 1].shape[0])
             if i != last:
                 f = torch.cat([f, self._feat(bits_below[i - 1])], 1)
             cur = SparseTensor(f, coords[i - 1], strides[i - 1])
@@ -316,7 +336,9 @@ class Model(nn.Module):
         torch.cuda.current_stream().synchronize()                                     # the scale's dependency
         out_h = torch.empty(rows_h.shape[0], dtype=torch.int16, pin_memory=True)
         self.rans_decoder.decode(rows_h.numpy().view(np.uint16), out_h.numpy().view(np.uint16))
-        return out_h.to(logits.device, non_blocking=True)
+        out = out_h.to(logits.device, non_blocking=True)
+        out._fpcc_children = _children_count(out_h.numpy())
+        return out
 
     def rans_encode_fea(self, quantized_cdf: np.ndarray, rounded: np.ndarray):
         self.rans_encoder.encode(quantized_cdf[None], rounded)
