@@ -96,9 +96,10 @@ class PCC(nn.Module):
                 points_num_list = [[int.from_bytes(bs.read(3), 'little', signed=False)]
                                    for _ in range(len(self.cfg.decoder_channels))]
             em_bytes = bs.read()
+        offset = torch.tensor(coord_offset, dtype=torch.int32, device=dev)      # before anything is queued (pageable H2D waits)
         fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
         out = self.decoder(fea_recon, points_num_list)
-        coord = out.C[:, 1:] + torch.tensor(coord_offset, dtype=torch.int32, device=dev)
+        coord = out.C[:, 1:] + offset
         return coord, out.F.round_()
 
     def decompress_partitions(self, concat_bytes: bytes):

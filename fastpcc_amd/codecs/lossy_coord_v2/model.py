@@ -141,8 +141,9 @@ class PCC(nn.Module):
                 points_num_list = [[int.from_bytes(bs.read(3), 'little', signed=False)]
                                    for _ in range(len(self.encoder.blocks) - 1)]
             em_bytes = bs.read()
-        fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
+        # made before anything is queued: a host-to-device copy from pageable memory waits for the stream
         offset = torch.tensor(coord_offset, dtype=torch.int32, device=dev)
+        fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
         return self.decoder(fea_recon, points_num_list, offset)
 
     def decompress_partitions(self, concat_bytes: bytes) -> torch.Tensor:
