@@ -29,8 +29,6 @@ def host():
     global _host
     if _host is None:
         L = _load(_build.HOST_LIB, 'libfpcc_host.so')
-        L.fpcc_selftest_reciprocal.restype = i64
-        L.fpcc_selftest_reciprocal.argtypes = []
         L.fpcc_host_strerror.restype = C.c_char_p
         L.fpcc_host_strerror.argtypes = [i64]
         sig = {
@@ -84,7 +82,7 @@ HOST_SYMBOLS = (
     'fpcc_simple_enc_free', 'fpcc_simple_enc_push', 'fpcc_simple_enc_push_bin', 'fpcc_simple_enc_push_ranges',
     'fpcc_simple_enc_finish', 'fpcc_simple_dec_new', 'fpcc_simple_dec_free', 'fpcc_simple_dec_pop',
     'fpcc_simple_dec_pop_bin', 'fpcc_pool_new', 'fpcc_pool_free', 'fpcc_pool_binary_encode',
-    'fpcc_pool_histogram_encode', 'fpcc_pool_table_decode', 'fpcc_progress_wait', 'fpcc_pool_wait', 'fpcc_selftest_reciprocal')
+    'fpcc_pool_histogram_encode', 'fpcc_pool_table_decode', 'fpcc_progress_wait', 'fpcc_pool_wait')
 
 
 def hip():

@@ -28,26 +28,6 @@ constexpr uint32_t kLow = 1u << 23;   // lower bound of the normalised state int
 constexpr uint32_t kProbBits = 16;
 constexpr uint32_t kProbOne = 1u << kProbBits;
 
-// x / freq for x < 2^31 without a divide on the coder's dependency chain: floor(x / f) = (x * rcp[f]) >> (31 + sh[f]) with
-// sh = ceil(log2 f), rcp = ceil(2^(31 + sh) / f) (Alverson; the construction of ryg_rans' RansEncSymbolInit, exact for the
-// whole 31-bit range).  The state of a coder obeys x < 2^15 * freq <= 2^31 after its renormalisation.  One table for every
-// 16-bit frequency (512 KB, filled on first use): the lookup depends on the symbol only, not on the state.
-struct Reciprocal { uint32_t rcp; uint32_t shift; };
-static const Reciprocal *reciprocals() {
-    static const std::vector<Reciprocal> table = [] {
-        std::vector<Reciprocal> t(kProbOne + 1);
-        t[0] = {0u, 0u};
-        t[1] = {~0u, 0u};                                    // f = 1: (x * (2^32 - 1)) >> 32 = x - 1 for x >= 1; handled by the caller
-        for (uint32_t f = 2; f <= kProbOne; ++f) {
-            uint32_t sh = 0;
-            while ((1u << sh) < f) ++sh;
-            t[f] = {static_cast<uint32_t>(((1ull << (sh + 31)) + f - 1) / f), sh - 1};
-        }
-        return t;
-    }();
-    return table.data();
-}
-
 // Writes a stream backwards into [base, base + cap).
 class BackWriter {
 public:
@@ -63,13 +43,7 @@ public:
             *--cur_ = static_cast<uint8_t>(x);
             x >>= 8;
         }
-        uint32_t q;
-        if (BITS == kProbBits) {
-            const Reciprocal r = rcp_[freq];
-            q = freq == 1 ? x : static_cast<uint32_t>((static_cast<uint64_t>(x) * r.rcp) >> 32) >> r.shift;
-        } else {
-            q = x / freq;
-        }
+        const uint32_t q = x / freq;
         state_ = (q << BITS) + (x - q * freq) + start;
     }
 
@@ -93,7 +67,6 @@ private:
     uint8_t *base_, *cur_, *end_;
     uint32_t state_;
     bool full_ = false;
-    const Reciprocal *rcp_ = reciprocals();
 };
 
 class FrontReader {
@@ -238,27 +211,6 @@ int64_t binary_encode(const uint8_t *bits, const uint16_t *p1, int64_t n, uint8_
 }  // namespace
 
 extern "C" {
-
-// number of (x, freq) pairs for which the reciprocal table disagrees with x / freq, over every 16-bit frequency and the
-// states a coder can hold (x < 2^15 * freq): edges of the range and a multiplicative walk through it.  0 = exact.
-int64_t fpcc_selftest_reciprocal(void) {
-    const Reciprocal *t = reciprocals();
-    int64_t bad = 0;
-    for (uint32_t f = 1; f <= kProbOne; ++f) {
-        const uint64_t top = (uint64_t(kLow >> kProbBits) << 8) * f;          // exclusive bound of the state
-        auto check = [&](uint64_t x64) {
-            if (x64 >= top) return;
-            const uint32_t x = static_cast<uint32_t>(x64);
-            const uint32_t q = f == 1 ? x : static_cast<uint32_t>((static_cast<uint64_t>(x) * t[f].rcp) >> 32) >> t[f].shift;
-            bad += q != x / f;
-        };
-        for (uint64_t x : {uint64_t(0), uint64_t(1), uint64_t(f) - 1, uint64_t(f), uint64_t(f) + 1, 2 * uint64_t(f) - 1, top - 1,
-                           top - f, top - f - 1, top / 2, uint64_t(kLow) - 1, uint64_t(kLow), uint64_t(kLow) + 1})
-            check(x);
-        for (uint64_t x = 3; x < top; x = x * 7 / 4 + 11) { check(x); check(x - x % f); check(x - x % f + f - 1); }
-    }
-    return bad;
-}
 
 const char *fpcc_host_strerror(int64_t code) {
     switch (code) {

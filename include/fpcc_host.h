@@ -25,8 +25,6 @@ enum {
     FPCC_HOST_E_CDF = -3,      /* CDF cannot be made strictly increasing */
     FPCC_HOST_E_TIMEOUT = -4   /* a background job's input flag never became ready */
 };
-/* Self-test of the divide-free quotient used by the encoders (0 = exact over every frequency and state edge). */
-int64_t fpcc_selftest_reciprocal(void);
 const char *fpcc_host_strerror(int64_t code);
 
 /* Replaces batched_pmf_to_quantized_cdf / pmf_to_quantized_cdf<OVERFLOW> (cdf_ops.cpp:4-109,136-143), one row.

@@ -56,9 +56,3 @@ def test_exp_lut_checksum(golden_dir):
     oracle_lib().orc_exp_lut(lut.ctypes.data_as(C.c_void_p))
     assert hashlib.sha256(lut.tobytes()).hexdigest() == g['sha256']
     assert lut[:8].tolist() == g['head'] and lut[-8:].tolist() == g['tail']
-
-
-def test_divide_free_quotient_is_exact():
-    """the encoders replace x / freq by a multiplication with a tabulated reciprocal: exact for every 16-bit frequency"""
-    from fastpcc_amd._native import host
-    assert host().fpcc_selftest_reciprocal() == 0
