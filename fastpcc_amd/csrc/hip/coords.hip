@@ -203,16 +203,35 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
     const int oct = keys ? (int)(keys[i] & 7) : (int)(i & 7);   // keys == NULL: generated set, row = 8*parent + octant
     const int ox = oct & 1, oy = (oct >> 1) & 1, oz = oct >> 2;
     const int32_t p = parent_of ? parent_of[i] : (int32_t)(i >> 3);
+    // The 27 neighbours of a child lie in the 2x2x2 block of parents {ox-1, ox} x {oy-1, oy} x {oz-1, oz} (parent offsets):
+    // 8 parent rows are looked up once (instead of once per neighbour) and their 8 children each fetched as two 16-byte
+    // loads; the 27 answers are then selected from registers.
+    __shared__ int32_t s_kids[64 * kThreads];                    // [parent in the block * 8 + octant][thread] -> child row or -1
+    int32_t *kids = s_kids + threadIdx.x;                        // (indexed at run time by the child's own octant: not registers)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int px = ox - 1 + (b & 1), py = oy - 1 + ((b >> 1) & 1), pz = oz - 1 + (b >> 2);     // in {-1, 0, 1}
+        const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
+        const int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
+        if (q >= 0 && child_row) {
+            const int4 lo = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8);
+            const int4 hi = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8 + 4);
+            int32_t *kb = kids + b * 8 * kThreads;
+            kb[0] = lo.x; kb[kThreads] = lo.y; kb[2 * kThreads] = lo.z; kb[3 * kThreads] = lo.w;
+            kb[4 * kThreads] = hi.x; kb[5 * kThreads] = hi.y; kb[6 * kThreads] = hi.z; kb[7 * kThreads] = hi.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kids[(b * 8 + c) * kThreads] = q >= 0 ? q * 8 + c : -1;
+        }
+    }
+#pragma unroll
     for (int d = 0; d < 27; ++d) {
         const int tx = ox + (d % 3) - 1, ty = oy + (d / 3) % 3 - 1, tz = oz + d / 9 - 1;   // in {-1,0,1,2}
-        // parent offset floor(t/2) in {-1,0,1}; child octant t mod 2
-        const int px = (tx + 2) / 2 - 1, py = (ty + 2) / 2 - 1, pz = (tz + 2) / 2 - 1;
+        // parent offset floor(t/2) in {-1,0,1} -> index in the block; child octant t mod 2
+        const int bx = (tx + 2) / 2 - ox, by = (ty + 2) / 2 - oy, bz = (tz + 2) / 2 - oz;  // in {0, 1}
+        const int b = bx | (by << 1) | (bz << 2);
         const int co = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-        const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
-        int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
-        int32_t found = -1;
-        if (q >= 0) found = child_row ? child_row[(int64_t)q * 8 + co] : q * 8 + co;
-        nbr[(int64_t)d * n + i] = found;
+        nbr[(int64_t)d * n + i] = kids[(b * 8 + co) * kThreads];
     }
 }
 
