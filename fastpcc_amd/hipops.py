@@ -426,7 +426,7 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
     keys = torch.empty(n, dtype=torch.int64, device=nbr.device)
     group = 64 if n >= 32 * 1024 else 32              # the tile heights fpcc_conv_f32 uses for these map sizes
     n_groups = n // group
-    # with tens of thousands of tiles the launch has no tail worth shaping: heaviest-first pays up to ~8 K tiles
+    # (on maps of millions of rows the launch has no tail worth shaping and the extra sort costs more than it returns)
     heaviest_first = heaviest_first and 2 <= n_groups <= LPT_MAX_GROUPS
     masks = torch.empty(n, dtype=torch.int32, device=nbr.device) if heaviest_first else None
     _ok(L.fpcc_conv_row_keys(_dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(),
@@ -442,7 +442,7 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
     return out
 
 
-LPT_MAX_GROUPS = 8192
+LPT_MAX_GROUPS = 1 << 14
 
 
 @functools.lru_cache(maxsize=8192)
