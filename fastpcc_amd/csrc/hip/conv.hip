@@ -581,9 +581,22 @@ __global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ y,
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= n) return;
     float acc = 0.0f;
-    for (int k = 0; k < n_off; ++k) {
-        const int32_t idx = nbr[(int64_t)k * nbr_ks + o * nbr_os];
-        if (idx >= 0) acc = acc + y[(int64_t)idx * ldy + k];
+    if (n_off == 27) {
+        // all 27 indices, then all 27 gathers (an absent neighbour reads row 0 and is not added), then the chain: the loads
+        // are independent of each other and of the sum
+        int32_t idx[27];
+        float v[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) idx[k] = nbr[(int64_t)k * nbr_ks + o * nbr_os];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = y[(int64_t)(idx[k] >= 0 ? idx[k] : 0) * ldy + k];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = idx[k] >= 0 ? acc + v[k] : acc;
+    } else {
+        for (int k = 0; k < n_off; ++k) {
+            const int32_t idx = nbr[(int64_t)k * nbr_ks + o * nbr_os];
+            if (idx >= 0) acc = acc + y[(int64_t)idx * ldy + k];
+        }
     }
     const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
     out[o] = finish(acc, bias ? bias[0] : 0.0f, act, sl, clip);
