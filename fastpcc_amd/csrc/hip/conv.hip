@@ -269,6 +269,23 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
 #pragma unroll
     for (int j = 0; j < JB; ++j) acc[j] = 0.0f;
 
+    if (c_in == 1 && a.n_off == 27 && a.nbr) {
+        // one input channel (the first layer): 27 independent index loads, 27 independent gathers, then the chain -- the
+        // general loop below issues them one dependent pair at a time
+        int32_t idx[27];
+        float xv[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) idx[k] = a.nbr[(int64_t)k * a.nbr_ks + o * a.nbr_os];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) xv[k] = a.x1[(int64_t)(idx[k] >= 0 ? idx[k] : 0) * a.ld1];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float *wr = wg + (int64_t)k * a.c_out + j0;
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+                if (JB == 1 || j0 + j < a.c_out) acc[j] = idx[k] >= 0 ? fmaf(xv[k], wr[j], acc[j]) : acc[j];
+        }
+    } else
     for (int k = 0; k < a.n_off; ++k) {
         const int32_t idx = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + o * a.nbr_os] : (int32_t)o;
         if (idx < 0) continue;
@@ -376,6 +393,17 @@ int launch_mfma(const ConvArgs &a, hipStream_t s) {
     return launch_mfma_cfg<NBT, CH, 1, NBT>(a, s);
 }
 
+// per-point layer with ONE input channel (the first MLP layer on a residual / logit column): an outer product, written with
+// consecutive threads on consecutive output columns (the row-per-thread kernel above stores with a row-stride between lanes)
+__global__ __launch_bounds__(256) void k_conv_c1_pointwise(ConvArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n_out * a.c_out) return;
+    const int64_t o = e / a.c_out;
+    const int j = (int)(e - o * a.c_out);
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    a.out[o * a.ldo + j] = finish(fmaf(a.x1[o * a.ld1], a.w[j], 0.0f), a.bias ? a.bias[j] : 0.0f, a.act, slope, a.clip);
+}
+
 template <int JB>
 int launch_valu(const ConvArgs &a, hipStream_t s) {
     const int n_jb = (a.c_out + JB - 1) / JB;
@@ -454,6 +482,10 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
         if (c_out == 128) return launch_mfma<4, 16>(a, s);
         if (c_out == 64) return launch_mfma<2, 16>(a, s);
         return launch_mfma<1, 16>(a, s);
+    }
+    if (c1 == 1 && c2 == 0 && n_offsets == 1 && !nbr && groups == 1 && !out_map && c_out >= 8) {
+        hipLaunchKernelGGL(k_conv_c1_pointwise, dim3(blocks_for(n_out * c_out, 256)), dim3(256), 0, s, a);
+        return check_hip(hipGetLastError(), "k_conv_c1_pointwise");
     }
     if (c_out == 1) return launch_valu<1>(a, s);
     if (c_out <= 4) return launch_valu<4>(a, s);
