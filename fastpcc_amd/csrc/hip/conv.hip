@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
     float acc[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) acc[j] = 0.0f;
+    const bool vec4 = a.c1 % 4 == 0 && a.ld1 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0;
 
     if (c_in == 1 && a.n_off == 27 && a.nbr) {
         // one input channel (the first layer): 27 independent index loads, 27 independent gathers, then the chain -- the
@@ -291,6 +292,16 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
         if (idx < 0) continue;
         const float *xr1 = a.x1 + (int64_t)idx * a.ld1;
         const float *wk = wg + (int64_t)k * c_in * a.c_out + j0;
+        if (JB == 1 && vec4) {
+            // one output channel: the input row as 16-byte loads (same natural-order chain)
+            for (int c = 0; c < a.c1; c += 4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr1 + c);
+                acc[0] = fmaf(xv.x, wk[(int64_t)c * a.c_out], acc[0]);
+                acc[0] = fmaf(xv.y, wk[(int64_t)(c + 1) * a.c_out], acc[0]);
+                acc[0] = fmaf(xv.z, wk[(int64_t)(c + 2) * a.c_out], acc[0]);
+                acc[0] = fmaf(xv.w, wk[(int64_t)(c + 3) * a.c_out], acc[0]);
+            }
+        } else
         for (int c = 0; c < a.c1; ++c) {
             const float xv = xr1[c];
             const float *wr = wk + (int64_t)c * a.c_out;
