@@ -19,7 +19,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 MFMA_PEAK_TFLOPS = 157.3       # fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
@@ -105,7 +104,7 @@ def main():
     replicas.init('nccl')          # RCCL; only the barrier and two scalar reductions use it
     device = torch.device('cuda', local)
 
-    from util import enliven
+    from fastpcc_amd.synthetic import enliven
     from fastpcc_amd import hipops
     from fastpcc_amd.codecs.lossy_coord_v2 import Model
     from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1

@@ -330,6 +330,190 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-autonomous MFMA path ("wave kernel").  Every wave is its own work unit: 32 output rows x NBW column blocks of 32,
+// no LDS operand staging and NO workgroup barrier anywhere in the main loop.
+//   A (gathered rows): global -> registers in MFMA operand layout, one stage ahead (as in k_conv_mfma);
+//   B (weights): global/L2 -> registers from a PACKED copy of the weights (fpcc_conv_pack_weights_f32) in which the four
+//     B operands lane (i, h) needs for one group of 8 channels and one column block are 16 contiguous bytes and the 64
+//     lanes of a wave read 1 KB contiguous:  wp[m][cc][g8][nb][h][i][j] = w[m][32 cc + 8 g8 + 4 h + j][32 nb + i].
+//     The weights of a layer (<= 1.8 MB) stay L2-resident; a wave re-loads the B registers of group g8 for the NEXT stage
+//     right after the MFMAs of group g8 of the current one, so every load has a whole stage of MFMAs to land.
+// The 4 waves of a workgroup only share the launch; each walks the kernel offsets present in ITS 32 rows.  What this buys
+// over the workgroup-tiled kernel: no barrier skew between waves whose 32-row blocks have different offsets, no
+// LDS round trip of W, work units of 1/2 .. 1/8 the size (shorter tail of a launch), and with NBW = 4 every gathered row is
+// fetched once instead of twice.  Same summation order (order 1).
+template <int NBW, int CH>
+struct WaveCfg {
+    static constexpr int G8 = CH / 8;
+    static constexpr int MIN_WAVES = NBW >= 4 ? 3 : (NBW == 2 ? 4 : 6);   // per SIMD: accumulators 16 NBW + B 16 NBW + A 16 + addresses
+};
+
+template <int NBW, int CH, int SB>
+__global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
+                                                                                  int nbt, unsigned n_units) {
+    constexpr int G8 = CH / 8;
+    __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned n_cg = (unsigned)(nbt / NBW);
+    // unit = (32-row block, column group); the column groups of one row block are adjacent units (same workgroup: their A
+    // rows hit the CU's vector L1).  Natural order: contiguous unit ranges per XCD; with a row order: dispatch order.
+    const unsigned blk = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned unit = blk * 4u + (unsigned)wv;
+    if (unit >= n_units) return;                    // no barrier below: a wave may leave on its own
+    const unsigned rb = unit / n_cg, cg = unit - rb * n_cg;
+    const int g = blockIdx.y;
+    const int64_t row0 = (int64_t)rb * 32;
+    const int c_in = a.c1 + a.c2;
+    const int n_chunks = c_in / CH;
+    int32_t *s_nbr = s_nbr_all[wv];
+
+    int32_t my_row = -1;
+    if (row0 + li < a.n_out) my_row = a.row_order ? a.row_order[row0 + li] : (int32_t)(row0 + li);
+    // neighbour rows of my 32 output rows -> this wave's LDS slice; lane half h takes the offsets of parity h
+    unsigned wmask = 0;
+    for (int k0 = 0; k0 < a.n_off; k0 += 2) {
+        const int k = k0 + lh;
+        int32_t v = -1;
+        if (k < a.n_off && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
+        if (k < a.n_off) s_nbr[k * 32 + li] = v;
+        const unsigned long long b = __ballot(v >= 0);
+        if (b & 0xffffffffull) wmask |= 1u << k0;
+        if (b >> 32) wmask |= 1u << (k0 + 1);
+    }
+    __builtin_amdgcn_wave_barrier();               // LDS operations of one wave execute in order; keep the compiler from reordering
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    const int n_stages = __popc(wmask) * n_chunks;
+    if (n_stages > 0) {
+        // packed weights of (group g, offset k, chunk cc): G8 * nbt KB-blocks; this wave reads blocks [cg*NBW, cg*NBW + NBW) of each g8
+        const int64_t chunk_floats = (int64_t)G8 * nbt * 256;
+        const float *wp_g = wp + (int64_t)g * a.n_off * n_chunks * chunk_floats + ((int64_t)cg * NBW) * 256 + lane * 4;
+        // Branch-free on purpose: control flow inside the stage loop makes hipcc drain vmcnt(0) at the join, which would
+        // wait for the loads issued a moment ago.  Loop invariants are taken out by hand (the compiler re-reads kernel
+        // arguments and the zero row's address through scalar loads -- and waits for them -- inside the loop otherwise).
+        const float *const zero = (const float *)g_zero_row + 4 * lh;
+        const float *const x1b = a.x1 + 4 * lh, *const x2b = a.x2 ? a.x2 + 4 * lh - a.c1 : zero;
+        const int64_t ld1 = a.ld1, ld2 = a.ld2;
+        const int c1 = a.c1;
+        auto a_ptr = [&](int k, int cc) -> const float * {
+            const bool in_x1 = cc * CH < c1;                 // wave-uniform
+            const float *xb = (in_x1 ? x1b : x2b) + cc * CH;
+            const int64_t ld = in_x1 ? ld1 : ld2;
+            const int32_t idx = s_nbr[k * 32 + li];
+            const int32_t neg = idx >> 31;                    // 0 or ~0; a select here comes back as a branch (if-conversion)
+            const uint64_t m = (uint64_t)(int64_t)neg;
+            const uint64_t p = reinterpret_cast<uint64_t>(xb + (int64_t)(idx & ~neg) * ld);
+            return reinterpret_cast<const float *>((p & ~m) | (reinterpret_cast<uint64_t>(zero) & m));
+        };
+        unsigned rest = wmask;
+        int k_cur = __ffs(rest) - 1;
+        int k_next = k_cur, cc_next = 0;
+        // Register plan: ONE A buffer and ONE B buffer, both refilled in place group by group -- right after the MFMAs of
+        // group g8 have consumed ra[g8] / rb[g8][*], the same registers are loaded with group g8 of the NEXT stage, so every
+        // load has a whole stage of MFMAs (64 x NBW/4 x 64 cycles) to land and nothing is copied.  hipcc's scheduler would
+        // otherwise sink every load down to its first use (it minimises live ranges), exposing a full L2 / HBM latency per
+        // stage; sched_barrier pins the issue points.  Mask SB lets the scalar / vector address arithmetic of the next
+        // stage float between the MFMAs (0: nothing crosses).
+        f32x4 ra[G8], rb[G8][NBW];
+        {
+            // first stage's operands, issued in the SAME order as the refills inside the loop (group by group, A then B): the
+            // wait counts at the loop head are merged over both ways into it, and a different order here (the scheduler
+            // reverses it if left alone) turns them into vmcnt(0) on every iteration
+            const float *ap = a_ptr(k_cur, 0);
+            const float *bp = wp_g + (int64_t)k_cur * n_chunks * chunk_floats;
+#pragma unroll
+            for (int g8 = 0; g8 < G8; ++g8) {
+                __builtin_amdgcn_sched_barrier(0);
+                ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    rb[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int s = 0; s < n_stages; ++s) {
+            if (++cc_next == n_chunks) {
+                cc_next = 0;
+                rest &= rest - 1;
+                k_next = rest ? __ffs(rest) - 1 : k_cur;       // past the last stage: re-read a valid one (never used)
+            }
+            const float *ap = a_ptr(k_next, cc_next);
+            const float *bp = wp_g + ((int64_t)k_next * n_chunks + cc_next) * chunk_floats;
+            __builtin_amdgcn_sched_barrier(SB);
+#pragma unroll
+            for (int g8 = 0; g8 < G8; ++g8) {
+                const f32x4 av = ra[g8];
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, rb[g8][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, rb[g8][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, rb[g8][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[g8][nb].w, acc[nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(SB);
+                // the registers of this group are free now: refill them for the next stage
+                ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    __builtin_amdgcn_sched_barrier(SB);
+                    rb[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(SB);
+            }
+            k_cur = k_next;
+        }
+    }
+
+    // output rows of my accumulator registers: register r holds row (r & 3) + 8 (r >> 2) + 4 h of the block
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    int32_t orow[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)              // lane rr (< 32) holds that row's output index; all lanes active here
+        orow[reg] = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t o = orow[reg];
+        if (o < 0) continue;
+        const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+        if (dst < 0) continue;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int col = 32 * ((int)cg * NBW + nb) + li;
+            const float b = a.bias ? a.bias[col] : 0.0f;
+            a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ w, int64_t n_mats, int c_in, int c_out,
+                                                      float *__restrict__ wp) {
+    // one thread per packed element: [m][cc][g8][nb][h][i][j] <- w[m][32 cc + 8 g8 + 4 h + j][32 nb + i]
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_mat = (int64_t)c_in * c_out;
+    if (e >= n_mats * per_mat) return;
+    const int nbt = c_out / 32;
+    const int64_t m = e / per_mat;
+    int64_t r = e - m * per_mat;
+    const int j = (int)(r & 3); r >>= 2;
+    const int i = (int)(r & 31); r >>= 5;
+    const int h = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % nbt); r /= nbt;
+    const int g8 = (int)(r & 3); r >>= 2;
+    const int cc = (int)r;
+    wp[e] = w[m * per_mat + (int64_t)(32 * cc + 8 * g8 + 4 * h + j) * c_out + 32 * nb + i];
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // 0: VALU kernel, 16 / 32: MFMA kernel with that chunk size
@@ -415,6 +599,45 @@ __global__ __launch_bounds__(256) void k_conv_c1_pointwise(ConvArgs a) {
     a.out[o * a.ldo + j] = finish(fmaf(a.x1[o * a.ld1], a.w[j], 0.0f), a.bias ? a.bias[j] : 0.0f, a.act, slope, a.clip);
 }
 
+// Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobCount = 3 };
+int g_knob[kKnobCount] = {-1, -1, -1};
+int knob(int k) {
+    if (g_knob[k] < 0) {
+        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB"};
+        static const int defaults[kKnobCount] = {1, 0, 1};
+        const char *e = getenv(names[k]);
+        g_knob[k] = e ? atoi(e) : defaults[k];
+    }
+    return g_knob[k];
+}
+
+template <int NBW>
+int launch_wave_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
+    const int64_t row_blocks = (a.n_out + 31) / 32;
+    const int64_t units = row_blocks * (nbt / NBW);
+    if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
+    // knob FPCC_WAVE_SB=1: the address arithmetic of the next stage may be scheduled between the MFMAs
+    const int sb = knob(kKnobWaveSb);
+    const dim3 grid((unsigned)((units + 3) / 4), a.groups);
+    if (sb) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    return check_hip(hipGetLastError(), "k_conv_wave");
+}
+
+// Column blocks per wave by map size (knob FPCC_WAVE_NBW=1|2|4 forces): wide units on large maps (every gathered row
+// fetched once, fewest B loads per MFMA), narrow units where the launch would otherwise not fill the chip.
+int launch_wave(const ConvArgs &a, const float *wp, hipStream_t s) {
+    const int forced = knob(kKnobWaveNbw);
+    const int nbt = a.c_out / 32;
+    const int64_t work = a.n_out * a.groups;
+    int nbw = forced > 0 ? forced : (work >= 128 * 1024 ? 4 : work >= 16 * 1024 ? 2 : 1);
+    while (nbw > nbt || nbt % nbw) nbw >>= 1;
+    if (nbw >= 4) return launch_wave_cfg<4>(a, wp, nbt, s);
+    if (nbw == 2) return launch_wave_cfg<2>(a, wp, nbt, s);
+    return launch_wave_cfg<1>(a, wp, nbt, s);
+}
+
 template <int JB>
 int launch_valu(const ConvArgs &a, hipStream_t s) {
     const int n_jb = (a.c_out + JB - 1) / JB;
@@ -446,11 +669,43 @@ extern "C" int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, 
     return mfma_chunk(c1, c2, c_out) ? 1 : 0;
 }
 
+extern "C" int fpcc_conv_set_tuning(int which, int value) {
+    if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");
+    const int before = knob(which);
+    g_knob[which] = value < 0 ? 0 : value;
+    return before;
+}
+
+extern "C" int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int groups) {
+    // the wave kernel takes the 32-channel-chunk shapes of the MFMA path
+    if (mfma_chunk(c1, c2, c_out) != 32 || n_offsets < 1 || n_offsets > kMaxOffsets || groups < 1) return 0;
+    return (int64_t)groups * n_offsets * (c1 + c2) * c_out;
+}
+
+extern "C" int fpcc_conv_pack_weights_f32(const float *w, int64_t n_mats, int c_in, int c_out, float *w_packed, void *stream) {
+    if (n_mats < 0 || c_in < 32 || c_in % 32 || (c_out != 32 && c_out != 64 && c_out != 128))
+        return fail_arg("conv_pack_weights: c_in must be a multiple of 32 and c_out one of 32, 64, 128");
+    if (n_mats == 0) return FPCC_OK;
+    if (!w || !w_packed) return fail_arg("conv_pack_weights: null pointer");
+    hipLaunchKernelGGL(k_pack_weights, dim3(blocks_for(n_mats * c_in * c_out, 256)), dim3(256), 0, as_stream(stream), w, n_mats,
+                       c_in, c_out, w_packed);
+    return check_hip(hipGetLastError(), "k_pack_weights");
+}
+
 extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2, const int32_t *nbr,
                              int n_offsets, int64_t nbr_ks, int64_t nbr_os, const float *w, const float *bias, int c_out,
                              int groups, const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo,
                              int64_t n_out, int act, const float *slope, float clip, const int32_t *row_order,
                              void *ws, int64_t ws_bytes, void *stream) {
+    return fpcc_conv_f32_pk(x1, c1, ld1, x2, c2, ld2, nbr, n_offsets, nbr_ks, nbr_os, w, nullptr, bias, c_out, groups, out_map,
+                            om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order, ws, ws_bytes, stream);
+}
+
+extern "C" int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2, const int32_t *nbr,
+                                int n_offsets, int64_t nbr_ks, int64_t nbr_os, const float *w, const float *w_packed,
+                                const float *bias, int c_out, int groups, const int32_t *out_map, int64_t om_os,
+                                int64_t om_gs, float *out, int ldo, int64_t n_out, int act, const float *slope, float clip,
+                                const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream) {
     if (n_out < 0 || c1 < 1 || c2 < 0 || c_out < 1 || groups < 1 || n_offsets < 1 || n_offsets > 32)
         return fail_arg("conv_f32: sizes out of range (n_offsets must be 1..32)");
     if (n_out == 0) return FPCC_OK;
@@ -484,6 +739,10 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
     // chunks were walked in sequence anyway).  With 64 input channels (2 chunks of 32) the same change loses 2-15 %.
     if (ch == 16 && c2 == 0 && c1 == 48 && c_out <= 64 && n_out * (int64_t)groups >= 32 * 1024)
         return c_out == 64 ? launch_mfma_cfg<2, 48, 4, 1>(a, s) : launch_mfma_cfg<1, 48, 4, 1>(a, s);
+    if (ch == 32 && w_packed) {
+        if (!aligned16(w_packed)) return fail_arg("conv_f32: packed weights must be 16-byte aligned");
+        if (knob(kKnobWaveOn)) return launch_wave(a, w_packed, s);
+    }
     if (ch == 32) {
         if (c_out == 128) return launch_mfma<4, 32>(a, s);
         if (c_out == 64) return launch_mfma<2, 32>(a, s);

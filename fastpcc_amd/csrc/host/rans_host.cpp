@@ -27,6 +27,14 @@ namespace {
 constexpr uint32_t kLow = 1u << 23;   // lower bound of the normalised state interval
 constexpr uint32_t kProbBits = 16;
 constexpr uint32_t kProbOne = 1u << kProbBits;
+constexpr int kMaxRefill = 3;         // bytes a decoder may shift in per symbol (2 suffice for any valid stream)
+
+// a quantised CDF the coders accept: starts at 0, strictly increasing, ends at 2^16
+bool cdf_well_formed(const uint32_t *c, int64_t len) {
+    if (len < 2 || c[0] != 0 || c[len - 1] != kProbOne) return false;
+    for (int64_t i = 1; i < len; ++i) if (c[i] <= c[i - 1]) return false;
+    return true;
+}
 
 // Writes a stream backwards into [base, base + cap).
 class BackWriter {
@@ -76,11 +84,15 @@ public:
     }
     template <uint32_t BITS>
     inline uint32_t peek() const { return state_ & ((1u << BITS) - 1u); }
+    // a valid encoder flushes a state in [2^23, 2^31); anything below marks a corrupt or truncated stream
+    bool valid() const { return state_ >= kLow; }
     template <uint32_t BITS>
     inline void take(uint32_t start, uint32_t freq) {
         uint32_t x = freq * (state_ >> BITS) + (state_ & ((1u << BITS) - 1u)) - start;
-        while (x < kLow) {
-            // reading past the end yields zeros: a truncated stream decodes to garbage, never out of bounds
+        // A state of a valid stream is >= 2^7 after the update, so at most two bytes bring it back above 2^23.  The
+        // refill is bounded (never `while`): a corrupt stream whose state collapses to 0 would otherwise shift in zeros
+        // for ever.  Reading past the end yields zeros: garbage out, never out of bounds, always finite.
+        for (int r = 0; r < kMaxRefill && x < kLow; ++r) {
             uint32_t b = p_ < end_ ? *p_ : 0u;
             ++p_;
             x = (x << 8) | b;
@@ -145,6 +157,7 @@ int64_t single_table_decode(const uint8_t *stream, int64_t stream_len, int64_t n
     for (int32_t b = 0; b < bins; ++b)
         for (uint32_t s = c[b]; s < c[b + 1]; ++s) slot_to_bin[s] = static_cast<uint16_t>(b);
     FrontReader r(stream, stream_len);
+    if (!r.valid() && n > 0) return FPCC_HOST_E_ARG;
     int64_t next_mark = progress ? std::min<int64_t>(n, first_chunk > 0 ? first_chunk : 4096) : n;
     for (int64_t i = 0; i < n;) {
         for (; i < next_mark; ++i) {
@@ -162,10 +175,13 @@ template <bool ESCAPE>
 int64_t indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t *index, int64_t n, const Tables &t,
                        int32_t *out) {
     if (stream_len < 4) return FPCC_HOST_E_ARG;
+    for (int64_t ti = 0; ti < t.count; ++ti)
+        if (!cdf_well_formed(t.cdf + t.start[ti], t.len[ti])) return FPCC_HOST_E_CDF;
     if (!ESCAPE && t.count == 1 && n >= 8192 && t.len[0] - 1 <= 65535)
         return single_table_decode(stream, stream_len, n, t.cdf + t.start[0], static_cast<int32_t>(t.len[0]) - 1,
                                    t.offsets[0], out);
     FrontReader r(stream, stream_len);
+    if (!r.valid() && n > 0) return FPCC_HOST_E_ARG;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t ti = index ? index[i] : i % t.count;
         if (ti < 0 || ti >= t.count) return FPCC_HOST_E_ARG;
@@ -177,7 +193,10 @@ int64_t indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t 
         r.take<kProbBits>(c[v], c[v + 1] - c[v]);
         if (ESCAPE && v == bins - 1) {
             int width = 0;
-            while (r.peek<1>() == 0) { r.take<1>(0u, 1u); ++width; }
+            while (r.peek<1>() == 0) {
+                r.take<1>(0u, 1u);
+                if (++width > 31) return FPCC_HOST_E_ARG;      // no int32 magnitude is that wide: corrupt stream
+            }
             r.take<1>(1u, 1u);
             int32_t mag = 1;
             for (int b = 0; b < width; ++b) {
@@ -232,6 +251,7 @@ int64_t fpcc_pmf_to_quantized_cdf(const double *pmf, int64_t n, int overflow, in
     }
     double denom = mass;
     if (overflow) denom += std::max(1.0 - mass, 0.0);   // the escape bin takes what is left of 1
+    if (!(denom > 0.0) || !std::isfinite(denom)) return FPCC_HOST_E_ARG;   // all-zero histogram (the reference asserts)
 
     std::vector<uint32_t> edges(static_cast<size_t>(n) + (overflow ? 2 : 1));
     double running = 0.0;
@@ -302,6 +322,7 @@ int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const
     // is computed with selects; only the byte refill -- rare and regular -- stays a branch.
     const uint8_t *p = stream + 4, *end = stream + stream_len;
     uint32_t x = uint32_t(stream[0]) | uint32_t(stream[1]) << 8 | uint32_t(stream[2]) << 16 | uint32_t(stream[3]) << 24;
+    if (x < kLow && n > 0) return FPCC_HOST_E_ARG;                    // not a state any encoder flushes
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t p1 = prob1[i];
         const uint32_t split = kProbOne - p1;
@@ -312,7 +333,7 @@ int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const
         const uint32_t start = split & mask;
         x = freq * (x >> kProbBits) + slot - start;
         bits_out[i] = static_cast<uint8_t>(one);
-        while (x < kLow) {
+        for (int r = 0; r < kMaxRefill && x < kLow; ++r) {        // bounded: see FrontReader::take
             const uint32_t b = p < end ? *p : 0u;                 // past the end: zeros (garbage out, never out of bounds)
             ++p;
             x = (x << 8) | b;
@@ -427,7 +448,9 @@ int64_t fpcc_simple_enc_finish(fpcc_simple_enc *e, uint8_t *out, int64_t cap) {
 
 fpcc_simple_dec *fpcc_simple_dec_new(const uint8_t *stream, int64_t stream_len) {
     if (!stream || stream_len < 4) return nullptr;
-    return new (std::nothrow) fpcc_simple_dec(stream, stream_len);
+    auto *d = new (std::nothrow) fpcc_simple_dec(stream, stream_len);
+    if (d && !d->r.valid()) { delete d; return nullptr; }              // initial state below 2^23: corrupt stream
+    return d;
 }
 void fpcc_simple_dec_free(fpcc_simple_dec *d) { delete d; }
 
@@ -578,6 +601,7 @@ int64_t fpcc_pool_table_decode(fpcc_pool *p, const uint8_t *stream, int64_t stre
                                int64_t *progress) {
     if (!p || !stream || !cdf || !symbols_out || !progress || n < 0 || cdf_len < 2 || cdf_len - 1 > 65535 || stream_len < 4)
         return FPCC_HOST_E_ARG;
+    if (!cdf_well_formed(cdf, cdf_len)) return FPCC_HOST_E_CDF;       // the table comes straight from the bitstream
     static_assert(sizeof(std::atomic<int64_t>) == sizeof(int64_t), "progress counter must be a plain 64-bit word");
     auto *prog = reinterpret_cast<std::atomic<int64_t> *>(progress);
     prog->store(0, std::memory_order_relaxed);

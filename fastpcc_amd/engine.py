@@ -639,7 +639,7 @@ class _ConvBase(nn.Module):
         x1 = parts[0]
         x2 = parts[1] if len(parts) > 1 else None
         derived = self._derived()
-        kw = dict(x2=x2, bias=derived['b'], act=act.kind, slope=act.slope, clip=clip)
+        kw = dict(x2=x2, bias=derived['b'], act=act.kind, slope=act.slope, clip=clip, pack=True)
         w = derived['w']
         c_out = self.out_channels
         if self.GENERATIVE:
@@ -655,7 +655,7 @@ class _ConvBase(nn.Module):
                     cols = wh.shape[1]
                     bh = d['gen_b'][h] if d['gen_b'][0] is not None else None
                     ops.conv_f32(x1, wh, cols, src.n, bias=bh, act=act.kind, slope=act.slope, clip=clip,
-                                 out=out[:, h * 128: h * 128 + cols])
+                                 out=out[:, h * 128: h * 128 + cols], pack=True)
                 out = out.view(8 * src.n, c_out)
             else:
                 out = ops.conv_f32(x1, w, c_out, src.n, groups=8, **kw)
@@ -676,7 +676,7 @@ class _ConvBase(nn.Module):
             if plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
-                                   act=act.kind, slope=act.slope, clip=clip)[:, :c_out]
+                                   act=act.kind, slope=act.slope, clip=clip, pack=True)[:, :c_out]
             else:
                 out = ops.conv_f32(x1, w, c_out, src.n, **kw)
         elif self.ks == 3:
@@ -686,14 +686,14 @@ class _ConvBase(nn.Module):
             d = self._derived()
             plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
             if x2 is None and 'k3_w' in d:
-                y = ops.conv_f32(x1, d['k3_w'], 32, src.n)       # per input row: its dot product with every offset's kernel
+                y = ops.conv_f32(x1, d['k3_w'], 32, src.n, pack=True)       # per input row: its dot product with every offset's kernel
                 out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
                                      slope=act.slope, clip=clip)
             elif plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
                                    nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
-                                   clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None)[:, :c_out]
+                                   clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None, pack=True)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
             else:
@@ -721,11 +721,13 @@ def _fusable_in_training(act: _Act) -> bool:
         return True
     if act.param is None:
         return False
+    # (parameter version, value): an optimiser step, load_state_dict() or an EMA copy bumps `_version`, which is a host-side
+    # integer -- a stale sign can therefore never select the fused backward
     cached = getattr(act.param, '_fpcc_host_value', None)
-    if cached is None:
-        cached = float(act.param.detach().reshape(-1)[0].item())
+    if cached is None or cached[0] != act.param._version:
+        cached = (act.param._version, float(act.param.detach().reshape(-1)[0].item()))
         act.param._fpcc_host_value = cached
-    return cached > 0
+    return cached[1] > 0
 
 
 def refresh_prelu_cache(model: nn.Module) -> None:
@@ -733,7 +735,7 @@ def refresh_prelu_cache(model: nn.Module) -> None:
     ps = [m.module.weight for m in model.modules() if isinstance(m, MinkowskiPReLU) and m.module.weight.numel() == 1]
     if ps:
         for p, v in zip(ps, torch.cat([p.detach().reshape(1) for p in ps]).tolist()):
-            p._fpcc_host_value = v
+            p._fpcc_host_value = (p._version, v)
 
 
 def _finish_autograd(out: torch.Tensor, bias: Optional[torch.Tensor], act: _Act, clip: float) -> torch.Tensor:
@@ -790,7 +792,7 @@ class MinkowskiLinear(nn.Module):
         b = self.linear.bias
         out = ops.conv_f32(parts[0], self._weight_t(), self.linear.out_features, parts[0].shape[0],
                            x2=parts[1] if len(parts) > 1 else None, bias=None if b is None else b.detach(),
-                           act=act.kind, slope=act.slope, clip=clip)
+                           act=act.kind, slope=act.slope, clip=clip, pack=True)
         return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
 
 

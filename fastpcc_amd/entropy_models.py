@@ -261,10 +261,13 @@ class NoisyDeepFactorizedEntropyModel(nn.Module):
                  broadcast_shape_bytes: Tuple[int, ...] = (2,)):
         super().__init__()
         batch_shape = torch.Size(batch_shape)
-        self.prior_weights, self.prior_biases, self.prior_factors = make_parameters(batch_shape.numel(), init_scale, num_filters)
+        weights, biases, factors = make_parameters(batch_shape.numel(), init_scale, num_filters)
         self.prior = DistributionQuantizedCDFTable(
-            _NoisyDeepFactorized(batch_shape, self.prior_weights, self.prior_biases, self.prior_factors, 1 / bottleneck_scaler),
+            _NoisyDeepFactorized(batch_shape, weights, biases, factors, 1 / bottleneck_scaler),
             lower_bound, upper_bound, 1, overflow_coding, bottleneck_scaler)      # one coded unit per call, like the reference
+        # registered after `prior`, as the reference does (continuous_batched.py:192-194): the state_dict lists
+        # prior._extra_state before the parameter lists (tests/golden/me_semantics.json holds the reference's key order)
+        self.prior_weights, self.prior_biases, self.prior_factors = weights, biases, factors
         proc = bottleneck_process
         self.quantize_bottleneck = 'quantization' in proc
         proc = proc.replace('quantization', '', 1)

@@ -4,6 +4,7 @@ Tensors are torch CUDA(=HIP) tensors used purely as device buffers: every wrappe
 passes raw pointers plus the current HIP stream, and raises on a non-zero status.  No computation happens in Python and
 there is no alternative implementation: without the library or a GPU these functions raise.
 """
+import collections
 import ctypes as C
 import functools
 from typing import Optional, Tuple
@@ -29,6 +30,11 @@ _SIGS = {
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
+    'fpcc_conv_f32_pk': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32,
+                                _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
+    'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
+    'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    'fpcc_conv_pack_weights_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_transpose_weights_f32': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -252,6 +258,38 @@ def _rows2d(t: torch.Tensor, name: str):
     return t.data_ptr(), t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
 
 
+# Packed copies of convolution weights for the wave-autonomous MFMA kernel (fpcc_conv_pack_weights_f32), one per weight
+# tensor.  The entry keeps the source tensor alive (so its address cannot be handed to another tensor) and is rebuilt
+# when the tensor was written in place (`_version`).  Inference only: training changes the weights every step.
+_PACKED: 'collections.OrderedDict' = collections.OrderedDict()
+_PACKED_MAX = 1024
+
+
+def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int, groups: int) -> Optional[torch.Tensor]:
+    """packed copy of w [groups, n_offsets, c1 + c2, c_out] for fpcc_conv_f32_pk, or None when the shape has no wave kernel"""
+    if not lib().fpcc_conv_packed_floats(c1, c2, c_out, n_offsets, groups):
+        return None
+    key = (w.data_ptr(), w.numel(), c1 + c2, c_out)
+    ent = _PACKED.get(key)
+    if ent is not None and ent[1] == w._version:
+        _PACKED.move_to_end(key)
+        return ent[2]
+    out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    _ok(lib().fpcc_conv_pack_weights_f32(w.data_ptr(), groups * n_offsets, c1 + c2, c_out, out.data_ptr(), _stream()))
+    _PACKED[key] = (w, w._version, out)
+    while len(_PACKED) > _PACKED_MAX:
+        _PACKED.popitem(last=False)
+    return out
+
+
+KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB = 0, 1, 2
+
+
+def conv_set_tuning(which: int, value: int) -> int:
+    """process-wide tuning knob of the wave kernel (fpcc_conv_set_tuning); returns the previous value"""
+    return _ok(lib().fpcc_conv_set_tuning(int(which), int(value)))
+
+
 # When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
 # bench.py to time the dominant kernel inside the timed region (events only, no synchronisation).
 CONV_TRACE = None
@@ -262,8 +300,10 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
              bias: Optional[torch.Tensor] = None, groups: int = 1, out_map: Optional[torch.Tensor] = None,
              om_os: int = 0, om_gs: int = 1, out: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
              act: int = ACT_NONE, slope: Optional[torch.Tensor] = None, clip: float = 0.0,
-             row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[dst(o,g)] = act(sum_k X[nbr[k*nbr_ks + o*nbr_os]] @ w[g][k] + bias); see include/fpcc_hip.h."""
+             row_order: Optional[torch.Tensor] = None, pack: bool = False) -> torch.Tensor:
+    """out[dst(o,g)] = act(sum_k X[nbr[k*nbr_ks + o*nbr_os]] @ w[g][k] + bias); see include/fpcc_hip.h.
+    pack: keep a packed copy of `w` (packed_weights) and run the shapes that have one on the wave-autonomous kernel --
+    for weights that stay put between calls (inference)."""
     p1, c1, ld1 = _rows2d(x1, 'x1')
     if x2 is not None:
         p2, c2, ld2 = _rows2d(x2, 'x2')
@@ -285,16 +325,18 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
+    wp = packed_weights(w, c1, c2, c_out, n_offsets, groups) if pack and not ws_bytes else None
     trace = CONV_TRACE
     if trace is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _ok(lib().fpcc_conv_f32(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
-                            w.data_ptr(), _dev(bias, torch.float32, 'bias', True), c_out, groups,
-                            _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
-                            _dev(slope, torch.float32, 'slope', True), float(clip),
-                            _dev(row_order, torch.int32, 'row_order', True),
-                            None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
+    _ok(lib().fpcc_conv_f32_pk(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                               w.data_ptr(), None if wp is None else wp.data_ptr(),
+                               _dev(bias, torch.float32, 'bias', True), c_out, groups,
+                               _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
+                               _dev(slope, torch.float32, 'slope', True), float(clip),
+                               _dev(row_order, torch.int32, 'row_order', True),
+                               None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
     if trace is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()

@@ -216,7 +216,7 @@ class RansDecoder:
         self._pin = np.frombuffer(encoded, dtype=np.uint8)   # keeps the bytes alive for the decoder
         self._h = host().fpcc_simple_dec_new(_p(self._pin), self._pin.size)
         if not self._h:
-            raise ValueError('stream shorter than 4 bytes')
+            raise ValueError('not a rANS stream: shorter than 4 bytes or a final state below 2^23')
         return 0
 
     def decode(self, cdf_arr: np.ndarray, symbol_arr: np.ndarray) -> int:

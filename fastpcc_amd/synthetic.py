@@ -2,7 +2,8 @@
 
 `body_cloud` is the stand-in for an 8iVFB frame (cfg#2): a closed, one-voxel-thick surface made of a torso, a head and
 two limbs (ellipsoids), voxelised by dense parametric sampling; `scale` is tuned so that the named resolutions give the
-named voxel counts."""
+named voxel counts.  `surface_cloud` is the small 'ShapeNet-like' plumbing cloud (cfg#1); `enliven` gives a model the
+seeded weights every benchmark and parity test uses (no checkpoints exist here)."""
 from typing import Tuple
 
 import numpy as np
@@ -81,3 +82,49 @@ def lidar_cloud(seed: int = 3, beams: int = 64, azimuths: int = 2048, resolution
     q = np.round((p - p.min(0)) * ((resolution - 1) / extent)).astype(np.int64)
     key = np.unique((q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2])
     return np.stack(((key >> 42), (key >> 21) & 0x1fffff, key & 0x1fffff), 1).astype(np.int32)
+
+
+def surface_cloud(seed: int, resolution: int, n_samples: int) -> np.ndarray:
+    """Unique int voxels [n, 3] on a union of ellipsoid shells and planes inside [0, resolution)^3 -- the
+    'ShapeNet-like' plumbing cloud (cfg#1)."""
+    rng = np.random.default_rng(seed)
+    pts = []
+    per = n_samples // 5
+    for _ in range(3):
+        centre = rng.uniform(0.3, 0.7, 3) * resolution
+        radii = rng.uniform(0.12, 0.3, 3) * resolution
+        d = rng.normal(size=(per, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts.append(centre + d * radii)
+    for _ in range(2):
+        origin = rng.uniform(0.2, 0.8, 3) * resolution
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        v -= u * (u @ v)
+        v /= np.linalg.norm(v)
+        ab = rng.uniform(-0.4, 0.4, (per, 2)) * resolution
+        pts.append(origin + ab[:, :1] * u + ab[:, 1:] * v)
+    p = np.round(np.concatenate(pts)).astype(np.int64)
+    p = p[((p >= 0) & (p < resolution)).all(1)]
+    return np.unique(p, axis=0)
+
+
+def enliven(model: 'torch.nn.Module', seed: int, gain: float = 2.35) -> None:
+    """Seeded re-initialisation that keeps activations O(1) through the 12-level pyramid (the default
+    U(-1/sqrt(fan), 1/sqrt(fan)) init shrinks them to zero, which would make every parity test trivial)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if '.prior_' in name:                       # deep-factorised prior: keep make_parameters' init
+                continue
+            if name.endswith('module.weight'):          # PReLU slope
+                p.copy_(0.1 + 0.3 * torch.rand(p.shape, generator=g))
+            elif name.endswith('kernel') or name.endswith('linear.weight'):
+                fan = p.shape[-2] * (p.shape[0] if p.dim() == 3 else 1) if name.endswith('kernel') else p.shape[1]
+                if name.endswith('kernel') and p.dim() == 3 and p.shape[0] == 27:
+                    fan = p.shape[1] * 13               # about half of the 27 neighbours exist on a surface
+                bound = gain / (3.0 * fan) ** 0.5 * 3.0 ** 0.5
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+            else:                                       # biases
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.3)

@@ -126,6 +126,28 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
                   const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
                   int act, const float *slope, float clip, const int32_t *row_order, void *ws, int64_t ws_bytes,
                   void *stream);
+/* The same operator with an additional PACKED copy of the weights (NULL: exactly fpcc_conv_f32).  Shapes for which
+ * fpcc_conv_packed_floats() != 0 (C_in, c1 multiples of 32; C_out in {32, 64, 128}) then run on the wave-autonomous MFMA
+ * kernel: every wave owns 32 output rows x 1, 2 or 4 column blocks and reads its B operands straight from the packed
+ * weights (L2-resident) as coalesced 16-byte loads -- no LDS staging, no workgroup barrier.  Same results bit for bit (the
+ * summation order is order 1 either way); shapes evaluated offset-split (order 2) ignore the packed copy.
+ * fpcc_conv_pack_weights_f32: w [n_mats][c_in][c_out] (n_mats = groups * n_offsets) ->
+ *     w_packed[m][cc][g8][nb][h][i][j] = w[m][32 cc + 8 g8 + 4 h + j][32 nb + i]      (same number of floats);
+ * the caller caches it next to the weights (fastpcc_amd/hipops.py keeps one per weight tensor). */
+int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int groups);
+/* Tuning knobs of the wave kernel (process-wide; initial values from FPCC_CONV_WAVE / FPCC_WAVE_NBW / FPCC_WAVE_SB).  None
+ * changes a result -- the tests run every setting against the same oracle output.  Returns the previous value.
+ *   0  use the wave kernel when packed weights are given (1) or the workgroup-tiled kernel (0)
+ *   1  column blocks per wave: 0 = by map size, else 1 | 2 | 4
+ *   2  1 = the next stage's address arithmetic may be scheduled between the MFMAs, 0 = nothing crosses the load points */
+int fpcc_conv_set_tuning(int which, int value);
+int fpcc_conv_pack_weights_f32(const float *w, int64_t n_mats, int c_in, int c_out, float *w_packed, void *stream);
+int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2,
+                     const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                     const float *w, const float *w_packed, const float *bias, int c_out, int groups,
+                     const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
+                     int act, const float *slope, float clip, const int32_t *row_order, void *ws, int64_t ws_bytes,
+                     void *stream);
 /* row_order (MFMA path only, NULL = natural): a permutation of [0, n_out); tile position p computes output row
  * row_order[p].  It changes which rows share a 32-row MFMA block -- and with it how many (block, offset) products are
  * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows

@@ -15,6 +15,8 @@ Sources of truth used:
                  (imported with lib.entropy_models.rans_coder -> oracle/_ref coder and the MinkowskiEngine wrapper
                  stubbed): seeded parameters, log_prob / prob, quantised CDF tables, compress strings
   kdtree.json    partition sizes / checksums of lib/data_utils.py:168-234 kd_tree_partition on seeded coordinates
+  me_semantics.json  the reference's own statements about MinkowskiEngine / torchsparse conventions: child tables, identity
+                 kernels of the fold convolutions, state_dict key / shape lists of its models built on a parameter-only stub engine
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -469,8 +471,148 @@ def make_ptq_import():
     return out
 
 
+def _stub_engines():
+    """Stand-ins for the two sparse-tensor engines, good for CONSTRUCTING the reference's modules only: every class creates
+    the parameters / sub-modules that MinkowskiEngine 0.5.4 documents (kernel [volume, C_in, C_out] -- 2-D for volume 1 --,
+    bias [1, C_out], MinkowskiLinear.linear = nn.Linear, MinkowskiPReLU.module = nn.PReLU, MinkowskiBatchNorm.bn =
+    nn.BatchNorm1d) and nothing can be evaluated.  What the fixtures take from them is the reference's own module tree:
+    names, order and shapes of its state_dict."""
+    import enum
+    import torch
+    import torch.nn as nn
+    ME = types.ModuleType('MinkowskiEngine')
+
+    class KernelGenerator:
+        def __init__(self, kernel_size=-1, stride=1, dilation=1, region_type=None, dimension=3, **_):
+            as3 = lambda v: [v] * dimension if isinstance(v, int) else list(v)
+            self.kernel_size, self.kernel_stride, self.kernel_dilation = as3(kernel_size), as3(stride), as3(dilation)
+            self.kernel_volume = int(np.prod(self.kernel_size))
+            self.region_type, self.dimension = region_type, dimension
+
+    class _Conv(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                     kernel_generator=None, expand_coordinates=False, dimension=3, **_):
+            super().__init__()
+            kg = kernel_generator or KernelGenerator(kernel_size, stride, dilation, dimension=dimension)
+            self.kernel_generator = kg
+            shape = (in_channels, out_channels) if kg.kernel_volume == 1 else (kg.kernel_volume, in_channels, out_channels)
+            self.kernel = nn.Parameter(torch.zeros(shape))
+            self.bias = nn.Parameter(torch.zeros(1, out_channels)) if bias else None
+
+    def wrap(name, attr, cls):
+        def init(self, *a, **k):
+            nn.Module.__init__(self)
+            setattr(self, attr, cls(*a, **k))
+        return type(name, (nn.Module,), {'__init__': init})
+
+    for name in ('MinkowskiConvolution', 'MinkowskiConvolutionTranspose', 'MinkowskiGenerativeConvolutionTranspose'):
+        setattr(ME, name, type(name, (_Conv,), {}))
+    ME.MinkowskiLinear = wrap('MinkowskiLinear', 'linear', nn.Linear)
+    ME.MinkowskiBatchNorm = wrap('MinkowskiBatchNorm', 'bn', nn.BatchNorm1d)
+    for name, cls in (('MinkowskiReLU', nn.ReLU), ('MinkowskiPReLU', nn.PReLU), ('MinkowskiLeakyReLU', nn.LeakyReLU),
+                      ('MinkowskiSigmoid', nn.Sigmoid)):
+        setattr(ME, name, wrap(name, 'module', cls))
+    for name in ('MinkowskiPruning', 'MinkowskiMaxPooling', 'MinkowskiPoolingTranspose', 'MinkowskiGlobalPooling',
+                 'MinkowskiAvgPooling', 'MinkowskiSumPooling', 'MinkowskiGlobalMaxPooling', 'MinkowskiGlobalAvgPooling'):
+        setattr(ME, name, type(name, (nn.Module,), {'__init__': lambda self, *a, **k: nn.Module.__init__(self)}))
+    ME.KernelGenerator = KernelGenerator
+    ME.RegionType = enum.Enum('RegionType', 'HYPER_CUBE HYPER_CROSS CUSTOM')
+    ME.MinkowskiAlgorithm = enum.Enum('MinkowskiAlgorithm', 'DEFAULT MEMORY_EFFICIENT SPEED_OPTIMIZED')
+    ME.CoordinateMapType = enum.Enum('CoordinateMapType', 'CPU CUDA')
+    ME.SparseTensorOperationMode = enum.Enum('SparseTensorOperationMode', 'SEPARATE_COORDINATE_MANAGER SHARE_COORDINATE_MANAGER')
+    ME.SparseTensorQuantizationMode = enum.Enum('SparseTensorQuantizationMode',
+                                                'RANDOM_SUBSAMPLE UNWEIGHTED_AVERAGE UNWEIGHTED_SUM NO_QUANTIZATION')
+    ME.set_sparse_tensor_operation_mode = lambda mode: None
+    for name in ('SparseTensor', 'CoordinateManager', 'CoordinateMapKey', 'TensorField'):
+        setattr(ME, name, type(name, (), {}))
+    mst = types.ModuleType('MinkowskiEngine.MinkowskiSparseTensor')
+    mst.SparseTensorQuantizationMode = ME.SparseTensorQuantizationMode
+    mst.SparseTensor = ME.SparseTensor
+    ME.MinkowskiSparseTensor = mst
+    sys.modules['MinkowskiEngine'] = ME
+    sys.modules['MinkowskiEngine.MinkowskiSparseTensor'] = mst
+    ts = types.ModuleType('torchsparse'); ts_nn = types.ModuleType('torchsparse.nn')
+    ts.SparseTensor = type('SparseTensor', (), {}); ts_nn.Conv3d = type('Conv3d', (), {}); ts.nn = ts_nn
+    ts_nn.__path__ = []; ts.__path__ = []                                   # importable as packages
+    ts_f = types.ModuleType('torchsparse.nn.functional'); ts_nn.functional = ts_f
+    ts_u = types.ModuleType('torchsparse.utils'); ts_u.__path__ = []; ts.utils = ts_u
+    ts_c = types.ModuleType('torchsparse.utils.tensor_cache'); ts_c.TensorCache = type('TensorCache', (), {}); ts_u.tensor_cache = ts_c
+    for name, mod in (('torchsparse', ts), ('torchsparse.nn', ts_nn), ('torchsparse.nn.functional', ts_f),
+                      ('torchsparse.utils', ts_u), ('torchsparse.utils.tensor_cache', ts_c)):
+        sys.modules[name] = mod
+    sys.modules.setdefault('plyfile', types.SimpleNamespace(PlyData=None, PlyElement=None))
+    sys.modules.setdefault('open3d', types.ModuleType('open3d'))        # only used by the evaluators' file IO
+    return ME
+
+
+def make_me_semantics():
+    """What the reference itself states about the two engines' conventions, read from the reference (not typed in):
+      * child table of `minkowski_expand_coord_2x` (lib/minkowski_sparse_conv_layers.py:403-408) -- offsets of the 8 children of
+        a voxel in kernel-index order of the MinkowskiEngine path (x fastest);
+      * `unfold_kernel` and the `fold2bin` identity kernel of the two lossless codecs (lossl_coord_me/model.py:328-337: ME
+        layout [K, C_in, C_out], x fastest; lossl_coord_int/model.py:240-246: [K, C_out, C_in], z fastest);
+      * names, order and shapes of the state_dict of lossy_coord_v2's PCC at baseline_r1 and of lossy_coord_lossy_color's PCC
+        at its baseline_r1, built on the stub engine above (the module tree is the reference's).
+    lib.* / models.* are imported from /root/reference with their JIT-built extensions stubbed."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    import yaml
+    _stub_engines()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]                      # earlier generators install partial stand-ins under these names
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}      # oracle/_ref: the reference's own coders
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from lib.minkowski_sparse_conv_layers import minkowski_expand_coord_2x
+        from models.convolutional.lossy_coord_v2.model import PCC as PCCv2
+        from models.convolutional.lossy_coord_v2.model_config import ModelConfig as CfgV2
+        from models.convolutional.lossy_coord_lossy_color.model import PCC as PCCcolor
+        from models.convolutional.lossy_coord_lossy_color.model_config import ModelConfig as CfgColor
+        from models.convolutional.lossl_coord_me.model import Model as ModelME
+        from models.convolutional.lossl_coord_me.model_config import Config as CfgME
+        from models.convolutional.lossl_coord_int.model import Model as ModelInt
+        from models.convolutional.lossl_coord_int.model_config import Config as CfgInt
+    finally:
+        ce.load = real
+    out = {}
+    zero = torch.zeros((1, 4), dtype=torch.int32)
+    out['expand_coord_2x'] = {str(s): minkowski_expand_coord_2x(zero, s)[0].tolist() for s in (2, 4, 16)}
+
+    def with_yaml(cfg, path):
+        with open(os.path.join(REF, path)) as f:
+            for k, v in yaml.safe_load(f)['model'].items():
+                assert hasattr(cfg, k), k
+                setattr(cfg, k, tuple(v) if isinstance(v, list) else v)
+        cfg.check()                             # the reference's own post-merge hook (lib/simple_config.py:17-37): types, then
+        return cfg                              # check_local_value, which broadcasts compressed_channels over the levels
+
+    def keys(model):
+        return [[k, list(v.shape) if isinstance(v, torch.Tensor) else None] for k, v in model.state_dict().items()]
+
+    me = ModelME(CfgME())
+    out['lossl_coord_me'] = {'unfold_kernel': me.unfold_kernel[0].tolist(),
+                             'fold2bin_kernel_shape': list(me.fold2bin_conv.kernel.shape),
+                             'fold2bin_kernel': me.fold2bin_conv.kernel.detach().reshape(8, 8).tolist(),
+                             'bin2oct_kernel': me.bin2oct_kernel.tolist()}
+    mi = ModelInt(CfgInt(), torch.device('cpu'))
+    out['lossl_coord_int'] = {'unfold_kernel': mi.unfold_kernel[0].tolist(),
+                              'fold2bin_kernel_shape': list(mi.fold2bin_kernel.shape),
+                              'fold2bin_kernel': mi.fold2bin_kernel.reshape(8, 8).tolist(),
+                              'bin2oct_kernel': mi.bin2oct_kernel.tolist(),
+                              'state_dict': keys(mi)}
+    out['lossy_coord_v2/baseline_r1'] = keys(PCCv2(with_yaml(CfgV2(), 'config/convolutional/lossy_coord_v2/baseline_r1.yaml')))
+    out['lossy_coord_lossy_color/baseline_r1'] = keys(PCCcolor(with_yaml(
+        CfgColor(), 'config/convolutional/lossy_coord_lossy_color/baseline_r1.yaml')))
+    return out
+
+
 def main():
-    for name, fn in (('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

@@ -75,3 +75,66 @@ def test_job_errors_surface_in_wait():
     pool.binary_encode(bits, np.array([5, 1, 7, 9], dtype=np.uint16))
     assert len(pool.wait()) == 1
     pool.close()
+
+
+# -- corrupt input must fail or finish, never spin (a pool thread that hangs blocks wait() and the pool's destructor) ----
+def test_zero_state_stream_is_rejected_not_spun_on():
+    from fastpcc_amd.rans_coder import RansDecoder
+    zeros = b'\0\0\0\0' + b'\0' * 12
+    out = np.empty((1, 20000), dtype=np.int32)
+    coder = IndexedRansCoder(False, 1)
+    coder.init_with_quantized_cdfs([[0, 30000, 65536]], np.zeros(1, np.int32))
+    with pytest.raises((RuntimeError, ValueError)):
+        coder.decode([zeros], out)                                   # single-table path (n >= 8192)
+    with pytest.raises((RuntimeError, ValueError)):
+        coder.decode([zeros], out[:, :10].copy())                    # search path
+    esc = IndexedRansCoder(True, 1)
+    esc.init_with_pmfs(np.array([[.1, .2, .4, .2, .1]]), np.array([-2], dtype=np.int32))
+    with pytest.raises((RuntimeError, ValueError)):
+        esc.decode([zeros], out[:, :10].copy())                      # the escape tail reads 1-bit symbols: was unbounded
+    with pytest.raises((RuntimeError, ValueError)):
+        BinaryRansCoder(1).decode([zeros], np.full((1, 50), 1000, np.uint32), np.zeros((1, 50), dtype=bool))
+    with pytest.raises((RuntimeError, ValueError)):
+        RansDecoder().flush(zeros)
+    pool = CoderPool(1)
+    sym = np.empty(20000, dtype=np.int32)
+    prog = pool.table_decode(zeros, sym.size, [0, 30000, 65536], 0, sym)
+    with pytest.raises((RuntimeError, ValueError)):
+        pool.need(prog, sym.size)
+    with pytest.raises((RuntimeError, ValueError)):
+        pool.wait()
+    pool.close()
+
+
+def test_state_collapsing_mid_stream_terminates():
+    # a well-formed head followed by a truncated body: the decoder shifts in zeros past the end; it must return
+    rng = np.random.default_rng(11)
+    bits, p, stream = _binary_case(rng, 40000)
+    out = np.zeros((1, bits.size), dtype=bool)
+    BinaryRansCoder(1).decode([stream[:8]], p[None].astype(np.uint32), out)       # garbage out, but finite
+    coder = IndexedRansCoder(False, 1)
+    coder.init_with_quantized_cdfs([[0, 1, 65536]], np.zeros(1, np.int32))
+    sym = np.empty((1, 30000), dtype=np.int32)
+    coder.decode([bytes([0, 0, 128, 0])], sym)          # state 2^23, slot 0 -> bin 0 of frequency 1: the state shrinks every step
+
+
+def test_non_monotone_cdf_from_a_bitstream_is_rejected():
+    bad = [0, 40000, 40000, 65536]          # a zero-frequency bin: an unmapped slot would decode with freq 0
+    coder = IndexedRansCoder(False, 1)
+    coder.init_with_quantized_cdfs([bad], np.zeros(1, np.int32))
+    stream = bytes([0, 0, 128, 0, 1, 2, 3])
+    with pytest.raises((RuntimeError, ValueError)):
+        coder.decode([stream], np.empty((1, 9000), dtype=np.int32))
+    with pytest.raises((RuntimeError, ValueError)):
+        coder.decode([stream], np.empty((1, 9), dtype=np.int32))
+    pool = CoderPool(1)
+    with pytest.raises((RuntimeError, ValueError)):
+        pool.table_decode(stream, 9000, bad, 0, np.empty(9000, dtype=np.int32))
+    assert pool.wait() == []
+    pool.close()
+
+
+def test_all_zero_histogram_is_an_error_not_undefined_behaviour():
+    from fastpcc_amd.rans_coder import batched_pmf_to_quantized_cdf
+    with pytest.raises((RuntimeError, ValueError)):
+        batched_pmf_to_quantized_cdf(np.zeros((1, 5)), np.zeros(1, np.int32), False)

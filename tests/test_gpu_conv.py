@@ -314,3 +314,96 @@ def test_row_order_on_tiny_maps(ops, n):
     table[table >= n] = -1
     order = ops.conv_row_order(_cuda(table), 27, n, 1, n, 5)
     assert sorted(order.cpu().tolist()) == list(range(n))
+
+
+# ---- wave-autonomous kernel (packed weights): every tuning must give the workgroup-tiled kernel's bits -------------
+@pytest.fixture()
+def knobs(ops):
+    saved = [ops.conv_set_tuning(k, v) for k, v in ((ops.KNOB_WAVE_ON, 1), (ops.KNOB_WAVE_NBW, 0), (ops.KNOB_WAVE_SB, 1))]
+    yield ops
+    for k, v in zip((ops.KNOB_WAVE_ON, ops.KNOB_WAVE_NBW, ops.KNOB_WAVE_SB), saved):
+        ops.conv_set_tuning(k, v)
+
+
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (64, 0, 128), (128, 0, 64), (64, 0, 64), (32, 0, 32),
+                                         (96, 0, 32), (32, 32, 64)])
+def test_wave_kernel_conv3_equals_tiled_kernel_and_oracle(knobs, scene, c1, c2, c_out):
+    ops = knobs
+    rng = np.random.default_rng(c1 * 7 + c2 * 3 + c_out)
+    lvl, table = scene['lvl'], scene['k3']
+    n = lvl.n
+    x1 = _cuda(rng.normal(size=(n, c1)).astype(np.float32))
+    x2 = _cuda(rng.normal(size=(n, c2)).astype(np.float32)) if c2 else None
+    w = _cuda((rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32))
+    b = _cuda(rng.normal(size=c_out).astype(np.float32))
+    slope = torch.tensor([0.2], device='cuda')
+    nbr = _cuda(table)
+    order = ops.conv_row_order(nbr, 27, n, 1, n, 13)
+    kw = dict(x2=x2, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, bias=b, act=ops.ACT_PRELU, slope=slope, clip=1.5)
+    base = ops.conv_f32(x1, w, c_out, n, **kw).cpu().numpy()
+    want = sc.conv_chain(x1.cpu().numpy(), table, w.cpu().numpy(), b.cpu().numpy(), n, x2=None if x2 is None else x2.cpu().numpy(),
+                         act=sc.ACT_PRELU, slope=0.2, clip=1.5, order=1)
+    assert (_bits(base) == _bits(want)).all()
+    assert ops.packed_weights(w, c1, c2, c_out, 27, 1) is not None
+    for nbw in (1, 2, 4):
+        for sb in (0, 1):
+            ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
+            ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
+            for ro in (None, order):
+                got = ops.conv_f32(x1, w, c_out, n, row_order=ro, pack=True, **kw).cpu().numpy()
+                assert (_bits(got) == _bits(base)).all(), (nbw, sb, ro is not None)
+
+
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 127, 128, 129, 4999])
+def test_wave_kernel_ragged_row_counts_pointwise(knobs, n):
+    ops = knobs
+    rng = np.random.default_rng(n)
+    for c1, c2, c_out in ((128, 0, 128), (64, 64, 32), (32, 0, 64)):
+        x1 = _cuda(rng.normal(size=(n, c1)).astype(np.float32))
+        x2 = _cuda(rng.normal(size=(n, c2)).astype(np.float32)) if c2 else None
+        w = _cuda(rng.normal(size=(c1 + c2, c_out)).astype(np.float32))
+        b = _cuda(rng.normal(size=c_out).astype(np.float32))
+        base = ops.conv_f32(x1, w, c_out, n, x2=x2, bias=b).cpu().numpy()
+        for nbw in (1, 2, 4):
+            ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
+            got = ops.conv_f32(x1, w, c_out, n, x2=x2, bias=b, pack=True).cpu().numpy()
+            assert (_bits(got) == _bits(base)).all(), (c1, c2, c_out, nbw)
+
+
+def test_wave_kernel_strided_transposed_generative(knobs, scene):
+    ops = knobs
+    rng = np.random.default_rng(99)
+    lvl, up = scene['lvl'], scene['up']
+    child_row = _cuda(np.ascontiguousarray(scene['k2'].T))
+    slope = torch.tensor([0.3], device='cuda')
+    for c_in, c_out in ((64, 64), (128, 128), (32, 32), (128, 32)):
+        xf = _cuda(rng.normal(size=(lvl.n, c_in)).astype(np.float32))
+        xc = _cuda(rng.normal(size=(up.n, c_in)).astype(np.float32))
+        w = _cuda((rng.normal(size=(8, c_in, c_out)) / np.sqrt(c_in)).astype(np.float32))
+        b = _cuda(rng.normal(size=c_out).astype(np.float32))
+        cases = [
+            (xf, dict(n_out=up.n, nbr=child_row, n_offsets=8, nbr_ks=1, nbr_os=8, bias=b, act=ops.ACT_RELU)),        # stride 2
+            (xc, dict(n_out=up.n, groups=8, out_map=child_row, om_os=8, om_gs=1, out_rows=lvl.n, bias=b,
+                      act=ops.ACT_PRELU, slope=slope)),                                                               # transposed
+            (xc, dict(n_out=up.n, groups=8, bias=b, act=ops.ACT_PRELU, slope=slope)),                                 # generative
+        ]
+        for x, kw in cases:
+            n_out = kw.pop('n_out')
+            rows = kw.get('out_rows')
+            def run(**extra):
+                out = torch.zeros((rows, c_out), device='cuda') if rows else None      # rows without a parent stay untouched
+                return ops.conv_f32(x, w, c_out, n_out, out=out, **{k: v for k, v in kw.items() if k != 'out_rows'}, **extra).cpu().numpy()
+            base = run()
+            for nbw in (1, 2, 4):
+                ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
+                assert (_bits(run(pack=True)) == _bits(base)).all(), (c_in, c_out, nbw, sorted(kw))
+
+
+def test_packed_weights_follow_in_place_updates(knobs):
+    ops = knobs
+    x = torch.randn((300, 64), device='cuda')
+    w = torch.randn((64, 64), device='cuda')
+    a = ops.conv_f32(x, w, 64, 300, pack=True)
+    w.mul_(2.0)                                     # same storage, new version: the packed copy must be rebuilt
+    b = ops.conv_f32(x, w, 64, 300, pack=True)
+    assert torch.equal(b, ops.conv_f32(x, w, 64, 300)) and not torch.equal(a, b)

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
 from torch.profiler import profile, ProfilerActivity
-from util import enliven
+from fastpcc_amd.synthetic import enliven
 from fastpcc_amd import engine as ME
 from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
 from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import baseline_r1

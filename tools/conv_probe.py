@@ -26,8 +26,9 @@ torch.manual_seed(0)
 f = torch.randn((n, c_in), device='cuda')
 w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
 pairs = int((nbr >= 0).sum().item())
+PACK = bool(int(os.environ.get('PACK', '1')))
 def run(row_order):
-    return ops.conv_f32(f, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=row_order)
+    return ops.conv_f32(f, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=row_order, pack=PACK)
 def lpt(order, group):
     present = (nbr >= 0)[:, order.long()]
     pad = (-n) % group
@@ -37,14 +38,24 @@ def lpt(order, group):
     body = order[:full * group].reshape(full, group)[gp].reshape(-1)
     return torch.cat([body, order[full * group:]]).contiguous()
 cases = [('natural', None), ('pattern', order)]
+if os.environ.get('ONLY'):
+    cases = [c for c in cases if c[0] == os.environ['ONLY']]
+variants = [(None, None)]
+if os.environ.get('SWEEP'):
+    variants = [(0, 0)] + [(nbw, sb) for nbw in (1, 2, 4) if nbw <= c_out // 32 for sb in (0, 1)]
 if os.environ.get('LPT'):
     cases.append(('pattern+lpt', lpt(order, int(os.environ['LPT']))))
-for name, ro in cases:
+for (nbw, sb) in variants:
+  tag = ''
+  if nbw is not None:
+      ops.conv_set_tuning(ops.KNOB_WAVE_ON, int(nbw > 0)); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
+      tag = f' [tiled kernel]' if nbw == 0 else f' [wave nbw={nbw} sb={sb}]'
+  for name, ro in cases:
     for _ in range(3):
         run(ro)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
         run(ro)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-    print(f'level {level} rows {n} pairs/row {pairs / n:.2f} {c_in}->{c_out} {name} order: {dt * 1e6:.1f} us  '
+    print(f'level {level} rows {n} pairs/row {pairs / n:.2f} {c_in}->{c_out} {name} order{tag}: {dt * 1e6:.1f} us  '
           f'{2 * pairs * c_in * c_out / dt / 1e12:.1f} TFLOP/s algorithmic')

@@ -4,7 +4,7 @@ import cProfile, os, pstats, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-from util import enliven
+from fastpcc_amd.synthetic import enliven
 from fastpcc_amd import engine as ME
 from fastpcc_amd.codecs.lossy_coord_v2 import Model
 from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from torch.profiler import profile, ProfilerActivity
-from util import enliven
+from fastpcc_amd.synthetic import enliven
 from fastpcc_amd import engine as ME
 from fastpcc_amd.codecs.lossy_coord_v2 import Model
 from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
