@@ -346,12 +346,19 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a, int n_jb) {
 template <int NBW, int CH>
 struct WaveCfg {
     static constexpr int G8 = CH / 8;
-    static constexpr int MIN_WAVES = NBW >= 4 ? 3 : (NBW == 2 ? 4 : 6);   // per SIMD: accumulators 16 NBW + B 16 NBW + A 16 + addresses
+    static constexpr int REGS = 16 * NBW + 16 * (1 + NBW) + 28;              // accumulators + operands + addresses
+    static constexpr int MIN_WAVES = REGS <= 96 ? 5 : REGS <= 128 ? 4 : 3;   // per SIMD
 };
 
-template <int NBW, int CH, int SB>
+// Operand registers: ONE A buffer and ONE B buffer refilled in place group by group -- right after the MFMAs of group g8 have
+// consumed ra[g8] / rb[g8][*] the same registers are loaded with group g8 of the NEXT stage, so every load has a whole stage
+// of MFMAs to land and nothing is copied.  (A ring of 2-4 whole-stage buffers, refilled after the stage's last MFMA, was
+// 30-50 % slower on every map size: profiles/r02/wave_kernel_sweeps.md.)
+// DBG (timing experiments only, results are wrong): bit 0 = every gathered row is row 0 (no gather traffic), bit 1 = every
+// stage reads the weights of chunk 0 (B stream stays in the vector L1)
+template <int NBW, int CH, int SB, int DBG = 0>
 __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
-                                                                                  int nbt, unsigned n_units) {
+                                                                                         int nbt, unsigned n_units) {
     constexpr int G8 = CH / 8;
     __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
 
@@ -363,9 +370,9 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
     const unsigned blk = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const unsigned unit = blk * 4u + (unsigned)wv;
     if (unit >= n_units) return;                    // no barrier below: a wave may leave on its own
-    const unsigned rb = unit / n_cg, cg = unit - rb * n_cg;
+    const unsigned rb_ = unit / n_cg, cg = unit - rb_ * n_cg;
     const int g = blockIdx.y;
-    const int64_t row0 = (int64_t)rb * 32;
+    const int64_t row0 = (int64_t)rb_ * 32;
     const int c_in = a.c1 + a.c2;
     const int n_chunks = c_in / CH;
     int32_t *s_nbr = s_nbr_all[wv];
@@ -396,8 +403,8 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
         // packed weights of (group g, offset k, chunk cc): G8 * nbt KB-blocks; this wave reads blocks [cg*NBW, cg*NBW + NBW) of each g8
         const int64_t chunk_floats = (int64_t)G8 * nbt * 256;
         const float *wp_g = wp + (int64_t)g * a.n_off * n_chunks * chunk_floats + ((int64_t)cg * NBW) * 256 + lane * 4;
-        // Branch-free on purpose: control flow inside the stage loop makes hipcc drain vmcnt(0) at the join, which would
-        // wait for the loads issued a moment ago.  Loop invariants are taken out by hand (the compiler re-reads kernel
+        // Branch-free on purpose: divergent control flow inside the stage loop makes hipcc drain vmcnt(0) at the join, which
+        // would wait for the loads issued a moment ago.  Loop invariants are taken out by hand (the compiler re-reads kernel
         // arguments and the zero row's address through scalar loads -- and waits for them -- inside the loop otherwise).
         const float *const zero = (const float *)g_zero_row + 4 * lh;
         const float *const x1b = a.x1 + 4 * lh, *const x2b = a.x2 ? a.x2 + 4 * lh - a.c1 : zero;
@@ -407,48 +414,49 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
             const bool in_x1 = cc * CH < c1;                 // wave-uniform
             const float *xb = (in_x1 ? x1b : x2b) + cc * CH;
             const int64_t ld = in_x1 ? ld1 : ld2;
-            const int32_t idx = s_nbr[k * 32 + li];
+            int32_t idx = s_nbr[k * 32 + li];
+            if (DBG & 1) idx = idx < 0 ? idx : 0;
             const int32_t neg = idx >> 31;                    // 0 or ~0; a select here comes back as a branch (if-conversion)
             const uint64_t m = (uint64_t)(int64_t)neg;
             const uint64_t p = reinterpret_cast<uint64_t>(xb + (int64_t)(idx & ~neg) * ld);
             return reinterpret_cast<const float *>((p & ~m) | (reinterpret_cast<uint64_t>(zero) & m));
         };
+        // fetch position: the next (offset, chunk) stage whose operands are to be requested; past the last stage it stays
+        // on the last one (re-read, never used)
         unsigned rest = wmask;
-        int k_cur = __ffs(rest) - 1;
-        int k_next = k_cur, cc_next = 0;
-        // Register plan: ONE A buffer and ONE B buffer, both refilled in place group by group -- right after the MFMAs of
-        // group g8 have consumed ra[g8] / rb[g8][*], the same registers are loaded with group g8 of the NEXT stage, so every
-        // load has a whole stage of MFMAs (64 x NBW/4 x 64 cycles) to land and nothing is copied.  hipcc's scheduler would
-        // otherwise sink every load down to its first use (it minimises live ranges), exposing a full L2 / HBM latency per
-        // stage; sched_barrier pins the issue points.  Mask SB lets the scalar / vector address arithmetic of the next
-        // stage float between the MFMAs (0: nothing crosses).
+        int k_f = __ffs(rest) - 1, cc_f = 0;
+        const float *ap, *bp;
+        auto next_stage = [&]() {
+            ap = a_ptr(k_f, cc_f);
+            bp = (DBG & 2) ? wp_g : wp_g + ((int64_t)k_f * n_chunks + cc_f) * chunk_floats;
+            if (cc_f + 1 < n_chunks) {
+                ++cc_f;
+            } else {
+                const unsigned r2 = rest & (rest - 1);
+                if (r2) { rest = r2; k_f = __ffs(r2) - 1; cc_f = 0; }
+            }
+        };
+        // hipcc's scheduler would sink every load down to its first use (it minimises live ranges), exposing a full L2 / HBM
+        // latency per stage; sched_barrier pins the issue points.  Mask SB lets the scalar / vector address arithmetic of the
+        // next stage float between the MFMAs (0: nothing crosses).
         f32x4 ra[G8], rb[G8][NBW];
-        {
-            // first stage's operands, issued in the SAME order as the refills inside the loop (group by group, A then B): the
-            // wait counts at the loop head are merged over both ways into it, and a different order here (the scheduler
-            // reverses it if left alone) turns them into vmcnt(0) on every iteration
-            const float *ap = a_ptr(k_cur, 0);
-            const float *bp = wp_g + (int64_t)k_cur * n_chunks * chunk_floats;
+        // The first stage's operands, issued in the SAME order as the refills inside the loop (group by group, A then B): the
+        // wait counts at the loop head are merged over both ways into it, and a different order here (the scheduler reverses
+        // it if left alone) turns them into vmcnt(0) on every iteration.
+        next_stage();
 #pragma unroll
-            for (int g8 = 0; g8 < G8; ++g8) {
-                __builtin_amdgcn_sched_barrier(0);
-                ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    rb[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
-                }
-            }
+        for (int g8 = 0; g8 < G8; ++g8) {
             __builtin_amdgcn_sched_barrier(0);
-        }
-        for (int s = 0; s < n_stages; ++s) {
-            if (++cc_next == n_chunks) {
-                cc_next = 0;
-                rest &= rest - 1;
-                k_next = rest ? __ffs(rest) - 1 : k_cur;       // past the last stage: re-read a valid one (never used)
+            ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                __builtin_amdgcn_sched_barrier(0);
+                rb[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
             }
-            const float *ap = a_ptr(k_next, cc_next);
-            const float *bp = wp_g + ((int64_t)k_next * n_chunks + cc_next) * chunk_floats;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < n_stages; ++s) {
+            next_stage();                                       // stage s + 1
             __builtin_amdgcn_sched_barrier(SB);
 #pragma unroll
             for (int g8 = 0; g8 < G8; ++g8) {
@@ -471,7 +479,6 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
                 }
                 __builtin_amdgcn_sched_barrier(SB);
             }
-            k_cur = k_next;
         }
     }
 
@@ -600,12 +607,12 @@ __global__ __launch_bounds__(256) void k_conv_c1_pointwise(ConvArgs a) {
 }
 
 // Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
-enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobCount = 3 };
-int g_knob[kKnobCount] = {-1, -1, -1};
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobCount = 5 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
-        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB"};
-        static const int defaults[kKnobCount] = {1, 0, 1};
+        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 8192};
         const char *e = getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
@@ -617,21 +624,27 @@ int launch_wave_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) 
     const int64_t row_blocks = (a.n_out + 31) / 32;
     const int64_t units = row_blocks * (nbt / NBW);
     if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
-    // knob FPCC_WAVE_SB=1: the address arithmetic of the next stage may be scheduled between the MFMAs
-    const int sb = knob(kKnobWaveSb);
     const dim3 grid((unsigned)((units + 3) / 4), a.groups);
-    if (sb) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    const int dbg = knob(kKnobWaveDbg);
+    // knob FPCC_WAVE_SB=1: the address arithmetic of the next stage may be scheduled between the MFMAs
+    if (dbg == 1) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 1>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (dbg == 2) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 2>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (dbg == 3) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 3>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (knob(kKnobWaveSb)) hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
     else hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
     return check_hip(hipGetLastError(), "k_conv_wave");
 }
 
-// Column blocks per wave by map size (knob FPCC_WAVE_NBW=1|2|4 forces): wide units on large maps (every gathered row
-// fetched once, fewest B loads per MFMA), narrow units where the launch would otherwise not fill the chip.
+// Unit width (column blocks per wave) by map size, measured on MI355X (profiles/r02/wave_kernel_sweeps.md): two column blocks
+// from 32 Ki rows up, one below -- on a 18 K-row map one-block units are 20 % faster (4x the units for the same chip), on
+// 272 K rows two-block units gather every row half as often.  Four-block units (every row gathered once) are never the
+// fastest: the B stream is 256 bytes per MFMA at any width, and three waves per SIMD hide less than five.
+// Knob FPCC_WAVE_NBW = 1|2|4 forces.
 int launch_wave(const ConvArgs &a, const float *wp, hipStream_t s) {
-    const int forced = knob(kKnobWaveNbw);
     const int nbt = a.c_out / 32;
     const int64_t work = a.n_out * a.groups;
-    int nbw = forced > 0 ? forced : (work >= 128 * 1024 ? 4 : work >= 16 * 1024 ? 2 : 1);
+    int nbw = knob(kKnobWaveNbw);
+    if (nbw <= 0) nbw = work >= 32 * 1024 ? 2 : 1;
     while (nbw > nbt || nbt % nbw) nbw >>= 1;
     if (nbw >= 4) return launch_wave_cfg<4>(a, wp, nbt, s);
     if (nbw == 2) return launch_wave_cfg<2>(a, wp, nbt, s);
@@ -650,8 +663,10 @@ int launch_valu(const ConvArgs &a, hipStream_t s) {
 
 using namespace fpcc;
 
-// rows up to which multi-offset convolutions are evaluated offset-split (workspace: n_offsets * n_out * c_out floats)
-constexpr int64_t kSplitMaxRows = 8192;
+// rows up to which multi-offset convolutions are evaluated offset-split (workspace: n_offsets * n_out * c_out floats).
+// NOT a tuning knob in production: it selects summation order 2 vs 1, i.e. the bits of the result (FPCC_SPLIT_MAX_ROWS /
+// knob 4 exist for experiments; encoder and decoder must agree on it).
+#define kSplitMaxRows ((int64_t)knob(kKnobSplitRows))
 
 static bool use_split(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
     return mfma_chunk(c1, c2, c_out) == 32 && (c_out == 128 || c_out == 64 || c_out == 32) && n_offsets >= 8 &&

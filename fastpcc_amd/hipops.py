@@ -282,7 +282,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
     return out
 
 
-KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB = 0, 1, 2
+KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS = 0, 1, 2, 3, 4
 
 
 def conv_set_tuning(which: int, value: int) -> int:
@@ -321,7 +321,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     if om_os == 0:
         om_os = groups
     ws, ws_bytes = None, 0
-    if n_offsets >= 8 and nbr is not None and n_out <= 8192:
+    if n_offsets >= 8 and nbr is not None and n_out <= 65536:
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)

@@ -78,6 +78,10 @@ class OracleV2:
         self.order_fn = order_fn or (lambda kind, c1, c2, c_out, n_out: 0)
         self._kmaps = {}
         self.trace: Dict[str, np.ndarray] = {}     # activations by layer prefix (filled when keep_trace)
+        # The reference goes on evaluating the feature predictors below the last coded level and discards the result
+        # (geo_lossl_em.py:196-210, `del lower_fea_recon`).  True stops where the product stops (same bytes: nothing reads
+        # that tail); used when this oracle is TIMED beside the GPU path, so that both do the same work.
+        self.skip_unused_tail = False
         self.keep_trace = False
 
     # ---- primitive layers ----------------------------------------------------------------------------------------
@@ -265,6 +269,9 @@ class OracleV2:
         lower = bottom
         coord_strings = []
         self.symbols = {'occupancy': [], 'prob': []}
+        strides = [f.level.stride for f in feas] + [bottom.level.stride]
+        last_coded = min((i for i in range(len(feas)) if i > cfg.skip_encoding_fea or strides[i] != strides[i + 1]),
+                         default=len(feas))
         for idx in range(len(feas) - 1, -1, -1):
             fea = feas[idx]
             target = fea.level
@@ -275,12 +282,16 @@ class OracleV2:
                 coord_strings.append(BinaryRansCoder(1).encode(mask.reshape(1, -1), prob.reshape(1, -1))[0])
                 self.symbols['occupancy'].append(mask)
                 self.symbols['prob'].append(prob.reshape(-1))
+            if self.skip_unused_tail and idx <= last_coded and idx <= cfg.skip_encoding_fea:
+                break
             fea_pred = self.hyper_fea(idx, lower, target)
             if idx > cfg.skip_encoding_fea:
                 res = self.residual(idx, fea, fea_pred).f
                 res = torch.round(res * scaler)
                 res_list.append(res.to(torch.int32).numpy())
                 res = res / scaler
+                if self.skip_unused_tail and idx == last_coded:
+                    break
                 lower = self.em_decoder_block(idx, fea_pred, res)
             else:
                 lower = self.em_decoder_block(idx, fea_pred)

@@ -345,13 +345,12 @@ def test_wave_kernel_conv3_equals_tiled_kernel_and_oracle(knobs, scene, c1, c2, 
                          act=sc.ACT_PRELU, slope=0.2, clip=1.5, order=1)
     assert (_bits(base) == _bits(want)).all()
     assert ops.packed_weights(w, c1, c2, c_out, 27, 1) is not None
-    for nbw in (1, 2, 4):
-        for sb in (0, 1):
-            ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
-            ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
-            for ro in (None, order):
-                got = ops.conv_f32(x1, w, c_out, n, row_order=ro, pack=True, **kw).cpu().numpy()
-                assert (_bits(got) == _bits(base)).all(), (nbw, sb, ro is not None)
+    for nbw, sb in ((1, 0), (1, 1), (2, 0), (2, 1), (4, 0), (4, 1), (0, 1)):
+        ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
+        ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
+        for ro in (None, order):
+            got = ops.conv_f32(x1, w, c_out, n, row_order=ro, pack=True, **kw).cpu().numpy()
+            assert (_bits(got) == _bits(base)).all(), (nbw, sb, ro is not None)
 
 
 @pytest.mark.parametrize('n', [1, 31, 32, 33, 127, 128, 129, 4999])
@@ -364,7 +363,7 @@ def test_wave_kernel_ragged_row_counts_pointwise(knobs, n):
         w = _cuda(rng.normal(size=(c1 + c2, c_out)).astype(np.float32))
         b = _cuda(rng.normal(size=c_out).astype(np.float32))
         base = ops.conv_f32(x1, w, c_out, n, x2=x2, bias=b).cpu().numpy()
-        for nbw in (1, 2, 4):
+        for nbw in (1, 2, 4, 0):
             ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
             got = ops.conv_f32(x1, w, c_out, n, x2=x2, bias=b, pack=True).cpu().numpy()
             assert (_bits(got) == _bits(base)).all(), (c1, c2, c_out, nbw)
@@ -394,7 +393,7 @@ def test_wave_kernel_strided_transposed_generative(knobs, scene):
                 out = torch.zeros((rows, c_out), device='cuda') if rows else None      # rows without a parent stay untouched
                 return ops.conv_f32(x, w, c_out, n_out, out=out, **{k: v for k, v in kw.items() if k != 'out_rows'}, **extra).cpu().numpy()
             base = run()
-            for nbw in (1, 2, 4):
+            for nbw in (1, 2, 4, 0):
                 ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw)
                 assert (_bits(run(pack=True)) == _bits(base)).all(), (c_in, c_out, nbw, sorted(kw))
 

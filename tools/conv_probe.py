@@ -41,15 +41,20 @@ cases = [('natural', None), ('pattern', order)]
 if os.environ.get('ONLY'):
     cases = [c for c in cases if c[0] == os.environ['ONLY']]
 variants = [(None, None)]
+DBG = [int(v) for v in os.environ.get('DBG', '0').split(',')]
 if os.environ.get('SWEEP'):
     variants = [(0, 0)] + [(nbw, sb) for nbw in (1, 2, 4) if nbw <= c_out // 32 for sb in (0, 1)]
+if os.environ.get('NBWS'):
+    variants = [(int(v), 1) for v in os.environ['NBWS'].split(',')]
+DEPTHS = [int(v) for v in os.environ.get('DEPTHS', '0').split(',')]
 if os.environ.get('LPT'):
     cases.append(('pattern+lpt', lpt(order, int(os.environ['LPT']))))
-for (nbw, sb) in variants:
+for dbg, depth, (nbw, sb) in [(a, b, c) for a in DBG for b in DEPTHS for c in variants]:
+  ops.conv_set_tuning(3, dbg)
   tag = ''
   if nbw is not None:
       ops.conv_set_tuning(ops.KNOB_WAVE_ON, int(nbw > 0)); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
-      tag = f' [tiled kernel]' if nbw == 0 else f' [wave nbw={nbw} sb={sb}]'
+      tag = f' [tiled kernel]' if nbw == 0 else f' [wave nbw={nbw} depth={depth} sb={sb} dbg={dbg}]'
   for name, ro in cases:
     for _ in range(3):
         run(ro)
