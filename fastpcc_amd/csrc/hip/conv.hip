@@ -580,13 +580,27 @@ int launch_split(ConvArgs a, hipStream_t s) {
     return check_hip(hipGetLastError(), "k_split_reduce");
 }
 
+// Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobMfmaCfg = 5, kKnobCount = 6 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1};
+int knob(int k) {
+    if (g_knob[k] < 0) {
+        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS",
+                                                "FPCC_MFMA_TILE"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 8192, 0};
+        const char *e = getenv(names[k]);
+        g_knob[k] = e ? atoi(e) : defaults[k];
+    }
+    return g_knob[k];
+}
+
 // Tile height by map size, measured on MI355X (profiles/r01, FPCC_MFMA_CFG sweeps): 64-row tiles (2x2 waves) from 32 Ki
 // rows up -- against 128-row tiles they halve the tail of the last wave of workgroups and execute fewer (tile, offset)
 // stages -- 128-row tiles (4x1) only for C_out <= 64 on the largest maps, 32-row tiles (1xNBT) below 32 Ki rows.
-// FPCC_MFMA_CFG=0|1|2 forces 128|64|32 rows (tuning aid, read once).
+// Knob FPCC_MFMA_TILE = 1|2|3 forces 128|64|32 rows (0: by size).
 template <int NBT, int CH>
 int launch_mfma(const ConvArgs &a, hipStream_t s) {
-    static const int forced = [] { const char *e = getenv("FPCC_MFMA_CFG"); return e ? atoi(e) : -1; }();
+    const int forced = knob(kKnobMfmaCfg) - 1;
     const int64_t work = a.n_out * a.groups;
     constexpr int WNS = NBT >= 2 ? 2 : 1;       // 64-row tile: 2 x WNS waves
     const int cfg = forced >= 0 ? forced : (NBT <= 2 && work >= 128 * 1024) ? 0 : work >= 32 * 1024 ? 1 : 2;
@@ -604,19 +618,6 @@ __global__ __launch_bounds__(256) void k_conv_c1_pointwise(ConvArgs a) {
     const int j = (int)(e - o * a.c_out);
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
     a.out[o * a.ldo + j] = finish(fmaf(a.x1[o * a.ld1], a.w[j], 0.0f), a.bias ? a.bias[j] : 0.0f, a.act, slope, a.clip);
-}
-
-// Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
-enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobCount = 5 };
-int g_knob[kKnobCount] = {-1, -1, -1, -1, -1};
-int knob(int k) {
-    if (g_knob[k] < 0) {
-        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, 8192};
-        const char *e = getenv(names[k]);
-        g_knob[k] = e ? atoi(e) : defaults[k];
-    }
-    return g_knob[k];
 }
 
 template <int NBW>

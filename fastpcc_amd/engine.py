@@ -245,7 +245,10 @@ class CoordinateManager:
             g = _Map(m.level - 1, m.bits + 1, 8 * m.n, None)
             g.parent, g.generated = m, True
             m.gen_child = g
-            self._register(g, 'gen')
+            # MinkowskiEngine gives the output map of a generative transposed convolution the empty string id; the reference
+            # relies on it (geo_lossl_em.py:272 builds id + 'pruned', lossy_coord_v2/layers.py:155-157 then looks 'pruned' up
+            # when the stride holds more than one map).  An id already taken at this stride gets a '#n' suffix (_register).
+            self._register(g, '')
         return m.gen_child
 
     def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str, count_hint: Optional[int] = None) -> _Map:
@@ -301,12 +304,34 @@ class CoordinateManager:
         return m.coords
 
     def kernel_map(self, in_key: CoordinateMapKey, out_key: CoordinateMapKey, stride=1, kernel_size=1, **_):
-        """Only the kernel_size == 1 form the reference uses (membership of `in` rows in `out`):
-        {0: int64 [2, L]} with row 0 = input rows, row 1 = output rows."""
+        """{kernel index k: int64 [2, L_k]} with row 0 = input rows, row 1 = output rows (ME: cm.kernel_map), kernel indexes
+        enumerated x fastest.  kernel_size 1 (membership of `in` rows in `out`, the form the codecs use:
+        geo_lossl_em.py:313, lossy_coord_v2/layers.py:186); 3 on one map (the 27-neighbour table); 2 with stride 2 from a map
+        to its stride-2 parent (the child table)."""
         ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
-        if ks != 1:
-            raise NotImplementedError('kernel_map is only provided for kernel_size == 1')
+        st = stride if isinstance(stride, int) else stride[0]
         a, b = self._map(in_key), self._map(out_key)
+        if ks == 3 and st == 1:
+            if a is not b:
+                raise NotImplementedError('kernel_map(kernel_size=3) is provided on one coordinate map')
+            nbr = self._nbr27(a)
+            out = {}
+            for k in range(27):
+                rows_out = torch.nonzero(nbr[k] >= 0).squeeze(1)
+                if rows_out.numel():
+                    out[k] = torch.stack((nbr[k][rows_out].long(), rows_out))
+            return out
+        if ks == 2 and st == 2:
+            if a.parent is not b or a.generated:
+                raise NotImplementedError('kernel_map(kernel_size=2, stride=2) maps a level onto its stride-2 parent')
+            out = {}
+            for k in range(8):
+                rows_out = torch.nonzero(a.child_row[:, k] >= 0).squeeze(1)
+                if rows_out.numel():
+                    out[k] = torch.stack((a.child_row[rows_out, k].long(), rows_out))
+            return out
+        if ks != 1:
+            raise NotImplementedError(f'kernel_map(kernel_size={ks}, stride={st})')
         if a.level != b.level:
             raise NotImplementedError('kernel_map(kernel_size=1) needs maps of equal stride')
         ka, kb = self._keys(a), self._keys(b)
@@ -316,6 +341,28 @@ class CoordinateManager:
         hit = kb[pos] == ka
         rows_in = torch.nonzero(hit).squeeze(1)
         return {0: torch.stack((rows_in, pos[hit]))}
+
+    def origin_map(self, key: CoordinateMapKey):
+        """(key of the origin map, [rows of sample b for every b]) -- ME: cm.origin_map, whose second element the colour
+        codec's training loss indexes per sample (lossy_coord_lossy_color/layers.py:247).  Rows are batch-major here."""
+        m = self._map(key)
+        edges = self.batch_offsets(m)
+        dev = self.device if m.keys is None else m.keys.device
+        return CoordinateMapKey(1, 'origin'), [torch.arange(a, b, device=dev) for a, b in zip(edges[:-1], edges[1:])]
+
+    def _ancestor_rows(self, m: _Map, target: _Map) -> torch.Tensor:
+        """row of `target` (a coarser map on m's parent chain) that holds each row of m"""
+        if m is target:
+            raise ValueError('the maps are the same')
+        dev = self.device if m.keys is None and m.parent.keys is None else (m.keys if m.keys is not None else m.parent.keys).device
+        idx = torch.arange(m.n, device=dev)
+        cur = m
+        while cur is not target:
+            if cur.parent is None:
+                raise ValueError('the target map is not an ancestor of the input map')
+            idx = torch.div(idx, 8, rounding_mode='floor') if cur.generated else cur.parent_of.long()[idx]
+            cur = cur.parent
+        return idx
 
     def batch_offsets(self, m: _Map) -> List[int]:
         """Row ranges of the samples of a batch (rows are batch-major)."""
@@ -822,6 +869,62 @@ class MinkowskiLeakyReLU(_Pointwise):
 
 class MinkowskiSigmoid(_Pointwise):
     MODULE = nn.Sigmoid
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm over the feature rows; `.bn` is the nn.BatchNorm1d, as in MinkowskiEngine (state_dict keys `bn.*`)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return SparseTensor(self.bn(x.F), coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+
+
+class _StridedPool(nn.Module):
+    def __init__(self, kernel_size, stride=1, dilation=1, kernel_generator=None, dimension=3, **_):
+        super().__init__()
+        ks, st = _as_stride(kernel_size)[0], _as_stride(stride)[0]
+        if ks != st:
+            raise NotImplementedError('pooling over non-overlapping cells only (kernel_size == stride), as the codecs use it')
+        self.cell = st
+
+
+class MinkowskiMaxPooling(_StridedPool):
+    """Maximum over the cells of a coarser coordinate map that already exists (`coordinates` = its key): the first half of
+    the decoder's local-maximum test (lossy_coord_v2/layers.py:159-161).  The product path does this inside fpcc_topk_keep;
+    this module exists so that the reference's own call sequence runs on the engine."""
+
+    def forward(self, x: SparseTensor, coordinates: Optional[CoordinateMapKey] = None) -> SparseTensor:
+        cm = x.coordinate_manager
+        src = cm._map(x.coordinate_map_key)
+        if coordinates is None:
+            dst = src
+            for _ in range(self.cell.bit_length() - 1):
+                dst = cm._ensure_parent(dst)
+        else:
+            dst = cm._map(coordinates)
+        if (1 << dst.level) != (1 << src.level) * self.cell:
+            raise ValueError('the target map does not have the pooled tensor stride')
+        rows = cm._ancestor_rows(src, dst)
+        f = x.F
+        out = torch.full((dst.n, f.shape[1]), float('-inf'), dtype=f.dtype, device=f.device)
+        out.scatter_reduce_(0, rows.unsqueeze(1).expand(-1, f.shape[1]), f, reduce='amax', include_self=True)
+        return SparseTensor(out, coordinate_map_key=dst.key, coordinate_manager=cm)
+
+
+class MinkowskiPoolingTranspose(_StridedPool):
+    """Every row of the finer map `coordinates` receives the feature of the cell it lies in (one contributor per row when
+    kernel_size == stride)."""
+
+    def forward(self, x: SparseTensor, coordinates: CoordinateMapKey) -> SparseTensor:
+        cm = x.coordinate_manager
+        src, dst = cm._map(x.coordinate_map_key), cm._map(coordinates)
+        if (1 << src.level) != (1 << dst.level) * self.cell:
+            raise ValueError('the target map does not have the un-pooled tensor stride')
+        rows = cm._ancestor_rows(dst, src)
+        return SparseTensor(x.F[rows], coordinate_map_key=dst.key, coordinate_manager=cm)
 
 
 class MinkowskiPruning(nn.Module):

@@ -282,7 +282,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
     return out
 
 
-KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS = 0, 1, 2, 3, 4
+KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS, KNOB_MFMA_TILE = 0, 1, 2, 3, 4, 5
 
 
 def conv_set_tuning(which: int, value: int) -> int:

@@ -3,8 +3,8 @@
 `ConvTransBlock`, `GenConvTransBlock`, `NNSequentialWith*Args` -- on top of fastpcc_amd.engine.
 
 Difference in execution only: convolution / linear, bias add and activation run as ONE kernel launch
-(fpcc_conv_f32's fused epilogue) instead of three MinkowskiEngine ops.  BatchNorm is not available (every in-scope config
-uses bn=False).
+(fpcc_conv_f32's fused epilogue) instead of three MinkowskiEngine ops.  With bn=True (no in-scope config) the block runs
+unfused: convolution, MinkowskiBatchNorm, activation.
 """
 import functools
 import math
@@ -40,21 +40,25 @@ class MEMLPBlock(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, bn: bool = False,
                  act: Union[str, nn.Module, None] = 'relu'):
         super().__init__()
-        if bn:
-            raise NotImplementedError('batch norm is not part of the in-scope configurations')
-        self.mlp = ME.MinkowskiLinear(in_channels, out_channels, bias=True)
-        self.bn = None
+        self.mlp = ME.MinkowskiLinear(in_channels, out_channels, bias=not bn)      # minkowski_sparse_conv_layers.py:38-39
+        self.bn = ME.MinkowskiBatchNorm(out_channels) if bn else None
         self.act = get_act_module(act)
 
     def forward(self, x, clip: float = 0.0):
-        if _fusable(self.act):
+        if self.bn is None and _fusable(self.act):
             return self.mlp(x, act=ME._act_of(self.act), clip=clip)
-        x = self.act(self.mlp(x))
+        x = self.mlp(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.act is not None:
+            x = self.act(x)
+        if clip > 0:
+            x = ME.SparseTensor(x.F.clamp(-clip, clip), coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         return x
 
     def __repr__(self):
         return f'MEMLPBlock(in_ch={self.mlp.linear.in_features}, out_ch={self.mlp.linear.out_features}, ' \
-               f'bn=False, act={self.act})'
+               f'bn={self.bn is not None}, act={self.act})'
 
 
 class BaseConvBlock(nn.Module):
@@ -62,23 +66,28 @@ class BaseConvBlock(nn.Module):
                  region_type: str = 'HYPER_CUBE', bn: bool = False, bias: Optional[bool] = None,
                  act: Union[str, nn.Module, None] = 'relu'):
         super().__init__()
-        if bn:
-            raise NotImplementedError('batch norm is not part of the in-scope configurations')
         self.region_type = getattr(ME.RegionType, region_type)
         self.conv = conv_class(
             in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=dilation,
-            bias=bias if bias is not None else True,
+            bias=bias if bias is not None else not bn,                      # minkowski_sparse_conv_layers.py:67-81
             kernel_generator=ME.KernelGenerator(kernel_size, stride, dilation, region_type=self.region_type,
                                                 dimension=dimension),
             dimension=dimension)
-        self.bn = None
+        self.bn = ME.MinkowskiBatchNorm(out_channels) if bn else None
         self.act = act
         self.act_module = get_act_module(act)
 
     def forward(self, x, *args, clip: float = 0.0, **kwargs):
-        if _fusable(self.act_module):
+        if self.bn is None and _fusable(self.act_module):
             return self.conv(x, *args, act=ME._act_of(self.act_module), clip=clip, **kwargs)
-        return self.act_module(self.conv(x, *args, **kwargs))
+        x = self.conv(x, *args, **kwargs)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.act_module is not None:
+            x = self.act_module(x)
+        if clip > 0:
+            x = ME.SparseTensor(x.F.clamp(-clip, clip), coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+        return x
 
     def __repr__(self):
         kg = self.conv.kernel_generator
