@@ -31,6 +31,7 @@ def parse():
     ap.add_argument('--resolution', type=int, default=1024, help='1024 -> ~1M voxels (cfg#2)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
     ap.add_argument('--cpu-resolution', type=int, default=512, help='resolution of the CPU sample (same generator; 1024 = the benchmarked frame itself)')
+    ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--secondary', type=int, default=1, help='0 skips the cfg#3 / #4 / #5 figures reported next to the headline (N = 1 only)')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
@@ -79,22 +80,36 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(cfg, weights, resolution, budget_s=25.0):
-    """The protocol of BASELINE.md section 3 / SURVEY.md section 8d: the CPU oracle configured like MinkowskiEngine's CPU
-    backend (per kernel offset index_select -> torch.mm -> index_add_, fp32) with every host thread, same seeded weights,
-    one warm-up and the median of up to five encode+decode runs, on a bounded sample of the workload (the same generator at
-    `resolution`); like the GPU path it stops after the last level that feeds the bitstream (identical bytes).  The OpenMP
-    FMA-chain evaluation (oracle/sparse_conv.c, the bit-exact checker) is timed once beside it as a secondary figure."""
+CPU_THREADS_CAP = 32
+
+
+def cpu_baseline_worker(resolution, budget_s, out_path):
+    """Runs in a child process started BEFORE this process touches the GPU (bench.py --cpu-baseline-worker): the protocol of
+    BASELINE.md section 3 / SURVEY.md section 8d -- the CPU oracle configured like MinkowskiEngine's CPU backend (per kernel
+    offset index_select -> torch.mm -> index_add_, fp32), same seeded weights, one warm-up and the median of up to five
+    encode+decode runs on a bounded sample of the workload (the same generator at `resolution`); like the GPU path it stops
+    after the last level that feeds the bitstream (identical bytes).  Threads: min(host cores, 32) -- on the 256-core GPU box
+    torch's CPU operators get SLOWER beyond 32 threads (15 K voxels: 0.5 s at 16 threads, 2.9 s at 64, no end within 50 s at
+    256; measured with tools/cpu_probe.py), so "all threads" would not be a baseline but a pathology.  The OpenMP FMA-chain
+    evaluation (oracle/sparse_conv.c, the bit-exact checker) is timed once beside it as a secondary figure."""
     import statistics
+    threads = min(os.cpu_count() or 1, CPU_THREADS_CAP)
+    os.environ['OMP_NUM_THREADS'] = str(threads)
     import numpy as np
     import torch
     import oracle
     from oracle.codec_v2 import OracleV2
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
     from fastpcc_amd.engine import summation_order as ME_order
-    from fastpcc_amd.synthetic import SCALE, batched, body_cloud
+    from fastpcc_amd.synthetic import SCALE, batched, body_cloud, enliven
     oracle.build()
-    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
+    cfg = baseline_r1()
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, 0)                                                   # the weights of the GPU run, re-created by seed
+    weights = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
     xyz = body_cloud(resolution, SCALE.get(resolution, SCALE[1024]), seed=2)       # at 1024: rank 0's benchmarked frame
     coords = batched(xyz).astype(np.int64)
     small = batched(xyz[: min(len(xyz), 2000)]).astype(np.int64)
@@ -116,18 +131,55 @@ def cpu_baseline(cfg, weights, resolution, budget_s=25.0):
     while len(times) < reps:
         times.append(run(mm))
     enc, dec = statistics.median(t[0] for t in times), statistics.median(t[1] for t in times)
+    out = {'value': round(len(xyz) / (enc + dec) / 1e6, 5), 'unit': 'Mpoints/s', 'cores': threads, 'kind': 'port',
+           'cpu': cpu_model(), 'host_cores': os.cpu_count(),
+           'sample': f'same generator at {resolution}^3: {len(xyz)} voxels; gather/GEMM/scatter-add oracle (torch.mm, {threads} threads: '
+                     f'more are slower on this host), median of {len(times)} encode+decode runs after a warm-up: enc {enc:.2f}s dec {dec:.2f}s; '
+                     f'unused encoder tail skipped as on the GPU'}
+    with open(out_path, 'w') as f:                                      # the primary figure is safe even if the secondary run stalls
+        json.dump(out, f)
     chain = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
     chain.skip_unused_tail = True
     chain.compress(small)
     c_enc, c_dec = run(chain)
-    return {'value': round(len(xyz) / (enc + dec) / 1e6, 5), 'unit': 'Mpoints/s', 'cores': threads, 'kind': 'port',
-            'cpu': cpu_model(),
-            'sample': f'same generator at {resolution}^3: {len(xyz)} voxels; gather/GEMM/scatter-add oracle (torch.mm, {threads} threads), '
-                      f'median of {len(times)} encode+decode runs after a warm-up: enc {enc:.2f}s dec {dec:.2f}s; unused encoder tail '
-                      f'skipped as on the GPU',
-            'secondary': {'what': 'oracle/sparse_conv.c FMA-chain evaluation (OpenMP), one run, same sample',
-                          'value': round(len(xyz) / (c_enc + c_dec) / 1e6, 5), 'unit': 'Mpoints/s',
-                          'enc_s': round(c_enc, 2), 'dec_s': round(c_dec, 2)}}
+    out['secondary'] = {'what': f'oracle/sparse_conv.c FMA-chain evaluation (OpenMP, {threads} threads), one run, same sample',
+                        'value': round(len(xyz) / (c_enc + c_dec) / 1e6, 5), 'unit': 'Mpoints/s', 'enc_s': round(c_enc, 2), 'dec_s': round(c_dec, 2)}
+    with open(out_path, 'w') as f:
+        json.dump(out, f)
+
+
+class CpuBaseline:
+    """the worker above as a child process with a hard time limit; started before the GPU is initialised, collected after"""
+
+    def __init__(self, resolution, limit_s=150.0):
+        import subprocess
+        import tempfile
+        self.limit_s = limit_s
+        self.path = os.path.join(tempfile.gettempdir(), f'fpcc_cpu_baseline_{os.getpid()}.json')
+        self.t0 = time.perf_counter()
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', self.path,
+                                      '--cpu-resolution', str(resolution)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def wait(self):
+        import subprocess
+        try:
+            self.proc.wait(timeout=max(1.0, self.limit_s - (time.perf_counter() - self.t0)))
+        except subprocess.TimeoutExpired:
+            self.proc.kill()                      # the exact PID this object started
+            self.proc.wait()
+
+    def result(self):
+        self.wait()
+        try:
+            with open(self.path) as f:
+                out = json.load(f)
+            os.unlink(self.path)
+        except (OSError, ValueError):
+            return {'value': None, 'unit': 'Mpoints/s', 'cores': min(os.cpu_count() or 1, CPU_THREADS_CAP), 'kind': 'port',
+                    'sample': f'the CPU oracle did not finish within {self.limit_s:.0f} s on this host'}
+        if 'secondary' not in out:
+            out['secondary'] = {'what': 'FMA-chain evaluation', 'value': None, 'note': f'not finished within {self.limit_s:.0f} s'}
+        return out
 
 
 def secondary(device):
@@ -213,14 +265,20 @@ def secondary(device):
 
 def main():
     args = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.cpu_resolution, 25.0, args.cpu_baseline_worker)
     from fastpcc_amd import replicas
     rank, world, local = replicas.env_rank()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    # the CPU baseline runs in a child process, started and finished before this process initialises the GPU (it would
+    # otherwise compete with the coder pool's host threads inside the timed region)
+    cpu_job = CpuBaseline(args.cpu_resolution) if (args.cpu_baseline and world == 1 and rank == 0) else None
+    if cpu_job is not None:
+        cpu_job.wait()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local)
     replicas.init('nccl')          # RCCL; only the barrier and two scalar reductions use it
     device = torch.device('cuda', local)
@@ -357,8 +415,8 @@ def main():
         if args.secondary and world == 1:
             del model, frame
             out['config']['secondary'] = secondary(device)
-        if args.cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(cfg, weights, args.cpu_resolution)
+        if cpu_job is not None:
+            out['cpu_baseline'] = cpu_job.result()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

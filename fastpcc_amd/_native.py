@@ -44,6 +44,7 @@ def host():
             'fpcc_simple_enc_finish': [vp, vp, i64],
             'fpcc_simple_dec_pop': [vp, vp, i64, i64, vp, i64],
             'fpcc_simple_dec_pop_bin': [vp, vp, i64, vp, i64],
+            'fpcc_simple_dec_tell': [vp, vp, vp],
             'fpcc_pool_binary_encode': [vp, vp, C.c_uint32, vp, vp, i64, vp, i64, vp],
             'fpcc_pool_histogram_encode': [vp, vp, C.c_uint32, vp, i64, i32, vp, vp, i64, vp, vp, i64, vp],
             'fpcc_pool_table_decode': [vp, vp, i64, i64, vp, i64, i32, vp, i64, vp],
@@ -81,7 +82,7 @@ HOST_SYMBOLS = (
     'fpcc_rans_binary_encode', 'fpcc_rans_binary_decode', 'fpcc_rans_binary_encode_multi', 'fpcc_simple_enc_new',
     'fpcc_simple_enc_free', 'fpcc_simple_enc_push', 'fpcc_simple_enc_push_bin', 'fpcc_simple_enc_push_ranges',
     'fpcc_simple_enc_finish', 'fpcc_simple_dec_new', 'fpcc_simple_dec_free', 'fpcc_simple_dec_pop',
-    'fpcc_simple_dec_pop_bin', 'fpcc_pool_new', 'fpcc_pool_free', 'fpcc_pool_binary_encode',
+    'fpcc_simple_dec_pop_bin', 'fpcc_simple_dec_tell', 'fpcc_pool_new', 'fpcc_pool_free', 'fpcc_pool_binary_encode',
     'fpcc_pool_histogram_encode', 'fpcc_pool_table_decode', 'fpcc_progress_wait', 'fpcc_pool_wait')
 
 

@@ -58,6 +58,10 @@ class GeoLosslessEntropyModel(nn.Module):
         self.last_symbols = None
         self.evaluate_unused_tail = False
         self._overlap = {}
+        # True: occupancy levels are decoded by the device-side binary rANS decoder (fpcc_rans_binary_decode_dev) -- nothing
+        # but the 4-byte count of occupied children leaves the GPU per level.  Same result; slower than the host path on the
+        # large levels (profiles/r02/device_rans.md), hence off by default.
+        self.device_decoder = False
         self.timing = None          # set to a dict to collect host-side wall-clock marks (seconds) of the last call
 
     # -- rANS of an integer array under its own histogram (geo_lossl_em.py:59-93) -------------------------------------
@@ -324,6 +328,26 @@ class GeoLosslessEntropyModel(nn.Module):
                 logits = occ_net(lower)
                 ta = time.perf_counter()
                 prob_d = ops.logit_to_prob16(logits.F.view(-1))
+                if self.device_decoder:
+                    raw = coord_bytes_list.pop(0)
+                    mask, ones, status = ops.rans_binary_decode_dev(ops.stream_to_device(raw, dev), len(raw), prob_d)
+                    count, ok = torch.cat((ones, status)).tolist()          # the level's one read-back: 8 bytes
+                    if ok != 0:
+                        raise ValueError('corrupt occupancy stream')
+                    if tm is not None:
+                        tm['dec_wait'] += time.perf_counter() - ta
+                    gen_id = logits.coordinate_map_key.get_key()[1]
+                    cur_map = cm._refine(cur_map, mask, gen_id + 'pruned', count_hint=int(count))
+                    del logits
+                    target_key = cur_map.key
+                    fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
+                    if idx > self.skip_encoding_fea:
+                        res = residuals(used, cur_map.n)
+                        used += cur_map.n
+                        lower = self.decoder_block[idx](res, fea_pred)
+                    else:
+                        lower = self.decoder_block[idx](fea_pred)
+                    continue
                 prob_t = torch.empty(prob_d.shape, dtype=prob_d.dtype, pin_memory=True)
                 prob_t.copy_(prob_d, non_blocking=True)
                 torch.cuda.current_stream().synchronize()                # the level's dependency: D2H of its probabilities

@@ -293,6 +293,9 @@ class Model(nn.Module):
         self.fea_side_info_cdf2[:, -1] = 65535
         self.rans_encoder = RansEncoder(32 * 1024 * 1024)
         self.rans_decoder = RansDecoder()
+        # True: the occupancy symbols of every level are decoded by fpcc_simple_dec_pop_dev (CDF rows never cross PCIe);
+        # slower than the chunked host path on this codec (profiles/r02/device_rans.md), hence off by default
+        self.device_decoder = False
 
     # ---------------------------------------------------------------------------------------------------------------
     def forward(self, pc_data: PCData):
@@ -337,6 +340,11 @@ class Model(nn.Module):
         ~55 GB/s) hides behind the decode instead of preceding it."""
         rows_d = ops.logits_to_cdf16(logits.contiguous(), PRE_SHIFT)
         n = rows_d.shape[0]
+        if self.device_decoder:
+            # the CDF rows stay where they were made: one wave decodes the level's symbols on the device, 4 bytes come back
+            sym, children = ops.simple_dec_pop_dev(self._dev_state, self._dev_stream, self._dev_stream_len, rows_d)
+            sym._fpcc_children = int(children.item())
+            return sym
         rows_h = torch.empty(rows_d.shape, dtype=rows_d.dtype, pin_memory=True)
         out_h = torch.empty(n, dtype=torch.int16, pin_memory=True)
         step = self.DECODE_CHUNK_ROWS
@@ -459,6 +467,12 @@ class Model(nn.Module):
         levels = self.max_downsample_times - skip
 
         bottom = torch.from_numpy(self.rans_decode_fea(n_bottom * 3).astype(np.int32)).reshape(-1, 3)
+        if self.device_decoder:
+            # the few bottom symbols (65 K-entry side tables) are decoded on the host; the device continues from there
+            x, pos = self.rans_decoder.tell()
+            self._dev_stream, self._dev_stream_len = ops.stream_to_device(payload, device), len(payload)
+            self._dev_state = torch.tensor([x - (1 << 32) if x >= 1 << 31 else x, pos & 0xffffffff if pos < 1 << 31 else pos - (1 << 32),
+                                            pos >> 32, 0], dtype=torch.int32).to(device)
         cur_rec = self.get_init_pc(F.pad(bottom, (1, 0, 0, 0)).to(device), 2 ** levels)
         cur_bins, top_rec, top_stride, cur_bin = [], None, None, None
         for idx in range(levels, 0, -1):

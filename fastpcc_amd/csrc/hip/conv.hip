@@ -133,7 +133,9 @@ __device__ __forceinline__ void stage_compute(const f32x4 (&ra)[C::G8], const fl
     }
 }
 
-template <int NBT, int CH, int WM, int WN>
+// DBG (timing experiments only, results are wrong): bit 0 = every gathered row is row 0, bit 1 = every stage reads the weights of
+// chunk 0, bit 2 = no per-stage barrier (races on the W buffers)
+template <int NBT, int CH, int WM, int WN, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
     using C = MfmaCfg<NBT, CH, WM, WN>;
     constexpr int C_OUT = C::C_OUT;
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
     __shared__ int32_t s_nbr[kMaxOffsets * TM];
     __shared__ int32_t s_row[TM];          // output row of each tile position (-1 past the end)
     __shared__ unsigned s_mask[WM];
+    __shared__ int32_t s_zero_idx[32];     // DBG bit 0: thirty-two times row 0
+    if (DBG & 1) { if (threadIdx.x < 32) s_zero_idx[threadIdx.x] = 0; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -216,11 +220,11 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
             }
 #pragma unroll
             for (int g8 = 0; g8 < C::G8; ++g8) ra_cur[g8] = ra_nxt[g8];
-            fetch_a<C, CH>(a, my_nbr + k_next * TM, cc_next, li, lh, ra_nxt);
-            fetch_w<C, CH>(wg, c_in, tid, k_next, cc_next, rw);
+            fetch_a<C, CH>(a, (DBG & 1) ? s_zero_idx : my_nbr + k_next * TM, cc_next, li, lh, ra_nxt);
+            fetch_w<C, CH>(wg, c_in, tid, (DBG & 2) ? 0 : k_next, (DBG & 2) ? 0 : cc_next, rw);
             if ((wmask >> k_cur) & 1u) stage_compute<C, CH>(ra_cur, sW + (s & 1) * CH * C_OUT, wc, li, lh, acc);
             stash_w<C>(sW + ((s + 1) & 1) * CH * C_OUT, tid, rw);
-            __syncthreads();
+            if (!(DBG & 4)) __syncthreads();
             k_cur = k_next;
         }
     }
@@ -532,11 +536,20 @@ int mfma_chunk(int c1, int c2, int c_out) {
     return 0;
 }
 
+int knob(int k);
+
 template <int NBT, int CH, int WM, int WN>
 int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
     constexpr int TM = 32 * WM;
     const unsigned tiles = (unsigned)((a.n_out + TM - 1) / TM);
-    hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN>), dim3(tiles, a.groups), dim3(64 * WM * WN), 0, s, a);
+    const dim3 grid(tiles, a.groups), block(64 * WM * WN);
+    const int dbg = (NBT == 4 && CH == 32) ? knob(3) : 0;          // kKnobWaveDbg: experiments on the 128-column shapes only
+    if (dbg == 1) hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN, 1>), grid, block, 0, s, a);
+    else if (dbg == 2) hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN, 2>), grid, block, 0, s, a);
+    else if (dbg == 3) hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN, 3>), grid, block, 0, s, a);
+    else if (dbg == 4) hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN, 4>), grid, block, 0, s, a);
+    else if (dbg == 7) hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN, 7>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma<NBT, CH, WM, WN>), grid, block, 0, s, a);
     return check_hip(hipGetLastError(), "k_conv_mfma");
 }
 
@@ -587,7 +600,7 @@ int knob(int k) {
     if (g_knob[k] < 0) {
         static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS",
                                                 "FPCC_MFMA_TILE"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, 8192, 0};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, FPCC_SPLIT_MAX_ROWS, 0};
         const char *e = getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
@@ -684,6 +697,8 @@ extern "C" int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, 
     if (use_split(c1, c2, c_out, n_offsets, groups, n_out)) return 2;
     return mfma_chunk(c1, c2, c_out) ? 1 : 0;
 }
+
+extern "C" int fpcc_numerics_version(void) { return FPCC_NUMERICS_VERSION; }
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
     if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");

@@ -127,7 +127,16 @@ struct ConvI8Args {
     const int32_t *bias; const int32_t *slope; const uint32_t *mul; const int64_t *zp; int shift; int out_bits;
     void *out; int ldo; int c_out; int64_t n_out; int out_pad;   // columns [c_out, out_pad) of an int8 output are zeroed
     const int32_t *row_order;               // tile position -> output row (NULL: identity)
+    const int32_t *res; int ld_res; const int32_t *slope2;   // int32 outputs only: out = clamp_i32(prelu(res + out (wrapping), slope2))
 };
+
+// tail of SparseResBlockIn32W8Out32.forward fused behind the convolution's own epilogue (cuda_ops.py:82-92): the int32 tensor
+// add of the reference wraps, the PReLU is `prelu` of src/element_wise/prelu.cu
+__device__ __forceinline__ int32_t residual_prelu(int32_t v, int32_t r, int32_t slope2) {
+    const int32_t x = (int32_t)((uint32_t)v + (uint32_t)r);
+    const int64_t y = prelu_q625((int64_t)x, slope2);
+    return (int32_t)(y < (int64_t)INT32_MIN ? (int64_t)INT32_MIN : (y > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : y));
+}
 
 // Source of every absent operand (missing neighbour, column past c_out, half k-step past the padded row): loads stay
 // unconditional, which lets the compiler keep them in flight across the MFMAs of the previous stage.
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p, int32_t *acc_out,
                 }
             }
             if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
-            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = v;
+            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
         }
     }
 }
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
                 }
             }
             if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
-            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = v;
+            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
         }
     }
 }
@@ -434,7 +443,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
 // stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
 __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const int32_t *bias, const int32_t *slope,
                                const uint32_t *mul, int mul_stride, const int64_t *zp, int shift, int out_bits,
-                               void *out, int ldo, int64_t n, int ch, int out_pad, const int32_t *row_group) {
+                               void *out, int ldo, int64_t n, int ch, int out_pad, const int32_t *row_group,
+                               const int32_t *res = nullptr, int ld_res = 0, const int32_t *slope2 = nullptr) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int width = out_pad > ch ? out_pad : ch;
     if (e >= n * width) return;
@@ -448,7 +458,7 @@ __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const in
         v = requant(t, mul[pc * mul_stride], zp ? zp[0] : 0, shift, out_bits);
     }
     if (out_bits == 8) static_cast<int8_t *>(out)[r * ldo + c] = (int8_t)v;
-    else if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = v;
+    else if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = res ? residual_prelu(v, res[r * ld_res + c], slope2[0]) : v;
 }
 
 // out = clamp_i32(prelu_q625(a (+ b)))
@@ -654,6 +664,19 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
                             const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul, const int64_t *zero_point,
                             int shift, int out_bits, void *out, int ldo, int out_pad, int c_out, int64_t n_out,
                             const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream) {
+    return fpcc_conv_i8_res(a, c_in, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, zp_comp, bias, slope, requant_mul,
+                            zero_point, shift, out_bits, out, ldo, out_pad, c_out, n_out, row_order, nullptr, 0, nullptr, ws,
+                            ws_bytes, stream);
+}
+
+extern "C" int fpcc_conv_i8_res(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
+                                int64_t nbr_os, int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp,
+                                const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
+                                const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad, int c_out,
+                                int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
+                                const int32_t *slope2, void *ws, int64_t ws_bytes, void *stream) {
+    if (residual && (!slope2 || out_bits != 32 || !requant_mul || ld_res < c_out))
+        return fail_arg("conv_i8: a fused residual needs its PReLU slope, a requantised int32 output and ld_res >= c_out");
     if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1 || n_offsets > kI8MaxOffsets)
         return fail_arg("conv_i8: sizes out of range (n_offsets must be 1..64)");
     if (n_out == 0) return FPCC_OK;
@@ -666,7 +689,8 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
     if (!requant_mul && out_bits != 32) return fail_arg("conv_i8: raw accumulators are int32");
     if (ldo < c_out || out_pad > ldo) return fail_arg("conv_i8: output row stride too small");
     ConvI8Args p{a, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, (c_in + 31) / 32, zp_comp,
-                 bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad, row_order};
+                 bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad, row_order,
+                 residual, ld_res, slope2};
     const int width = out_pad > c_out ? out_pad : c_out;
     const unsigned gx = (unsigned)((n_out + 127) / 128);
     hipStream_t s = as_stream(stream);
@@ -687,7 +711,8 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
         FPCC_LAUNCHED(k_conv_i8_split);
         if (requant_mul) {
             hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
-                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0, nullptr);
+                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0, nullptr,
+                               residual, ld_res, slope2);
             FPCC_LAUNCHED(k_epilogue_i32);
         }
         return FPCC_OK;

@@ -86,6 +86,8 @@ public:
     inline uint32_t peek() const { return state_ & ((1u << BITS) - 1u); }
     // a valid encoder flushes a state in [2^23, 2^31); anything below marks a corrupt or truncated stream
     bool valid() const { return state_ >= kLow; }
+    uint32_t state() const { return state_; }
+    const uint8_t *cursor() const { return p_; }
     template <uint32_t BITS>
     inline void take(uint32_t start, uint32_t freq) {
         uint32_t x = freq * (state_ >> BITS) + (state_ & ((1u << BITS) - 1u)) - start;
@@ -373,7 +375,8 @@ struct fpcc_simple_enc {
 
 struct fpcc_simple_dec {
     FrontReader r;
-    fpcc_simple_dec(const uint8_t *p, int64_t n) : r(p, n) {}
+    const uint8_t *base;
+    fpcc_simple_dec(const uint8_t *p, int64_t n) : r(p, n), base(p) {}
 };
 
 static inline void edge_range(const uint16_t *row, int64_t width, uint32_t s, uint32_t &lo, uint32_t &hi) {
@@ -474,6 +477,13 @@ int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_
         d->r.take<kProbBits>(lo, hi - lo);
         symbols_out[i] = static_cast<uint16_t>(s);
     }
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_simple_dec_tell(const fpcc_simple_dec *d, uint32_t *state_out, int64_t *position_out) {
+    if (!d || !state_out || !position_out) return FPCC_HOST_E_ARG;
+    *state_out = d->r.state();
+    *position_out = d->r.cursor() - d->base;
     return FPCC_HOST_OK;
 }
 

@@ -528,12 +528,15 @@ def _split_k3_ok(c_in: int, c2: int, c_out: int) -> bool:
     return c_out == 1 and c2 == 0 and c_in % 16 == 0
 
 
+PAD_MIN_ROWS = 8192        # FPCC_PAD_MIN_ROWS of include/fpcc_hip.h: part of the stream format, not a tuning knob
+
+
 @functools.lru_cache(maxsize=4096)
 def _pad_plan(c1: int, c2: int, c_out: int, n_out: int):
     """Shapes the MFMA kernel does not take as they are (C_in not a multiple of 16, C_out not 32/64/128) but that are big
     enough to matter are zero-padded to the next MFMA shape: -> (c1p, c2p, c_outp) or None.  Zero channels add exact
     zeros to the FMA chains, so only the (documented) summation order changes."""
-    if ops.conv_order(c1, c2, c_out) != 0 or c_out > 128 or c1 + c2 < 4 or (c1 + c2) * c_out < 32 or n_out < 8192:
+    if ops.conv_order(c1, c2, c_out) != 0 or c_out > 128 or c1 + c2 < 4 or (c1 + c2) * c_out < 32 or n_out < PAD_MIN_ROWS:
         return None
     c1p = (c1 + 15) // 16 * 16
     c2p = (c2 + 15) // 16 * 16 if c2 else 0

@@ -33,6 +33,7 @@ _SIGS = {
     'fpcc_conv_f32_pk': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32,
                                 _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
+    'fpcc_numerics_version': (_i32, []),
     'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
     'fpcc_conv_pack_weights_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
@@ -68,12 +69,16 @@ _SIGS = {
     'fpcc_hash_lookup_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_conv_i8': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                             _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i64, _vp]),
+    'fpcc_conv_i8_res': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_i8_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'fpcc_epilogue_i32': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     'fpcc_prelu_i32': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'fpcc_softmax_i32': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_logits_to_cdf16': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'fpcc_logits_to_ranges': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'fpcc_rans_binary_decode_dev': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'fpcc_simple_dec_pop_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
@@ -283,6 +288,11 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
 
 
 KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS, KNOB_MFMA_TILE = 0, 1, 2, 3, 4, 5
+
+
+def numerics_version() -> int:
+    """version of the summation-order rules that make up the stream format (include/fpcc_hip.h)"""
+    return lib().fpcc_numerics_version()
 
 
 def conv_set_tuning(which: int, value: int) -> int:
@@ -659,8 +669,10 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
             zp_comp: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
             slope: Optional[torch.Tensor] = None, requant_mul: Optional[torch.Tensor] = None,
             zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32,
-            row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw]."""
+            row_order: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            slope2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw].
+    residual (int32 [n_out, c_out]) + slope2: out = prelu(residual + out) fused behind the epilogue (fpcc_conv_i8_res)."""
     a = _rows_i8(a, 'a')
     if not w_padded.is_cuda:
         raise FpccError('weights must live on the GPU (libfpcc_hip has no CPU path); move the model with .cuda()')
@@ -674,12 +686,16 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
         ws_bytes = lib().fpcc_conv_i8_ws_bytes(1, n_offsets, int(mul is not None), c_out, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=a.device)
-    _ok(lib().fpcc_conv_i8(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
-                           nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
-                           _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
-                           _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
-                           int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _dev(row_order, torch.int32, 'row_order', True),
-                           None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
+    if residual is not None and tuple(residual.shape) != (n_out, c_out):
+        raise ValueError('residual must be int32 [n_out, c_out]')
+    _ok(lib().fpcc_conv_i8_res(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                               nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
+                               _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
+                               _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
+                               int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _dev(row_order, torch.int32, 'row_order', True),
+                               _dev(residual, torch.int32, 'residual', True), 0 if residual is None else c_out,
+                               _dev(slope2, torch.int32, 'slope2', True),
+                               None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
     return out
 
 
@@ -736,3 +752,36 @@ def logits_to_ranges(logits: torch.Tensor, pre_shift: int, symbols: torch.Tensor
     _ok(lib().fpcc_logits_to_ranges(_dev(logits, torch.int32, 'logits'), n, c, pre_shift,
                                     _dev(symbols, torch.int16, 'symbols'), start.data_ptr(), freqm1.data_ptr(), _stream()))
     return start, freqm1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-side rANS decoders (one wave per stream)
+
+def stream_to_device(data: bytes, device) -> torch.Tensor:
+    """a byte stream as a uint8 device tensor (4 bytes of slack so that word-wise readers stay inside the allocation)"""
+    t = torch.zeros(len(data) + 4, dtype=torch.uint8, pin_memory=True)
+    t[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+    return t.to(device, non_blocking=True)
+
+
+def rans_binary_decode_dev(stream: torch.Tensor, stream_len: int, prob16: torch.Tensor):
+    """-> (bits uint8 [n], ones int32 [1], status int32 [1]), all on the device; nothing is synchronised"""
+    n = prob16.numel()
+    dev = prob16.device
+    bits = torch.empty(n, dtype=torch.uint8, device=dev)
+    ones = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    _ok(lib().fpcc_rans_binary_decode_dev(_dev(stream, torch.uint8, 'stream'), int(stream_len), _dev(prob16, torch.int16, 'prob16', n == 0),
+                                          n, bits.data_ptr(), ones.data_ptr(), status.data_ptr(), _stream()))
+    return bits, ones, status
+
+
+def simple_dec_pop_dev(state: torch.Tensor, stream: torch.Tensor, stream_len: int, rows: torch.Tensor):
+    """rows int16 [n, width] (uint16 CDF rows of fpcc_logits_to_cdf16) -> (symbols int16 [n], children int32 [1]) on the
+    device; `state` (int32 [4]) is advanced"""
+    n, width = rows.shape
+    sym = torch.empty(n, dtype=torch.int16, device=rows.device)
+    children = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    _ok(lib().fpcc_simple_dec_pop_dev(_dev(state, torch.int32, 'state'), _dev(stream, torch.uint8, 'stream'), int(stream_len),
+                                      _dev(rows, torch.int16, 'rows', n == 0), n, width, sym.data_ptr(), n, children.data_ptr(), _stream()))
+    return sym, children

@@ -16,6 +16,7 @@ Execution differs from the reference, results do not (exact integer arithmetic):
     integer counterpart), `make_obs` / `SparseTensorHistogramObserver` / `SparseResBlockWithObs` (cuda_ops.py:20-59);
     `import_parameters` applies the reference's conversion formulas (pinned by tests/golden/ptq_import.json).
 """
+import functools
 import math
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Tuple
@@ -389,15 +390,19 @@ class SparseConvIn8Out8(_RequantParams):
             return self.forward_with_sparse_tensor(*args, **kwargs)
         return self.forward_with_coords(*args, **kwargs)
 
-    def forward_with_sparse_tensor(self, input: SparseTensor) -> SparseTensor:
-        return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self.forward_with_coords, self.unique)
+    def forward_with_sparse_tensor(self, input: SparseTensor, _residual=None) -> SparseTensor:
+        run = self.forward_with_coords if _residual is None else functools.partial(self.forward_with_coords, _residual=_residual)
+        return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, run, self.unique)
 
     def forward_with_coords(self, in_feats, in_coords, out_coords, in_out_maps=None, hashmap_kv=None,
-                            if_in_coords_equals_out_coords: bool = False):
+                            if_in_coords_equals_out_coords: bool = False, _residual=None):
+        ep = self._epilogue()
+        if _residual is not None:
+            ep['residual'], ep['slope2'] = _residual
         return sparse_conv_in8w8out32(
             in_feats, self._padded_weight(), in_coords, out_coords, self.kernel_size, self.stride, in_out_maps, hashmap_kv,
             self.int_zero_point_in_comp if self.use_zero_point_in else None, if_in_coords_equals_out_coords,
-            _epilogue=self._epilogue())
+            _epilogue=ep)
 
 
 class SparseConvIn8W8Out8(SparseConvIn8Out8):
@@ -506,8 +511,11 @@ class SparseResBlockIn32W8Out32(nn.Module):
     def forward(self, input: SparseTensor) -> SparseTensor:
         x = SparseTensor(self.input_requant(input.F), input.C, input.stride, input.spatial_range)
         x._caches = input._caches
-        x = self.conv2(self.conv_prelu(x))
-        out = SparseTensor(self.prelu(input.F, add=x.F), input.C, input.stride, input.spatial_range)   # prelu(input + x)
+        # prelu(input + conv2(...)) runs in the epilogue of conv2 (fpcc_conv_i8_res): three launches per block instead of four
+        # and the [N, C] int32 intermediate never reaches HBM
+        res = input.F if input.F.is_contiguous() else input.F.contiguous()
+        x = self.conv2.forward_with_sparse_tensor(self.conv_prelu(x), _residual=(res, self.prelu.slope))
+        out = SparseTensor(x.F, input.C, input.stride, input.spatial_range)
         out._caches = input._caches
         return out
 

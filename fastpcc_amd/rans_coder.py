@@ -228,6 +228,13 @@ class RansDecoder:
 
     decode_with_precomp = decode
 
+    def tell(self):
+        """(32-bit rANS state, offset of the next unread byte): where a device decoder picks the stream up"""
+        state = np.zeros(1, dtype=np.uint32)
+        pos = np.zeros(1, dtype=np.int64)
+        host_check(host().fpcc_simple_dec_tell(self._h, _p(state), _p(pos)))
+        return int(state[0]), int(pos[0])
+
     def decode_bin(self, cdf_arr: np.ndarray, symbol_arr: np.ndarray) -> int:
         edge = np.ascontiguousarray(cdf_arr, dtype=np.uint16).reshape(-1)
         bits = np.empty(symbol_arr.shape[0], dtype=np.uint8)

@@ -98,6 +98,22 @@ int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_
 /* ------------------------------------------------------------------------------------------------------------ */
 enum { FPCC_ACT_NONE = 0, FPCC_ACT_PRELU = 1, FPCC_ACT_RELU = 2 };
 
+/* Numerics version.  A decoder must recompute the encoder's fp32 activations BIT FOR BIT (they pass through round() and
+ * 16-bit probability quantisation before entropy coding), so the summation order of every layer is part of the stream
+ * format.  The order of a layer is a function of its shape and row count only, through these constants -- none of them is a
+ * tuning knob, changing one orphans every stream written before:
+ *     offset-split evaluation (order 2)      multi-offset maps of at most FPCC_SPLIT_MAX_ROWS rows, C_out in {32,64,128}
+ *     zero-padding to an MFMA shape (order 1) per-point / 3x3x3 layers on maps of at least FPCC_PAD_MIN_ROWS rows
+ *     two-phase conv3 -> 1 channel (order 2)  every 3x3x3 layer with one output channel and C_in % 16 == 0
+ *     MFMA channel order (order 1)            0,4,1,5,2,6,3,7 inside aligned groups of 8 channels
+ * Tile shapes, row order, kernel choice (workgroup-tiled or wave kernel) and every fpcc_conv_set_tuning knob but knob 4 leave
+ * all results unchanged (tests/test_gpu_fullsize.py).  The codecs' streams carry no version field (the reference's layout is
+ * kept byte for byte); tests/golden/v2_stream.json holds a stream of this version that every later build must decode. */
+#define FPCC_NUMERICS_VERSION 1
+#define FPCC_SPLIT_MAX_ROWS 8192
+#define FPCC_PAD_MIN_ROWS 8192
+int fpcc_numerics_version(void);
+
 /*
  * out[dst(o,g), :] = act( sum_k  X[nbr[k][o], :] @ W[g][k]  + bias )        o < n_out, g < groups
  *
@@ -343,6 +359,15 @@ int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_o
                  const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
                  int out_pad, int c_out, int64_t n_out, const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream);
 int64_t fpcc_conv_i8_ws_bytes(int has_nbr, int n_offsets, int has_requant, int c_out, int64_t n_out);
+/* The same with the tail of SparseResBlockIn32W8Out32.forward (cuda_ops.py:82-92) fused behind the epilogue of its second
+ * convolution: out = clamp_i32(prelu_q6.25(residual + requant(...) (int32, wrapping), slope2)) -- `prelu` of
+ * src/element_wise/prelu.cu applied to the reference's wrapping int32 tensor add.  residual int32 [n_out][ld_res] (NULL:
+ * exactly fpcc_conv_i8); needs out_bits == 32 and a requantising epilogue. */
+int fpcc_conv_i8_res(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                     int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope,
+                     const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
+                     int out_pad, int c_out, int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
+                     const int32_t *slope2, void *ws, int64_t ws_bytes, void *stream);
 
 /* Stand-alone epilogue on an int32 matrix [n][ch] (row stride ldi): requant_to_int{8,32}, bias_requant_*, prelu_requant_*,
  * bias_prelu_requant_* (src/element_wise/*.cu).  mul_per_channel == 0 broadcasts requant_mul[0]
@@ -367,6 +392,24 @@ int fpcc_logits_to_cdf16(const int32_t *logits, int64_t n, int c, int pre_shift,
  * symbol instead of 2*c), ready for fpcc_simple_enc_push_ranges. */
 int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift, const int16_t *symbols,
                           uint16_t *start_out, uint16_t *freq_minus_1_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* rANS decoders on the device (one wave per stream; the streams of libfpcc_host, same arithmetic)                  */
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Binary decoder = BinaryRansCoder.decode of rans_ext_cpp (lib/entropy_models/rans_coder/rans_wrapper.cpp:385-428) with
+ * stream, probabilities and result on the device: bits_out[i] in {0, 1}, ones_out[0] = number of ones, status[0] = 0 or
+ * -2 (initial state below 2^23: not a stream).  Decoding is serial by the format (one state per stream); the wave's other
+ * lanes fetch probabilities 64 at a time and hold the byte window. */
+int fpcc_rans_binary_decode_dev(const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
+                                uint8_t *bits_out, int32_t *ones_out, int32_t *status, void *hip_stream);
+/* RansDecoder.decode of simple_rans_ext_cpp (models/convolutional/lossy_coord_v3/rans_coder/simple_rans_wrapper.cpp:206-239)
+ * on the device: rows uint16 [n | 1][width <= 256] as fpcc_logits_to_cdf16 writes them, state int32[4] = {x, position low,
+ * position high, -} carried from launch to launch (initialise from fpcc_simple_dec_tell of libfpcc_host or from the
+ * stream's first four bytes with position 4).  children_out[0] (may be NULL) = sum of popcount(symbol + 1), the number of
+ * occupied children of the level. */
+int fpcc_simple_dec_pop_dev(int32_t *state, const uint8_t *stream, int64_t stream_len, const uint16_t *rows,
+                            int64_t n_rows, int64_t width, uint16_t *symbols_out, int64_t n, int32_t *children_out,
+                            void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,9 @@ fpcc_simple_dec *fpcc_simple_dec_new(const uint8_t *stream, int64_t stream_len);
 void fpcc_simple_dec_free(fpcc_simple_dec *);
 int64_t fpcc_simple_dec_pop(fpcc_simple_dec *, const uint16_t *rows, int64_t n_rows, int64_t width,
                             uint16_t *symbols_out, int64_t n);                           /* RansDecoder::decode */
+/* Where the decoder stands: the 32-bit rANS state and the offset of the next unread byte.  A device decoder
+ * (fpcc_simple_dec_pop_dev of libfpcc_hip) continues the same stream from there. */
+int64_t fpcc_simple_dec_tell(const fpcc_simple_dec *d, uint32_t *state_out, int64_t *position_out);
 int64_t fpcc_simple_dec_pop_bin(fpcc_simple_dec *, const uint16_t *edge, int64_t n_rows, uint8_t *bits_out, int64_t n);
 
 #ifdef __cplusplus

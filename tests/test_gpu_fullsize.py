@@ -189,3 +189,27 @@ def test_cfg4_two_million_coloured_voxels_round_trip_and_tuning_invariance():
             x2, c2 = x2.cpu().numpy(), c2.cpu().numpy()
             o2 = np.argsort((x2[:, 0].astype(np.int64) << 42) | (x2[:, 1].astype(np.int64) << 21) | x2[:, 2])
             assert (x2[o2] == rec_xyz[order]).all() and (c2[o2] == rec_rgb[order]).all(), f'reconstruction depends on {t}'
+
+
+def test_committed_stream_of_this_numerics_version_still_decodes(v2):
+    """tests/golden/v2_stream.json was written by tools/make_gpu_golden.py on an MI355X: a later build that changes an
+    order-selecting constant (include/fpcc_hip.h, 'Numerics version') decodes it to a different cloud -- and fails here
+    instead of silently orphaning streams."""
+    import hashlib, json, os
+    from fastpcc_amd.synthetic import surface_cloud
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'v2_stream.json')
+    if not os.path.exists(path):
+        pytest.skip('no committed GPU stream yet (tools/make_gpu_golden.py)')
+    cfg, model, _, ops, ME = v2
+    with open(path) as f:
+        g = json.load(f)
+    assert g['numerics_version'] == ops.numerics_version(), 'numerics version bumped: regenerate the golden stream deliberately'
+    data = bytes.fromhex(g['stream_hex'])
+    rec = model.decompress(data).cpu().numpy()
+    ME.clear_global_coordinate_manager()
+    keys = _key(rec)
+    assert len(rec) == g['decoded_voxels'] and hashlib.sha256(keys.tobytes()).hexdigest() == g['decoded_sha256']
+    xyz = surface_cloud(11, 128, 90000)
+    again = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda())
+    ME.clear_global_coordinate_manager()
+    assert again == data, 'the encoder no longer writes the committed stream for the committed input'

@@ -49,12 +49,12 @@ if os.environ.get('NBWS'):
 DEPTHS = [int(v) for v in os.environ.get('DEPTHS', '0').split(',')]
 if os.environ.get('LPT'):
     cases.append(('pattern+lpt', lpt(order, int(os.environ['LPT']))))
-for dbg, depth, (nbw, sb) in [(a, b, c) for a in DBG for b in DEPTHS for c in variants]:
+for dbg, (nbw, sb) in [(a, c) for a in DBG for c in variants]:
   ops.conv_set_tuning(3, dbg)
   tag = ''
   if nbw is not None:
       ops.conv_set_tuning(ops.KNOB_WAVE_ON, int(nbw > 0)); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
-      tag = f' [tiled kernel]' if nbw == 0 else f' [wave nbw={nbw} depth={depth} sb={sb} dbg={dbg}]'
+      tag = f' [tiled kernel dbg={dbg}]' if nbw == 0 else f' [wave nbw={nbw} sb={sb} dbg={dbg}]'
   for name, ro in cases:
     for _ in range(3):
         run(ro)
