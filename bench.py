@@ -52,7 +52,7 @@ def conv_flops(info, counts_cache):
 
 
 def pmc_traffic():
-    """HBM bytes per k_conv_mfma launch from the newest committed rocprofv3 PMC passes (profiles/r*/..._pmc_traffic.json,
+    """HBM bytes per MFMA convolution launch (k_conv_wave / k_conv_mfma) from the newest committed rocprofv3 PMC passes (profiles/r*/..._pmc_traffic.json,
     made by profiles/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950
     guide prescribes).  PMC counters cannot be collected from inside this process, so the committed measurement of the
     same command is reported; None when there is none."""
@@ -62,8 +62,9 @@ def pmc_traffic():
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    launches = sum(v['launches'] for k, v in data.items() if k.startswith('k_conv_mfma'))
-    total = sum(v['fetch_bytes'] + v['write_bytes'] for k, v in data.items() if k.startswith('k_conv_mfma'))
+    mfma = [v for k, v in data.items() if k.startswith('k_conv_mfma') or k.startswith('k_conv_wave')]
+    launches = sum(v['launches'] for v in mfma)
+    total = sum(v['fetch_bytes'] + v['write_bytes'] for v in mfma)
     if not launches:
         return None, None
     return total / launches, os.path.relpath(files[-1], ROOT)
@@ -405,7 +406,8 @@ def main():
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE)',
                          'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': round(bytes_fused / max(n_launch, 1)),
-                         'kernel': 'k_conv_mfma (fp32 gather->MFMA sparse convolution)',
+                         'kernel': 'k_conv_wave / k_conv_mfma (fp32 gather->MFMA sparse convolution: wave-autonomous kernel, workgroup-tiled '
+                                   'kernel for the offset-split small maps and the narrow shapes)',
                          'launches_per_step': n_launch // trace_steps,
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),
