@@ -14,7 +14,7 @@ import torch
 def batched_coordinates(coords: Sequence[torch.Tensor]):
     """[(n_i, 3) int] -> ((sum n_i, 4) int32 with the sample index in column 0, [n_i])"""
     sizes = [len(c) for c in coords]
-    out = torch.zeros((sum(sizes), coords[0].shape[1] + 1), dtype=torch.int32)
+    out = torch.zeros((sum(sizes), coords[0].shape[1] + 1), dtype=torch.int32, device=coords[0].device)
     at = 0
     for b, c in enumerate(coords):
         out[at: at + len(c), 0] = b
@@ -50,6 +50,8 @@ def kd_tree_partition(coord, max_num: int, attrs: Sequence = ()):
     -> (list of coordinate arrays, list (per attribute) of lists of arrays | None).  numpy in, numpy out; tensors in,
     tensors out."""
     is_tensor = isinstance(coord, torch.Tensor)
+    if is_tensor and coord.is_cuda:
+        return _kd_tree_partition_device(coord, max_num, attrs)
     c = coord.cpu().numpy() if is_tensor else np.asarray(coord)
     a = [None if t is None else (t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)) for t in attrs]
     parts, attr_parts = [], [None if t is None else [] for t in a]
@@ -80,6 +82,42 @@ def kd_tree_partition(coord, max_num: int, attrs: Sequence = ()):
     if is_tensor:
         parts = [torch.from_numpy(p) for p in parts]
         attr_parts = [None if lst is None else [torch.from_numpy(p) for p in lst] for lst in attr_parts]
+    return parts, attr_parts
+
+
+def _kd_tree_partition_device(coord: torch.Tensor, max_num: int, attrs: Sequence = ()):
+    """The same rule evaluated where the cloud lives (a frame that is already in HBM is not brought back to the host to be
+    cut): variance per axis in float64 (what np.var computes for an integer array), k-th smallest coordinate by
+    torch.kthvalue (as the reference does, on the host), boolean-mask splits that keep the row order.  One 8-byte read-back
+    per split (the size of the left part); parts and attributes stay on the device."""
+    attrs = [None if t is None else (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).to(coord.device) for t in attrs]
+    parts, attr_parts = [], [None if t is None else [] for t in attrs]
+
+    def emit(idx):
+        parts.append(coord[idx])
+        for t, out in zip(attrs, attr_parts):
+            if t is not None:
+                out.append(t[idx])
+
+    def split(idx):
+        n = idx.numel()
+        if n <= max_num:
+            emit(idx)
+            return
+        pts = coord[idx]
+        axis = int(torch.argmax(torch.var(pts.to(torch.float64), dim=0, unbiased=False)).item())
+        half = n // 2
+        column = pts[:, axis].contiguous()
+        value = torch.kthvalue(column, half).values
+        left = column <= value
+        if half <= max_num:
+            emit(idx[left])
+            emit(idx[~left])
+        else:
+            split(idx[left])
+            split(idx[~left])
+
+    split(torch.arange(coord.shape[0], device=coord.device))
     return parts, attr_parts
 
 
