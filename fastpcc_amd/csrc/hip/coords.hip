@@ -54,6 +54,33 @@ __global__ void k_morton(const int32_t *__restrict__ c, int64_t n, int64_t ld, i
     keys[i] = static_cast<int64_t>(morton3((uint32_t)r[a0], (uint32_t)r[a1], (uint32_t)r[a2]));
 }
 
+// ---- Hilbert keys ---------------------------------------------------------------------------------------------------
+// hilbert3d_encode_lut of the reference (lib/space_filling_curves/src/hilbert3d.cu:28-60) walks the coordinate bits from the
+// top through a 12-state machine: (state, Morton octant x | y << 1 | z << 2) -> (Hilbert digit, next state).  The machine
+// is generated here from the curve's geometry -- the root cube's octant order (reflected Gray path) and, per visited octant,
+// the signed axis permutation that maps the root curve onto the child's -- and uploaded once (fpcc_hilbert_init);
+// tests/golden/hilbert.json holds keys of the reference's own table to pin it.
+__device__ uint8_t g_hilbert[12 * 8];         // next_state * 8 | digit
+
+__global__ void k_hilbert(const int32_t *__restrict__ c, int64_t n, int64_t ld, int a0, int a1, int a2, int bits,
+                          int64_t *__restrict__ keys) {
+    __shared__ uint8_t tab[96];
+    if (threadIdx.x < 96) tab[threadIdx.x] = g_hilbert[threadIdx.x];
+    __syncthreads();
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *r = c + i * ld;
+    const uint32_t x = (uint32_t)r[a0], y = (uint32_t)r[a1], z = (uint32_t)r[a2];
+    uint32_t state = 0;
+    uint64_t key = 0;
+    for (int b = bits - 1; b >= 0; --b) {
+        const uint32_t t = tab[state | ((x >> b) & 1u) | (((y >> b) & 1u) << 1) | (((z >> b) & 1u) << 2)];
+        key = (key << 3) | (t & 7u);
+        state = t & ~7u;
+    }
+    keys[i] = static_cast<int64_t>(key);
+}
+
 __global__ void k_keys_from_coords(const int4 *__restrict__ c, int64_t n, int level, int bits, int64_t *__restrict__ keys) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -257,6 +284,56 @@ extern "C" int fpcc_morton3d_encode(const int32_t *coords, int64_t n, int64_t ro
     hipLaunchKernelGGL(k_morton, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), coords, n,
                        row_stride, col_bit0, col_bit1, col_bit2, keys_out);
     FPCC_LAUNCHED(k_morton);
+    return FPCC_OK;
+}
+
+namespace {
+struct AxisMap { int perm[3]; int flip[3]; };
+inline bool same(const AxisMap &a, const AxisMap &b) {
+    for (int i = 0; i < 3; ++i) if (a.perm[i] != b.perm[i] || a.flip[i] != b.flip[i]) return false;
+    return true;
+}
+// the 96-entry machine from the geometry (see k_hilbert); states in breadth-first order from the root
+void build_hilbert_table(uint8_t (&tab)[96]) {
+    static const int base[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 1, 1}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}};
+    static const AxisMap child[8] = {{{2, 0, 1}, {0, 0, 0}}, {{1, 2, 0}, {0, 0, 0}}, {{1, 2, 0}, {0, 0, 0}}, {{0, 1, 2}, {1, 1, 0}},
+                                     {{0, 1, 2}, {1, 1, 0}}, {{1, 2, 0}, {0, 1, 1}}, {{1, 2, 0}, {0, 1, 1}}, {{2, 0, 1}, {1, 0, 1}}};
+    AxisMap states[12] = {{{0, 1, 2}, {0, 0, 0}}};
+    int n_states = 1;
+    for (int s = 0; s < n_states && s < 12; ++s) {
+        for (int k = 0; k < 8; ++k) {
+            int o[3];
+            for (int i = 0; i < 3; ++i) o[i] = states[s].flip[i] ^ base[k][states[s].perm[i]];
+            AxisMap nxt;
+            for (int i = 0; i < 3; ++i) {
+                nxt.perm[i] = child[k].perm[states[s].perm[i]];
+                nxt.flip[i] = states[s].flip[i] ^ child[k].flip[states[s].perm[i]];
+            }
+            int id = 0;
+            while (id < n_states && !same(states[id], nxt)) ++id;
+            if (id == n_states && n_states < 12) states[n_states++] = nxt;
+            tab[s * 8 + (o[0] | o[1] << 1 | o[2] << 2)] = static_cast<uint8_t>(id * 8 + k);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int fpcc_hilbert3d_encode(const int32_t *coords, int64_t n, int64_t row_stride, int col_x, int col_y, int col_z,
+                                     int bits, int64_t *keys_out, void *stream) {
+    if (n < 0 || row_stride < 1 || bits < 1 || bits > 21) return fail_arg("hilbert3d_encode: bad sizes (bits must be in [1, 21])");
+    if (col_x < 0 || col_y < 0 || col_z < 0 || col_x >= row_stride || col_y >= row_stride || col_z >= row_stride)
+        return fail_arg("hilbert3d_encode: column outside the row");
+    if (n == 0) return FPCC_OK;
+    if (!coords || !keys_out) return fail_arg("hilbert3d_encode: null pointer");
+    static const int ready = [] {
+        uint8_t tab[96];
+        build_hilbert_table(tab);
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hilbert), tab, sizeof(tab));
+    }();
+    if (ready != (int)hipSuccess) return check_hip((hipError_t)ready, "hilbert table upload");
+    hipLaunchKernelGGL(k_hilbert, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), coords, n, row_stride,
+                       col_x, col_y, col_z, bits, keys_out);
+    FPCC_LAUNCHED(k_hilbert);
     return FPCC_OK;
 }
 

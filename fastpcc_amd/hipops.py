@@ -20,6 +20,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
 _SIGS = {
     # name: (restype, argtypes)
     'fpcc_morton3d_encode': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'fpcc_hilbert3d_encode': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_keys_from_coords': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'fpcc_coords_from_keys': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'fpcc_sort_keys': (_i64, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
@@ -155,6 +156,19 @@ def morton3d_encode(coords: torch.Tensor, cols=(0, 1, 2)) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.int64, device=coords.device)
     _ok(lib().fpcc_morton3d_encode(coords.data_ptr(), n, coords.stride(0) if n else coords.shape[1], cols[0], cols[1],
                                    cols[2], out.data_ptr(), _stream()))
+    return out
+
+
+def hilbert3d_encode(coords: torch.Tensor, bits: int, cols=(0, 1, 2)) -> torch.Tensor:
+    """Hilbert keys (the reference's hilbert3d_encode_lut); cols = the columns that play x, y, z"""
+    if coords.dtype != torch.int32 or coords.dim() != 2 or not coords.is_cuda:
+        raise TypeError('coords must be a 2-D int32 GPU tensor')
+    if coords.stride(1) != 1:
+        coords = coords.contiguous()
+    n = coords.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=coords.device)
+    _ok(lib().fpcc_hilbert3d_encode(coords.data_ptr(), n, coords.stride(0) if n else coords.shape[1], cols[0], cols[1], cols[2],
+                                    int(bits), out.data_ptr(), _stream()))
     return out
 
 

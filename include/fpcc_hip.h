@@ -50,6 +50,13 @@ int fpcc_device_count(void);
 int fpcc_morton3d_encode(const int32_t *coords, int64_t n, int64_t row_stride, int col_bit0, int col_bit1, int col_bit2,
                          int64_t *keys_out, void *stream);
 
+/* Hilbert key of int32 coordinates; replaces space_filling_curves_ext.hilbert3d_encode_lut
+ * (lib/space_filling_curves/src/hilbert3d.cu:28-60, binding.cu:19-23): `bits` in [1, 21] bits per axis, most significant
+ * first; col_x / col_y / col_z are the columns that play x, y, z (axis_order 'xyz' of a [n,3] array is 0,1,2).  The
+ * 12-state machine is generated from the curve's geometry and uploaded on first use (synchronous, once per process). */
+int fpcc_hilbert3d_encode(const int32_t *coords, int64_t n, int64_t row_stride, int col_x, int col_y, int col_z, int bits,
+                          int64_t *keys_out, void *stream);
+
 /* Level-l keys of batched coordinates [n,4] = (batch, x, y, z): what ME.SparseTensor(coordinates=...) hashes
  * (models/convolutional/lossy_coord_v2/model.py:147-153). */
 int fpcc_keys_from_coords(const int32_t *coords, int64_t n, int level, int bits, int64_t *keys_out, void *stream);

@@ -17,6 +17,7 @@ Sources of truth used:
   kdtree.json    partition sizes / checksums of lib/data_utils.py:168-234 kd_tree_partition on seeded coordinates
   me_semantics.json  the reference's own statements about MinkowskiEngine / torchsparse conventions: child tables, identity
                  kernels of the fold convolutions, state_dict key / shape lists of its models built on a parameter-only stub engine
+  hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -611,8 +612,33 @@ def make_me_semantics():
     return out
 
 
+def make_hilbert():
+    """keys of hilbert3d_encode_lut (lib/space_filling_curves/src/hilbert3d.cu:28-60; CUDA only, so the 96-entry state table is
+    read out of the source text and the kernel's loop evaluated here): every point of a 4x4x4 cube at 2 bits, seeded points at
+    1, 5, 10 and 21 bits, two axis orders"""
+    src = open(os.path.join(REF, 'lib/space_filling_curves/src/hilbert3d.cu')).read()
+    tab = [int(v) for v in re.search(r'kMortonToHilbertTable\[96\] = \{([^}]*)\}', src).group(1).replace('\n', ' ').split(',') if v.strip()]
+    assert len(tab) == 96
+
+    def key(x, y, z, bits):
+        t = k = 0
+        for b in range(bits - 1, -1, -1):
+            v = tab[t | ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2)]
+            k, t = (k << 3) | (v & 7), v & ~7
+        return k
+    rng = np.random.default_rng(11)
+    out = []
+    cube = [[x, y, z] for x in range(4) for y in range(4) for z in range(4)]
+    cases = [(2, cube)] + [(bits, rng.integers(0, 1 << bits, (60, 3)).tolist()) for bits in (1, 5, 10, 21)]
+    for bits, pts in cases:
+        for order, cols in (('xyz', (0, 1, 2)), ('zxy', (2, 0, 1))):
+            out.append({'bits': bits, 'axis_order': order, 'cols': list(cols), 'xyz': pts,
+                        'keys': [key(p[cols[0]], p[cols[1]], p[cols[2]], bits) for p in pts]})
+    return out
+
+
 def main():
-    for name, fn in (('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

@@ -141,3 +141,19 @@ def test_empty_and_tiny_inputs(ops):
     par, pk, cr, cnt = ops.coarsen(one)
     assert int(cnt.item()) == 1 and par.cpu().tolist() == [0]
     assert cr[0].cpu().tolist() == [-1, -1, -1, -1, -1, 0, -1, -1]      # (5,6,7): octant = (x&1) + 2(y&1) + 4(z&1) = 5
+
+
+def test_hilbert_keys_match_reference_golden_and_oracle():
+    import json, os
+    from fastpcc_amd import hipops as ops
+    from oracle.hilbert import hilbert3d_encode
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'hilbert.json')) as f:
+        G = json.load(f)
+    for case in G:
+        xyz = torch.tensor(case['xyz'], dtype=torch.int32).cuda()
+        assert ops.hilbert3d_encode(xyz, case['bits'], case['cols']).cpu().tolist() == case['keys']
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 1 << 21, (200000, 4)).astype(np.int32)           # a wider row: columns 1..3 hold the axes
+    got = ops.hilbert3d_encode(torch.from_numpy(big).cuda(), 21, (1, 2, 3)).cpu().numpy()
+    assert (got == hilbert3d_encode(big, 21, (1, 2, 3))).all()
+    assert ops.hilbert3d_encode(torch.zeros((0, 3), dtype=torch.int32, device='cuda'), 10).shape == (0,)
