@@ -411,33 +411,39 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
         // would wait for the loads issued a moment ago.  Loop invariants are taken out by hand (the compiler re-reads kernel
         // arguments and the zero row's address through scalar loads -- and waits for them -- inside the loop otherwise).
         const float *const zero = (const float *)g_zero_row + 4 * lh;
-        const float *const x1b = a.x1 + 4 * lh, *const x2b = a.x2 ? a.x2 + 4 * lh - a.c1 : zero;
+        const float *const x1b = a.x1 + 4 * lh, *const x2b = a.x2 ? a.x2 + 4 * lh : zero;
         const int64_t ld1 = a.ld1, ld2 = a.ld2;
-        const int c1 = a.c1;
-        auto a_ptr = [&](int k, int cc) -> const float * {
-            const bool in_x1 = cc * CH < c1;                 // wave-uniform
-            const float *xb = (in_x1 ? x1b : x2b) + cc * CH;
-            const int64_t ld = in_x1 ? ld1 : ld2;
+        const int n1 = a.c1 / CH;                                // chunks [0, n1) lie in x1, the rest in x2
+        // Per kernel offset: this lane's row in x1 / x2 (one LDS read, two 64-bit multiply-adds), then one add per chunk.
+        // An absent neighbour reads the zero row with a zero chunk step.
+        const float *a1, *a2, *bpk;
+        int step;
+        auto set_offset = [&](int k) {
             int32_t idx = s_nbr[k * 32 + li];
             if (DBG & 1) idx = idx < 0 ? idx : 0;
-            const int32_t neg = idx >> 31;                    // 0 or ~0; a select here comes back as a branch (if-conversion)
-            const uint64_t m = (uint64_t)(int64_t)neg;
-            const uint64_t p = reinterpret_cast<uint64_t>(xb + (int64_t)(idx & ~neg) * ld);
-            return reinterpret_cast<const float *>((p & ~m) | (reinterpret_cast<uint64_t>(zero) & m));
+            const int32_t neg = idx >> 31;                        // 0 or ~0; a select here comes back as a branch (if-conversion)
+            const uint64_t m = (uint64_t)(int64_t)neg, z = reinterpret_cast<uint64_t>(zero) & m;
+            const int64_t row = idx & ~neg;
+            a1 = reinterpret_cast<const float *>((reinterpret_cast<uint64_t>(x1b + row * ld1) & ~m) | z);
+            a2 = reinterpret_cast<const float *>((reinterpret_cast<uint64_t>(x2b + row * ld2) & ~m) | z);
+            step = CH & ~neg;
+            bpk = (DBG & 2) ? wp_g : wp_g + (int64_t)k * n_chunks * chunk_floats;
         };
         // fetch position: the next (offset, chunk) stage whose operands are to be requested; past the last stage it stays
         // on the last one (re-read, never used)
         unsigned rest = wmask;
-        int k_f = __ffs(rest) - 1, cc_f = 0;
+        int cc_f = 0;
+        set_offset(__ffs(rest) - 1);
         const float *ap, *bp;
         auto next_stage = [&]() {
-            ap = a_ptr(k_f, cc_f);
-            bp = (DBG & 2) ? wp_g : wp_g + ((int64_t)k_f * n_chunks + cc_f) * chunk_floats;
+            const bool in1 = cc_f < n1;                           // wave-uniform
+            ap = (in1 ? a1 : a2) + (in1 ? cc_f : cc_f - n1) * step;
+            bp = (DBG & 2) ? bpk : bpk + cc_f * chunk_floats;
             if (cc_f + 1 < n_chunks) {
                 ++cc_f;
             } else {
                 const unsigned r2 = rest & (rest - 1);
-                if (r2) { rest = r2; k_f = __ffs(r2) - 1; cc_f = 0; }
+                if (r2) { rest = r2; cc_f = 0; set_offset(__ffs(r2) - 1); }
             }
         };
         // hipcc's scheduler would sink every load down to its first use (it minimises live ranges), exposing a full L2 / HBM

@@ -133,6 +133,52 @@ __global__ __launch_bounds__(256, 2) void k_probe2(const float *__restrict__ wp,
     if (lane == 0) { clk[wave_id * 2] = t1 - t0; clk[wave_id * 2 + 1] = r1 - r0; }
 }
 
+// mode 12 / 13: ONE accumulator (a one-block unit of the wave kernel): 16 dependent MFMAs per stage; mode 12 adds the unit's loads
+// (4 gathers of an L2-resident table + 4 B loads), mode 13 has none; mode 14: two accumulators, 32 MFMAs, 4 + 8 loads
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void k_probe3(const float *__restrict__ wp, const float *__restrict__ x, int stages, float *out, unsigned long long *clk) {
+    constexpr int NBW = MODE == 14 ? 2 : 1;
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x16 acc[NBW];
+    for (int nb = 0; nb < NBW; ++nb) for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    f32x4 ra[4], rb[4][NBW];
+    for (int g = 0; g < 4; ++g) { ra[g] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane + g); for (int nb = 0; nb < NBW; ++nb) rb[g][nb] = f32x4{.5f, .25f, .125f, 1.f} * (float)(nb + 1); }
+    const float *bp0 = wp + lane * 4;
+    unsigned seed = wave_id * 2654435761u + 12345u;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int s = 0; s < stages; ++s) {
+        seed = seed * 1664525u + 1013904223u;
+        const float *bp = bp0 + (long)((seed >> 8) % 108) * 4096;
+        const float *ap = x + (long)((((seed >> 4) + li * 977u) * 2654435761u >> 7) % 2048) * 128 + ((seed >> 20) & 3) * 32 + 4 * lh;
+        __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 av = ra[g];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, rb[g][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, rb[g][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, rb[g][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[g][nb].w, acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x6);
+            if (MODE != 13) {
+                ra[g] = *reinterpret_cast<const f32x4 *>(ap + 8 * g);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) { __builtin_amdgcn_sched_barrier(0x6); rb[g][nb] = *reinterpret_cast<const f32x4 *>(bp + (g * 4 + nb) * 256); }
+            }
+            __builtin_amdgcn_sched_barrier(0x6);
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int nb = 0; nb < NBW; ++nb) for (int r = 0; r < 16; ++r) sum += acc[nb][r];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+    if (lane == 0) { clk[wave_id * 2] = t1 - t0; clk[wave_id * 2 + 1] = r1 - r0; }
+}
+
 int main(int argc, char **argv) {
     const int stages = argc > 1 ? atoi(argv[1]) : 400;
     const int n_rows = 272488;
@@ -143,8 +189,8 @@ int main(int argc, char **argv) {
     std::vector<int> h(n_rows); unsigned s = 1; for (int i = 0; i < n_rows; ++i) { s = s * 1664525u + 1013904223u; h[i] = (s >> 4) % n_rows; }
     hipMemcpy(rows, h.data(), n_rows * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {0, 1, 10, 2, 8, 9, 11, 3, 4})
-        for (int wps = 1; wps <= 2; ++wps) {
+    for (int mode : {0, 13, 12, 14, 1, 2})
+        for (int wps = 1; wps <= 4; wps *= 2) {
             const int grid = 256 * wps;
             float best = 1e30f;
             std::vector<unsigned long long> c(grid * 8);
@@ -159,6 +205,9 @@ int main(int argc, char **argv) {
                 if (mode == 9) hipLaunchKernelGGL(k_probe<9>, dim3(grid), dim3(256), 0, 0, wp, x, rows, n_rows, stages, out, clk);
                 if (mode == 10) hipLaunchKernelGGL(k_probe<10>, dim3(grid), dim3(256), 0, 0, wp, x, rows, n_rows, stages, out, clk);
                 if (mode == 11) hipLaunchKernelGGL(k_probe<11>, dim3(grid), dim3(256), 0, 0, wp, x, rows, n_rows, stages, out, clk);
+                if (mode == 12) hipLaunchKernelGGL(k_probe3<12>, dim3(grid), dim3(256), 0, 0, wp, x, stages, out, clk);
+                if (mode == 13) hipLaunchKernelGGL(k_probe3<13>, dim3(grid), dim3(256), 0, 0, wp, x, stages, out, clk);
+                if (mode == 14) hipLaunchKernelGGL(k_probe3<14>, dim3(grid), dim3(256), 0, 0, wp, x, stages, out, clk);
                 if (mode == 3) hipLaunchKernelGGL(k_probe<3>, dim3(grid), dim3(256), 0, 0, wp, x, rows, n_rows, stages, out, clk);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
@@ -166,10 +215,11 @@ int main(int argc, char **argv) {
             hipMemcpy(c.data(), clk, grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             double cyc = 0, real = 0; for (int w = 0; w < grid * 4; ++w) { cyc += c[w * 2]; real += c[w * 2 + 1]; }
             cyc /= grid * 4; real /= grid * 4;
-            const double mfmas = (double)stages * 64 * grid * 4;
+            const int per_stage = mode == 12 || mode == 13 ? 16 : mode == 14 ? 32 : 64;
+            const double mfmas = (double)stages * per_stage * grid * 4;
             const double tf = mfmas * 4096 / (best * 1e-3) / 1e12;
             printf("mode %d waves/SIMD %d: %.3f ms  %.1f TFLOP/s  %.1f SIMD cycles per MFMA  clock %.2f GHz (in-kernel)\n", mode, wps, best, tf,
-                   cyc / (stages * 64.0) / wps, cyc / real * 0.1);
+                   cyc / (stages * (double)per_stage) / wps, cyc / real * 0.1);
         }
     return 0;
 }

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r02s; mkdir -p $O
+timeout 1200 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
+tail -22 $O/pytest_gpu.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
