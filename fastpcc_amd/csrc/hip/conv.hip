@@ -1,21 +1,30 @@
-// fp32 sparse convolution for gfx950: output-stationary gather -> LDS -> v_mfma_f32_32x32x2_f32.
+// fp32 sparse convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 157.3 TFLOP/s dense peak).
 //
-// One workgroup (4 waves) owns 128 consecutive output rows (rows are Morton-sorted, so their neighbourhoods overlap and
-// the gathered input rows are L2-resident) and ALL output channels.  It walks the kernel offsets that occur in its tile
-// and, per offset, the input channels in chunks of CH; a stage = (offset, chunk):
-//     global (gathered rows of X, one 128-byte line per row and chunk; the W[k] chunk, contiguous)
-//         -> registers (issued one stage ahead) -> LDS (double buffered, XOR-swizzled) -> MFMA fragments.
-// Every output element is ONE fp32 FMA chain (offsets ascending, channels in the order documented in fpcc_hip.h), it is
-// written once, nothing is scattered or atomically added: results are bitwise reproducible and independent of tiling,
-// which the codec needs because the decoder must recompute the encoder's activations exactly.
-// Offsets absent from a whole wave's 32 rows are skipped by that wave, offsets absent from the tile by the workgroup
-// (adding x*0 would not change the chain's value).
+// Every output element is ONE fp32 FMA chain -- kernel offsets ascending, channels in the order documented in
+// fpcc_hip.h ("summation order") -- written once, never scattered or atomically added, so results are bitwise
+// reproducible and independent of tiling, row order and which of the kernels below ran.  The codec needs that: the
+// decoder must recompute the encoder's activations exactly.  An absent neighbour contributes x*0 from a zero row, or is
+// skipped where a whole wave lacks the offset (neither changes the chain's value).
 //
-// Roofline: 2*L*C_in*C_out algorithmic flop against the fp32 MFMA peak (157 TFLOP/s); the gathered bytes
-// (L*C_in*4 from L2/MALL) are ~1/16 of what the MFMAs can consume at C_out = 128.
+// Three kernels, chosen per launch (launch_conv):
+//   k_conv_wave   wave-autonomous, the default for 32-multiple channel counts with packed weights (fpcc_conv_f32_pk):
+//                 a wave owns 32 output rows x NBW 32-column blocks; per (offset, 32-channel chunk) it gathers its A
+//                 fragment straight from the input rows into registers in MFMA layout (8 dword loads per lane, absent
+//                 rows redirected to the zero row by a bitwise pointer select) and streams B from the packed weights
+//                 wp[offset][chunk][g8][nb][h][i][j] as 16-byte coalesced loads that stay in L2.  No LDS, no barrier; the
+//                 operands of group g are refilled in place right after the MFMAs that consumed them, with
+//                 sched_barrier pinning the load issue points (hipcc otherwise sinks them to their first use).
+//   k_conv_mfma   workgroup-tiled: 4 waves own RT*32 rows and all output columns, X rows and W chunks go through
+//                 double-buffered XOR-swizzled LDS.  Used when weights are not packed (training, changing weights),
+//                 for 16-channel chunks, for grouped/transposed maps (out_map) and for the offset-split path.
+//   k_conv_valu   shapes MFMA tiles do not cover (C_out in {1, 8, 16}, C_in = 1 ...): one thread per output row and
+//                 <= 16 output channels, weights through the scalar cache.  Bandwidth-bound, tiny in this codec.
+// Maps with <= FPCC_SPLIT_MAX_ROWS rows run one launch per kernel offset into a workspace and k_split_reduce adds the
+// partial sums in offset order (summation order 2 -- part of the stream format, see FPCC_NUMERICS_VERSION).
 //
-// Shapes the MFMA kernel does not cover (C_out in {1, 8, 16}, C_in = 1, ...) are tiny in this codec and go through the
-// VALU kernel below: one thread per output row and block of <= 16 output channels, weights through the scalar cache.
+// Roofline: 2 * pairs * C_in * C_out algorithmic flop against the fp32 MFMA peak.  Measured limits of this design are in
+// profiles/r02/wave_kernel_sweeps.md: each VMEM instruction costs ~30 SIMD cycles of issue that more waves do not hide,
+// and the B stream (256 B per MFMA from L2) caps the wave kernel at ~100 TFLOP/s on the 272 K-row maps.
 #include "common.h"
 #include <cstdlib>
 

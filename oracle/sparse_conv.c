@@ -12,7 +12,7 @@
  *
  * Parity: UNPINNED against MinkowskiEngine (it cannot be built or run in this image).  It is
  * pinned against oracle/sparse_conv.py's torch formulation (index_select -> mm -> index_add_, the structure of ME's
- * CPU backend) in tests/test_oracle_conv.py.
+ * CPU backend) in tests/test_oracle_float.py::test_conv_mm_equals_chain.
  *
  * fp32 addition is not associative and the reference leaves the summation order to cuBLAS.  This restatement fixes
  * one: a single fused-multiply-add chain per output element, kernel offsets ascending, input channels in the order

@@ -9,7 +9,7 @@ section 8a.  Two evaluations of the same sum:
                  device kernel documenting the same order can be compared BIT FOR BIT
 
 Parity: UNPINNED against MinkowskiEngine (un-vendored, not installable here).  The two evaluations are checked against
-each other in tests/test_oracle_conv.py.
+each other in tests/test_oracle_float.py::test_conv_mm_equals_chain.
 """
 import ctypes as C
 from typing import Optional

@@ -1,0 +1,133 @@
+"""lossy_coord_v3 (octree codec with coded latents and top-k finest levels) on the GPU against oracle/codec_v3.py.
+
+What can be exact is exact: told the kernels' documented summation order, the oracle reproduces every logit, latent and
+symbol of the encoder bit for bit, the header and the side information byte for byte, and its decoder reconstructs the same
+points as the GPU decoder.  The 255-ary CDF rows come from a float softmax on either side (torch CPU vs GPU exp), so the
+coded bytes may differ by rounding of single CDF entries: lengths are compared within 1 %."""
+import numpy as np
+import pytest
+import torch
+
+from fastpcc_amd.synthetic import batched, surface_cloud
+from oracle.codec_v3 import OracleV3
+
+pytestmark = pytest.mark.gpu
+
+R1 = dict(num_latents=(0, 0, 2, 2, 0), lossl_geo_upsample=(0, 1, 1, 1, 1))           # config/.../dense_r1.yaml
+R4 = dict(num_latents=(0, 0, 2, 2, 0), lossl_geo_upsample=(0, 0, 1, 1, 1))           # dense_r4.yaml
+R7 = dict(num_latents=(0, 0, 0, 2, 2), lossl_geo_upsample=(0, 0, 0, 1, 1))           # dense_r7.yaml
+LOSSLESS = dict(num_latents=(0, 1, 2), lossl_geo_upsample=(1, 1, 1))
+
+
+def _model(channels, seed, **kw):
+    from fastpcc_amd.codecs.lossy_coord_v3 import Config, Model
+    from fastpcc_amd.codecs.lossy_coord_v3.init_random import randomize_
+    cfg = Config(channels=channels, max_stride=64, **kw)
+    model = Model(cfg)
+    randomize_(model, seed)
+    weights = {k: v.clone() for k, v in model.state_dict().items()}
+    return cfg, model.cuda().eval(), weights
+
+
+def _order(c_in, c_out, n_offsets, n_out):
+    from fastpcc_amd import hipops as ops
+    return ops.conv_order(c_in, 0, c_out, n_offsets, 1, n_out)
+
+
+def _rows(a):
+    return sorted(map(tuple, np.asarray(a).tolist()))
+
+
+@pytest.mark.parametrize('name,kw,channels', [('r1', R1, 32), ('r4', R4, 32), ('r7', R7, 64), ('lossless', LOSSLESS, 32)])
+def test_encoder_bit_exact_and_decoders_agree(name, kw, channels):
+    cfg, model, weights = _model(channels, 3, **kw)
+    xyz = surface_cloud(7, 64, 9000) + np.array([3, 0, 17], dtype=np.int32)
+    coords = batched(xyz)
+    dev = torch.from_numpy(coords).cuda()
+    model.trace = {}
+    data = model.compress(dev[torch.randperm(len(dev), device='cuda')])
+    oracle = OracleV3(weights, cfg, conv='chain', order_fn=_order)
+    want = oracle.compress(coords.astype(np.int64))
+    n_lossy = next((i for i, v in enumerate(cfg.lossl_geo_upsample) if v), len(cfg.lossl_geo_upsample))
+    head = 8 + 3 * n_lossy
+    assert data[:head] == want[:head]                                   # offsets, coarsest count, per-level point counts
+    seen = 0
+    for key, val in model.trace.items():
+        got = val.cpu().numpy()
+        ref = oracle.trace[key]
+        assert got.shape == ref.shape, key
+        assert (got.view(np.int32) == ref.view(np.int32)).all() if got.dtype == np.float32 else (got == ref.astype(got.dtype)).all(), key
+        seen += key.startswith('latent')
+    assert seen == sum(cfg.num_latents[i] for i in range(len(cfg.num_latents)) if cfg.lossl_geo_upsample[i])
+    lat = [v for k, v in model.trace.items() if k.startswith('latent')]
+    assert not lat or max(len(torch.unique(v)) for v in lat) >= 3      # the latents are not degenerate
+    assert abs(len(data) - len(want)) <= max(4, 0.01 * len(want))
+
+    rec = model.decompress(data).cpu().numpy()
+    ref = oracle.decompress(want)
+    assert (rec == ref).all()                                           # same points, same (Morton) order
+    if name == 'lossless':
+        assert _rows(rec) == _rows(xyz)
+    else:
+        # levels above the lossy ones are coded losslessly: the reconstruction's ancestors there are the cloud's
+        lo = xyz.min(0)                                                  # octree cells are aligned to the cloud's minimum corner
+        assert _rows(np.unique((rec - lo) >> n_lossy, axis=0)) == _rows(np.unique((xyz - lo) >> n_lossy, axis=0))
+        assert 0.5 * len(xyz) <= len(rec) <= len(xyz) + 2 * len(np.unique((xyz - lo) >> 1, axis=0))
+    assert model.compress(dev) == data                                  # input order does not matter, deterministic
+
+
+def test_gather_gemm_oracle_agrees_up_to_rounding():
+    """the independent evaluation of the convolution sum (gather -> GEMM -> accumulate per kernel offset) gives the same
+    latents and logits up to fp32 rounding"""
+    cfg, model, weights = _model(32, 5, **R1)
+    xyz = surface_cloud(2, 64, 6000)
+    coords = batched(xyz)
+    model.trace = {}
+    model.compress(torch.from_numpy(coords).cuda())
+    oracle = OracleV3(weights, cfg, conv='mm')
+    oracle.compress(coords.astype(np.int64))
+    for key, val in model.trace.items():
+        got, ref = val.cpu().numpy().astype(np.float64), oracle.trace[key].astype(np.float64)
+        if key.startswith('latent'):
+            assert np.mean(got != ref) < 0.02, key
+        elif key.startswith('logits'):
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_top_children_rule():
+    from fastpcc_amd.codecs.lossy_coord_v3.model import top_children
+    from oracle.codec_v3 import top_children as ref
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((500, 8), generator=g)
+    x[::7] = x[::7].round()                                              # ties inside rows and across the level
+    for n in (1, 499, 500, 1234, 3999, 4000):
+        assert (top_children(x.cuda(), n).cpu().numpy() == ref(x.numpy(), n)).all()
+    m = top_children(x.cuda(), 800)
+    assert m.any(1).all() and m.sum() >= 500
+
+
+def test_test_forward_partitions_and_full_width():
+    from fastpcc_amd.data import PCData
+    cfg, model, _ = _model(128, 1, **R1)
+    xyz = surface_cloud(4, 128, 40000)
+    dev = torch.from_numpy(batched(xyz)).cuda()
+    out = model(PCData(xyz=dev))
+    rec = out['pred'].cpu().numpy()
+    lo = xyz.min(0)
+    assert _rows(np.unique((rec - lo) >> 1, axis=0)) == _rows(np.unique((xyz - lo) >> 1, axis=0))
+    assert len(out['compressed_bytes']) > 0
+    cut = int(xyz[:, 0].mean())
+    halves = dev[dev[:, 1] < cut].contiguous(), dev[dev[:, 1] >= cut].contiguous()
+    rec2 = model.decompress_partitions(model.compress_partitions([dev, *halves])).cpu().numpy()
+    assert len(rec2) > 0.9 * len(xyz)                                   # every partition is aligned to its own corner
+
+
+def test_rejects_what_the_format_cannot_carry():
+    from fastpcc_amd.codecs.lossy_coord_v3 import Config, Model
+    with pytest.raises(ValueError):
+        Config(num_latents=(0, 0), lossl_geo_upsample=(1, 0)).check()       # lossy above lossless
+    with pytest.raises(ValueError):
+        Config(num_latents=(1, 0, 0, 0), lossl_geo_upsample=(0, 0, 0, 1)).check()
+    model = Model(Config(channels=32, num_latents=(0, 1, 0), lossl_geo_upsample=(0, 0, 1), max_stride=32)).cuda().eval()
+    with pytest.raises(NotImplementedError):                                # latents on a lossy level: not decodable
+        model.compress(torch.from_numpy(batched(surface_cloud(1, 32, 1500))).cuda())
