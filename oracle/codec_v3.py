@@ -88,15 +88,17 @@ class OracleV3:
         if self.conv == 'chain':
             return sc.conv_chain(x, None if table is None else table.astype(np.int32), w, b, n_out,
                                  order=self.order_fn(c_in, c_out, k, n_out))
-        out = np.zeros((n_out, c_out), dtype=np.float32)
+        # gather -> GEMM -> scatter-add per kernel offset, bias last: the structure (and, on one machine, the bits) of a
+        # torch evaluation of the same sum
+        xt, wt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), torch.from_numpy(np.ascontiguousarray(w))
+        out = torch.zeros((n_out, c_out), dtype=torch.float32)
         for i in range(k):
-            if table is None:
-                out += x @ w[i]
-                continue
-            rows = np.nonzero(table[i] >= 0)[0]
+            rows = torch.from_numpy(np.nonzero(table[i] >= 0)[0])
             if len(rows):
-                out[rows] += x[table[i, rows]] @ w[i]
-        return out if b is None else out + b
+                out.index_add_(0, rows, torch.mm(xt.index_select(0, torch.from_numpy(table[i][rows.numpy()].astype(np.int64))), wt[i]))
+        if b is not None:
+            out += torch.from_numpy(b)
+        return out.numpy()
 
     def sconv(self, pre: str, x: Sp, ks: int = 3, st: int = 1) -> Sp:
         w = self.P[pre + '.kernel']
@@ -113,8 +115,12 @@ class OracleV3:
         return Sp(f, out_c, out_stride, x.caches)
 
     def linear(self, pre: str, f: np.ndarray) -> np.ndarray:
-        w = self.P[pre + '.weight']                                   # [out, in]
-        return self._gemm(f, None, np.ascontiguousarray(w.T)[None], self.P.get(pre + '.bias'), f.shape[0])
+        w, b = self.P[pre + '.weight'], self.P.get(pre + '.bias')      # [out, in]
+        if self.conv == 'chain':
+            return sc.conv_chain(f, None, np.ascontiguousarray(w.T)[None], b, f.shape[0],
+                                 order=self.order_fn(w.shape[1], w.shape[0], 1, f.shape[0]))
+        return torch.nn.functional.linear(torch.from_numpy(np.ascontiguousarray(f, dtype=np.float32)), torch.from_numpy(w),
+                                          None if b is None else torch.from_numpy(b)).numpy()
 
     def act(self, pre: str, f: np.ndarray) -> np.ndarray:
         return prelu(f, self.P[pre + '.weight'])
@@ -274,12 +280,17 @@ class OracleV3:
             if idx != 1:
                 cur = self.expand(pre, cur, bits[idx], coords[idx - 1], caches)
         enc = RansEncoder(32 << 20)
+        self.coded = {'symbols': [], 'rows': [], 'fea': []}          # what went to the coder, in coding order
         while pending:
             latents, rows, sym = pending.pop()
             enc.encode(rows, sym)
+            self.coded['symbols'].append(sym)
+            self.coded['rows'].append(rows)
             while latents:
+                self.coded['fea'].append(latents[-1])
                 self.encode_fea(enc, *latents.pop())
         bottom = coords[-1][:, 1:].reshape(-1)
+        self.coded['fea'].append((histogram_cdf(bottom), bottom, None))
         self.encode_fea(enc, histogram_cdf(bottom), bottom)
         head = b''.join(int(v).to_bytes(2, 'little') for v in offset.tolist()) + (len(bottom) // 3).to_bytes(2, 'little')
         head += b''.join(int(n).to_bytes(3, 'little') for n in points_num)

@@ -18,6 +18,8 @@ Sources of truth used:
   me_semantics.json  the reference's own statements about MinkowskiEngine / torchsparse conventions: child tables, identity
                  kernels of the fold convolutions, state_dict key / shape lists of its models built on a parameter-only stub engine
   hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
+  codec_v3.json  the reference's lossy_coord_v3 model executed on the CPU over a functional torchsparse stand-in (kernel-offset
+                 enumeration restated, everything else the reference's code and coder): streams, side information, reconstructions
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -637,8 +639,224 @@ def make_hilbert():
     return out
 
 
+def _functional_torchsparse():
+    """A torchsparse stand-in that EVALUATES on the CPU, good enough to run the reference's lossy_coord_v3 codec end to end:
+    SparseTensor / TensorCache containers, spnn.Conv3d parameters ([K, C_in, C_out] kernel -- 2-D for K = 1 --, [C_out]
+    bias) and SF.conv3d as gather -> torch.mm -> index_add_ per kernel offset.  What is RESTATED here (not taken from
+    torchsparse, which cannot be installed) is the enumeration of kernel offsets: odd kernels centred with x fastest, even
+    kernels anchored at 0 with z fastest -- the enumeration of the reference's own integer engine
+    (lib/int_sparse_conv/src/hashmap/hashmap_cuda.cuh:239-258), whose float->int weight import is a plain permute
+    (cuda_ops.py:257-260), and the one the reference's fold / unfold kernels imply (me_semantics.json).  Strided outputs come
+    from SF.spdownsample, which the reference replaces with its own function.  Everything the model does WITH these
+    operators -- what is coded, in which order, with which side information -- is the reference's code."""
+    import enum
+    import torch
+    import torch.nn as nn
+    _stub_engines()
+    ts, ts_nn, SF = sys.modules['torchsparse'], sys.modules['torchsparse.nn'], sys.modules['torchsparse.nn.functional']
+
+    class TensorCache:
+        def __init__(self):
+            self.cmaps, self.kmaps, self.hashmaps = {}, {}, {}
+
+    class SparseTensor:
+        def __init__(self, feats, coords, stride=1, spatial_range=None):
+            self.F, self.C = feats, coords
+            self.stride = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+            self.spatial_range = spatial_range
+            self._caches = TensorCache()
+        feats = property(lambda self: self.F)
+        coords = property(lambda self: self.C)
+
+    as3 = lambda v: (v,) * 3 if isinstance(v, int) else tuple(int(i) for i in v)
+
+    def key(c):
+        c = c.long()
+        return (c[:, 0] << 60) | (c[:, 1] << 40) | (c[:, 2] << 20) | c[:, 3]
+
+    def kernel_table(in_c, out_c, ks, st):
+        keys = key(in_c)
+        order = torch.argsort(keys)
+        keys = keys[order]
+        volume = ks[0] * ks[1] * ks[2]
+        table = torch.full((volume, out_c.shape[0]), -1, dtype=torch.long)
+        axes = (0, 1, 2) if volume % 2 else (2, 1, 0)
+        for k in range(volume):
+            rem, q = k, out_c.long().clone()
+            for a in axes:
+                q[:, 1 + a] = q[:, 1 + a] * st[a] + rem % ks[a] - (ks[a] - 1) // 2
+                rem //= ks[a]
+            ok = (q[:, 1:] >= 0).all(1)
+            kq = key(torch.where(ok[:, None], q, torch.zeros_like(q)))
+            pos = torch.searchsorted(keys, kq).clamp(max=len(keys) - 1)
+            hit = ok & (keys[pos] == kq)
+            table[k, hit] = order[pos[hit]]
+        return table
+
+    def conv3d(input, weight, kernel_size, bias=None, stride=1, padding=0, dilation=1, transposed=False, generative=False,
+               config=None, training=False):
+        assert not transposed and not generative and as3(dilation) == (1, 1, 1)
+        ks, st = as3(kernel_size), as3(stride)
+        caches = input._caches
+        if st == (1, 1, 1):
+            out_c, out_stride = input.C, input.stride
+        else:
+            out_stride = tuple(a * b for a, b in zip(input.stride, st))
+            if out_stride in caches.cmaps:
+                out_c = caches.cmaps[out_stride][0]
+            else:
+                out_c = SF.spdownsample(input.C, st, ks, torch.zeros(3, dtype=torch.int32), input.spatial_range)
+        tag = (input.stride, ks, st)
+        if tag not in caches.kmaps:
+            caches.kmaps[tag] = kernel_table(input.C, out_c, ks, st)
+        table = caches.kmaps[tag]
+        w = weight.reshape(table.shape[0], -1, weight.shape[-1])
+        out = torch.zeros((out_c.shape[0], w.shape[-1]), dtype=input.F.dtype)
+        for k in range(table.shape[0]):
+            rows = torch.nonzero(table[k] >= 0)[:, 0]
+            if len(rows):
+                out.index_add_(0, rows, torch.mm(input.F.index_select(0, table[k, rows]), w[k]))
+        if bias is not None:
+            out += bias
+        caches.cmaps.setdefault(input.stride, (input.C, input.spatial_range))
+        caches.cmaps.setdefault(out_stride, (out_c, None))
+        ret = SparseTensor(out, out_c, out_stride, None)
+        ret._caches = caches
+        return ret
+
+    class Conv3d(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, bias=False,
+                     transposed=False, generative=False, config=None):
+            super().__init__()
+            self.in_channels, self.out_channels = in_channels, out_channels
+            self.kernel_size, self.stride, self.padding, self.dilation = as3(kernel_size), as3(stride), as3(padding), dilation
+            volume = int(np.prod(self.kernel_size))
+            self.kernel = nn.Parameter(torch.zeros((volume, in_channels, out_channels) if volume > 1 else (in_channels, out_channels)))
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+        def forward(self, input):
+            return conv3d(input, self.kernel, self.kernel_size, self.bias, self.stride, self.padding, self.dilation)
+
+    class _Cfg(dict):
+        __getattr__ = dict.get
+        __setattr__ = dict.__setitem__
+
+    cc = types.SimpleNamespace(Dataflow=enum.Enum('Dataflow', 'ImplicitGEMM GatherScatter FetchOnDemand CodedCSR'),
+                               get_default_conv_config=lambda conv_mode=None: _Cfg(), set_global_conv_config=lambda c: None)
+    SF.conv_config, SF.get_conv_mode, SF.conv3d = cc, (lambda: None), conv3d
+    SF.spdownsample = lambda *a, **k: (_ for _ in ()).throw(RuntimeError('the model installs its own spdownsample'))
+    ts.SparseTensor, ts_nn.Conv3d = SparseTensor, Conv3d
+    sys.modules['torchsparse.utils.tensor_cache'].TensorCache = TensorCache
+    return ts
+
+
+def make_codec_v3():
+    """The reference's lossy_coord_v3 model EXECUTED on the CPU over the functional torchsparse stand-in above, with the
+    reference's own rANS coder (oracle/_ref): state_dict layout, side-information tables, batch_quantize_pmf_torch vectors,
+    and whole compress / decompress runs on small seeded clouds with seeded weights (streams, headers, rounded latents,
+    symbols, reconstructions)."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    import yaml
+    _functional_torchsparse()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossy_coord_v3 import model as ref_model
+        from models.convolutional.lossy_coord_v3.model_config import Config
+    finally:
+        ce.load = real
+    from fastpcc_amd.codecs.lossy_coord_v3.init_random import randomize_
+    from fastpcc_amd.synthetic import batched, surface_cloud
+    torch.cuda.synchronize = lambda *a, **k: None                    # the reference synchronises unconditionally; CPU run
+
+    def cfg_of(path=None, **kw):
+        cfg = Config()
+        if path:
+            with open(os.path.join(REF, path)) as f:
+                text = f.read()
+            inc = re.search(r'#\s*include\s+"([^"]+)"', text)
+            if inc:
+                with open(os.path.join(REF, inc.group(1))) as f:
+                    for k, v in yaml.safe_load(f)['model'].items():
+                        setattr(cfg, k, tuple(v) if isinstance(v, list) else v)
+            for k, v in yaml.safe_load(text)['model'].items():
+                assert hasattr(cfg, k), k
+                setattr(cfg, k, tuple(v) if isinstance(v, list) else v)
+        for k, v in kw.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        return cfg
+
+    out = {'state_dict': {}}
+    for name in ('dense_r1', 'dense_r4', 'dense_r7'):
+        m = ref_model.Model(cfg_of(f'config/convolutional/lossy_coord_v3/{name}.yaml'))
+        out['state_dict'][name] = {'num_latents': list(m.cfg.num_latents), 'lossl_geo_upsample': list(m.cfg.lossl_geo_upsample),
+                                   'max_stride': m.cfg.max_stride, 'channels': m.cfg.channels,
+                                   'keys': [[k, list(v.shape)] for k, v in m.state_dict().items()]}
+    m.eval()
+    out['side_info'] = {'cdf1_head': m.fea_side_info_cdf1[0, :4].tolist(), 'cdf1_tail': m.fea_side_info_cdf1[0, -3:].tolist(),
+                        'cdf1_len': int(m.fea_side_info_cdf1.shape[1]), 'cdf2': m.fea_side_info_cdf2[0].tolist(),
+                        'bin2oct_kernel': m.bin2oct_kernel.tolist(), 'unfold_kernel': m.unfold_kernel[0].tolist()}
+    g = torch.Generator().manual_seed(11)
+    hist = torch.tensor([5, 0, 0, 17, 1, 1, 250, 3], dtype=torch.float32)
+    logits = torch.randn((3, 255), generator=g) * 3
+    out['quantize_pmf'] = {'hist': hist.tolist(), 'hist_cdf': ref_model.Model.batch_quantize_pmf_torch((hist / hist.sum())[None], False)[0].tolist(),
+                           'logits': logits.tolist(), 'logits_cdf': ref_model.Model.batch_quantize_pmf_torch(logits.clone()).tolist()}
+    x = torch.tensor([-25.0, -20.0, -3.5, 0.0, 19.9, 20.0, 31.0], requires_grad=True)
+    y = ref_model.BoundFunction.apply(x, torch.tensor(20.0))
+    y.backward(torch.tensor([0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5]))
+    out['bound'] = {'x': x.detach().tolist(), 'y': y.detach().tolist(), 'grad': x.grad.tolist()}
+
+    probe_a = torch.randn((257, 40), generator=g)
+    probe_b = torch.randn((40, 24), generator=g)
+    out['float_probe'] = {'seed': 11, 'mm_sha256': hashlib.sha256(torch.mm(probe_a, probe_b).numpy().tobytes()).hexdigest(),
+                          'softmax_sha256': hashlib.sha256(torch.softmax(logits, -1).numpy().tobytes()).hexdigest()}
+
+    runs = []
+    for label, kw, seed, res, pts in (
+            ('r1_like', dict(channels=8, max_stride=32, num_latents=(0, 0, 2, 1), lossl_geo_upsample=(0, 1, 1, 1)), 1, 32, 700),
+            ('r4_like', dict(channels=8, max_stride=64, num_latents=(0, 0, 2, 2, 0), lossl_geo_upsample=(0, 0, 1, 1, 1)), 2, 64, 1500),
+            ('lossless', dict(channels=16, max_stride=32, num_latents=(0, 1, 2), lossl_geo_upsample=(1, 1, 1)), 3, 32, 600)):
+        cfg = cfg_of(**kw)
+        model = ref_model.Model(cfg)
+        randomize_(model, seed)
+        model.eval()
+        xyz = surface_cloud(seed + 20, res, pts) + np.array([3, 0, 6], dtype=np.int32)
+        perm = np.random.default_rng(seed).permutation(len(xyz))
+        grabbed = {}
+        enc_oct, enc_fea = model.rans_encode_oct, model.rans_encode_fea
+        model.rans_encode_oct = lambda cdfs, vals: (grabbed.setdefault('symbols', []).append(vals.numpy().astype(int).tolist()),
+                                                    grabbed.setdefault('cdf_sha', []).append(hashlib.sha256(cdfs.numpy().tobytes()).hexdigest()),
+                                                    enc_oct(cdfs, vals))[-1]
+        model.rans_encode_fea = lambda cdf, vals, lo=None: (grabbed.setdefault('fea', []).append(
+            {'cdf': cdf.numpy().astype(int).tolist(), 'values': vals.numpy().astype(int).tolist(),
+             'lo': None if lo is None else int(lo.item())}), enc_fea(cdf, vals, lo))[-1]
+        with torch.no_grad():
+            data = model.compress(torch.from_numpy(batched(xyz)[perm]))
+            rec = model.decompress(data)
+        runs.append({'label': label, 'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                     'seed': seed, 'xyz': xyz[perm].tolist(),
+                     'param_abs_sum': float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)),
+                     'stream_hex': data.hex(), 'oct_symbols_in_coding_order': grabbed.get('symbols', []),
+                     'oct_cdf_sha256_in_coding_order': grabbed.get('cdf_sha', []),
+                     'fea_in_coding_order': grabbed['fea'], 'recon': rec.tolist()})
+        print('codec_v3', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
+    out['runs'] = runs
+    return out
+
+
 def main():
-    for name, fn in (('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()
