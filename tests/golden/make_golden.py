@@ -20,6 +20,8 @@ Sources of truth used:
   hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
   codec_v3.json  the reference's lossy_coord_v3 model executed on the CPU over a functional torchsparse stand-in (kernel-offset
                  enumeration restated, everything else the reference's code and coder): streams, side information, reconstructions
+  codec_int.json the reference's integer LiDAR codec (cuda_ops.py + lossl_coord_int/model.py) executed on the CPU over a stand-in for
+                 its CUDA extension (oracle/int_ops.c scalar functions, torch integer GEMMs): streams of seeded runs
   explut.json    sha256 + samples of the 6145-entry table in /root/reference/lib/int_sparse_conv/src/softmax.cu:18-20
 """
 import hashlib
@@ -855,8 +857,117 @@ def make_codec_v3():
     return out
 
 
+def _functional_int_ext():
+    """Stand-in for the reference's CUDA extension `int_sparse_conv_ext` (CUTLASS int8 GEMMs, hash table, fixed-point
+    element-wise kernels, LUT softmax), evaluated on the CPU: integer GEMMs are torch integer matmuls, the hash lookup is a
+    sorted search with the extension's own offset enumeration (hashmap_cuda.cuh:239-258) and the element-wise operators are
+    oracle/int_ops.c -- the restatement of the scalar device functions of src/element_wise/*.cu and softmax.cu that the
+    oracle itself uses.  So a run over this stand-in does not check that arithmetic again; what it contributes is everything
+    ABOVE it, executed from the reference: lib/int_sparse_conv/cuda_ops.py (which operator gets which multiplier, shift,
+    zero point and bias, the kernel-map construction, the residual block) and models/convolutional/lossl_coord_int/model.py
+    (traversal, multi-step prediction, caches, CDF construction, coding order, header)."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import codec_int as oi
+    ext = types.ModuleType('int_sparse_conv_ext')
+    tables = {}
+
+    def ep(x, bias, slope, mul, zp, shift, bits):
+        out = oi.epilogue(x.numpy(), None if bias is None else bias.numpy(), None if slope is None else slope.numpy(),
+                          oi._np(mul), int(zp.item()), int(shift), bits)
+        return torch.from_numpy(out).to({8: torch.int8, 16: torch.int16, 32: torch.int32}[bits])
+
+    for bits in (8, 16, 32):
+        setattr(ext, f'requant_to_int{bits}', lambda x, mul, zp, sh, b=bits: ep(x, None, None, mul, zp, sh, b))
+        setattr(ext, f'bias_requant_to_int{bits}', lambda x, bias, mul, zp, sh, b=bits: ep(x, bias, None, mul, zp, sh, b))
+        setattr(ext, f'prelu_requant_to_int{bits}', lambda x, slope, mul, zp, sh, b=bits: ep(x, None, slope, mul, zp, sh, b))
+        setattr(ext, f'bias_prelu_requant_to_int{bits}', lambda x, bias, slope, mul, zp, sh, b=bits: ep(x, bias, slope, mul, zp, sh, b))
+    ext.prelu = lambda x, slope: torch.from_numpy(oi.prelu_i32(x.numpy(), int(slope.item())))
+    ext.softmax_int32 = lambda x: torch.from_numpy(oi.softmax_i32(x.numpy()))
+
+    def gemm(a, b, c, d):
+        d.copy_(a.to(torch.int32) @ b.to(torch.int32).t() + c)
+
+    def gather_gemm_scatter(a, b, c, d, in_map, out_map):
+        rows = out_map.long()
+        d[rows] = a[in_map.long()].to(torch.int32) @ b.to(torch.int32).t() + c[rows]
+
+    ext.cutlass_gemm_int8, ext.cutlass_gather_gemm_scatter_int8 = gemm, gather_gemm_scatter
+
+    class GPUHashTable:
+        def __init__(self, keys, vals):
+            self.tag = keys.data_ptr()
+
+        def insert_coords(self, xyzb):
+            tables[self.tag] = xyzb[:, [3, 0, 1, 2]].numpy().astype(np.int64)
+
+        def lookup_coords(self, xyzb, ks, st, volume):
+            t = oi.kernel_table(tables[self.tag], xyzb[:, [3, 0, 1, 2]].numpy().astype(np.int64), tuple(ks.tolist()), tuple(st.tolist()))
+            assert t.shape[0] == volume
+            return torch.from_numpy((t + 1).T.astype(np.int32).copy())
+
+    ext.GPUHashTable = GPUHashTable
+    return ext
+
+
+def make_codec_int():
+    """The reference's integer LiDAR codec (models/convolutional/lossl_coord_int + lib/int_sparse_conv/cuda_ops.py) EXECUTED on
+    the CPU over the stand-in extension above and the reference's own rANS coder: whole compress / decompress runs with
+    seeded parameters on small sweeps.  Integer arithmetic throughout, so the streams are reproducible on any machine."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    _functional_torchsparse()
+    ext = _functional_int_ext()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from lib.int_sparse_conv import cuda_ops
+        from models.convolutional.lossl_coord_int import model as ref_model
+        from models.convolutional.lossl_coord_int.model_config import Config
+    finally:
+        ce.load = real
+    cuda_ops.int_sparse_conv_ext = ext
+    torch.cuda.synchronize = lambda *a, **k: None
+    from fastpcc_amd.codecs.lossl_coord_int import Config as MyConfig, Model as MyModel
+    from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+    from fastpcc_amd.synthetic import batched, lidar_cloud
+    runs = []
+    for label, kw, seed, beams, az in (('c16', dict(channels=16), 1, 8, 128),
+                                       ('c16_skip1', dict(channels=16, skip_top_scales_num=1), 2, 6, 160),
+                                       ('c16_more_ch', dict(channels=16, use_more_ch_for_multi_step_pred=True), 3, 8, 96),
+                                       ('c32_fea8', dict(channels=32, fea_stride=8, max_stride_wo_recurrent=512, max_stride=4096), 4, 8, 128)):
+        mine = MyModel(MyConfig(**kw), 'cpu')
+        randomize_(mine, seed)
+        cfg = Config()
+        for k, v in kw.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        model = ref_model.Model(cfg, torch.device('cpu'))
+        missing = model.load_state_dict(mine.state_dict(), strict=True)
+        model.eval()
+        xyz = lidar_cloud(seed + 30, beams=beams, azimuths=az) + np.array([5, 0, 9], dtype=np.int32)
+        perm = np.random.default_rng(seed).permutation(len(xyz))
+        with torch.no_grad():
+            data = model.compress(torch.from_numpy(batched(xyz)[perm]))
+            rec = model.decompress(data)
+        assert sorted(map(tuple, rec.tolist())) == sorted(map(tuple, xyz.tolist())), 'the reference run is not lossless'
+        runs.append({'label': label, 'config': kw, 'seed': seed, 'xyz': xyz[perm].tolist(), 'stream_hex': data.hex(),
+                     'recon_sha256': hashlib.sha256(np.ascontiguousarray(rec.numpy().astype(np.int32)).tobytes()).hexdigest(),
+                     'state_dict_keys': [[k, list(v.shape)] for k, v in model.state_dict().items()]})
+        print('codec_int', label, len(xyz), 'points ->', len(data), 'bytes')
+    return {'runs': runs}
+
+
 def main():
-    for name, fn in (('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

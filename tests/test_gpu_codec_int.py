@@ -60,3 +60,27 @@ def test_test_forward_and_partitions():
     halves = dev[dev[:, 1] < int(xyz[:, 0].mean())].contiguous(), dev[dev[:, 1] >= int(xyz[:, 0].mean())].contiguous()
     rec = model.decompress_partitions(model.compress_partitions([dev, *halves])).cpu().numpy()
     assert sorted(map(tuple, rec.tolist())) == sorted(map(tuple, xyz.tolist()))
+
+
+def _golden_runs():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_int.json')) as f:
+        return json.load(f)['runs']
+
+
+@pytest.mark.parametrize('run', _golden_runs(), ids=[r['label'] for r in _golden_runs()])
+def test_stream_identical_to_the_reference_run(run):
+    """tests/golden/codec_int.json holds streams written by the reference's own model code and coder (make_golden.py): the
+    HIP path must write the same bytes and decode them to the same points"""
+    import hashlib
+    from fastpcc_amd.codecs.lossl_coord_int import Config, Model
+    from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+    model = Model(Config(**run['config']), 'cuda')
+    randomize_(model, run['seed'])
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    dev = torch.from_numpy(batched(xyz)).cuda()
+    want = bytes.fromhex(run['stream_hex'])
+    assert model.compress(dev) == want
+    rec = model.decompress(want).cpu().numpy().astype(np.int32)
+    assert hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest() == run['recon_sha256']

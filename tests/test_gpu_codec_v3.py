@@ -131,3 +131,41 @@ def test_rejects_what_the_format_cannot_carry():
     model = Model(Config(channels=32, num_latents=(0, 1, 0), lossl_geo_upsample=(0, 0, 1), max_stride=32)).cuda().eval()
     with pytest.raises(NotImplementedError):                                # latents on a lossy level: not decodable
         model.compress(torch.from_numpy(batched(surface_cloud(1, 32, 1500))).cuda())
+
+
+def _golden_runs():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v3.json')) as f:
+        return json.load(f)['runs']
+
+
+@pytest.mark.parametrize('run', _golden_runs(), ids=[r['label'] for r in _golden_runs()])
+def test_against_the_reference_run(run):
+    """tests/golden/codec_v3.json: the reference's model code and coder executed by make_golden.py.  The symbols, the
+    header and the order of coding must be the reference's; latents and stream length agree up to fp32 rounding (the
+    reference run summed its convolutions in torch's CPU order)."""
+    from fastpcc_amd.codecs.lossy_coord_v3 import Config, Model
+    from fastpcc_amd.codecs.lossy_coord_v3.init_random import randomize_
+    cfg = Config(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    model = Model(cfg)
+    randomize_(model, run['seed'])
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    model.trace = {}
+    data = model.compress(torch.from_numpy(batched(xyz)).cuda())
+    want = bytes.fromhex(run['stream_hex'])
+    n_lossy = next((i for i, v in enumerate(cfg.lossl_geo_upsample) if v), len(cfg.lossl_geo_upsample))
+    assert data[:8 + 3 * n_lossy] == want[:8 + 3 * n_lossy]
+    levels = sorted((int(k[7:]) for k in model.trace if k.startswith('symbols')))        # finest level is coded first
+    assert [model.trace[f'symbols{l}'].cpu().numpy().astype(int).tolist() for l in levels] == run['oct_symbols_in_coding_order']
+    ref_latents = [np.array(f['values']) - f['lo'] for f in run['fea_in_coding_order'] if f['lo'] is not None]
+    mine = [model.trace[f'latent{l}.{j}'].cpu().numpy().reshape(-1) for l in levels
+            for j in reversed(range(sum(1 for k in model.trace if k.startswith(f'latent{l}.'))))]
+    assert len(mine) == len(ref_latents)
+    for a, b in zip(mine, ref_latents):
+        assert a.shape == b.shape and np.mean(a != b) < 0.03
+    assert abs(len(data) - len(want)) <= 0.03 * len(want) + 4
+    rec = model.decompress(data).cpu().numpy()
+    assert abs(len(rec) - len(run['recon'])) <= 0.05 * len(run['recon'])
+    if n_lossy == 0:
+        assert _rows(rec) == _rows(run['recon'])
