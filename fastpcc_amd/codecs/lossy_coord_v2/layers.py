@@ -138,9 +138,10 @@ class Decoder(nn.Module):
     def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns xyz int32 [N, 3] (plus coord_offset, a device int32[3], when given)."""
         last = len(self.upsample_blocks) - 1
+        top = fea.coordinate_manager._map(fea.coordinate_map_key)      # local maxima are taken inside the voxels of this level
         for i, (up, classify) in enumerate(zip(self.upsample_blocks, self.classify_blocks)):
             fea = up(fea)
-            keep = self.get_keep(classify(fea), points_num_list)
+            keep = self.get_keep(classify(fea), points_num_list, top)
             if i != last:
                 fea = self.pruning(fea, keep)
             else:
@@ -152,23 +153,43 @@ class Decoder(nn.Module):
                 return xyz[:int(count.item())]
 
     @torch.no_grad()
-    def get_keep(self, pred: ME.SparseTensor, points_num_list: Optional[List[List[int]]]) -> torch.Tensor:
-        """uint8 [n]: logit above the adaptive threshold, or the maximum of its 2x2x2 cell (layers.py:151-180)."""
+    def get_keep(self, pred: ME.SparseTensor, points_num_list: Optional[List[List[int]]], top=None) -> torch.Tensor:
+        """uint8 [n]: logit above the adaptive threshold, or the maximum of its cell (layers.py:151-180).  A cell is a voxel
+        of the decoder's INPUT level (`top`, tensor stride 2^stages: max_stride_lossy_recon in the reference) -- the 8
+        siblings in the first stage, 64 candidates in the second, 512 in the third."""
         cm = pred.coordinate_manager
         gen = cm._map(pred.coordinate_map_key)
         if not gen.generated:
             raise NotImplementedError('get_keep expects the candidates of a generative upsampling')
         logits = pred.F.view(-1)
+        parent = gen.parent
+        cell = None
+        if top is not None and parent is not top:
+            # follow the parent links of the candidates' parents up to the decoder's input level
+            cell, m = parent.parent_of, parent.parent
+            while m is not top:
+                if m is None or m.parent_of is None:
+                    raise RuntimeError('candidate set is not below the decoder input level')
+                cell, m = m.parent_of[cell.long()], m.parent
+            cell = cell.to(torch.int32).contiguous()
         if points_num_list is None:
-            # adaptive_pruning = False (layers.py:176-180): fixed threshold 0, plus the maximum of every 2x2x2 cell
+            # adaptive_pruning = False (layers.py:176-180): fixed threshold 0, plus the maximum of every cell
+            if cell is None:
+                cells = pred.F.view(-1, 8)
+                return ((cells > 0) | (cells == cells.max(1, keepdim=True).values)).view(-1).to(torch.uint8)
+            per_group = pred.F.view(-1, 8).max(1).values
+            cell_max = torch.full((top.n,), float('-inf'), dtype=per_group.dtype, device=per_group.device)
+            cell_max.scatter_reduce_(0, cell.long(), per_group, reduce='amax', include_self=True)
             cells = pred.F.view(-1, 8)
-            return ((cells > 0) | (cells == cells.max(1, keepdim=True).values)).view(-1).to(torch.uint8)
+            return ((cells > 0) | (cells == cell_max[cell.long()][:, None])).view(-1).to(torch.uint8)
         target = points_num_list.pop()
         if len(target) != 1:
             raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')
         if not logits.numel() > target[0]:
             raise ValueError('fewer candidates than points to keep')
-        return ops.topk_keep(logits, target[0])
+        if cell is None:
+            return ops.topk_keep(logits, target[0])
+        return ops.topk_keep_cells(logits, cell, top.n, target[0])
 
 
 class HyperDecoderUpsample(nn.Module):

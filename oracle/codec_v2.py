@@ -340,7 +340,8 @@ class OracleV2:
 
     # ---- lossy decoder -------------------------------------------------------------------------------------------
     def get_keep(self, pred: Feature, parent: oc.Level, target: int) -> np.ndarray:
-        """layers.py:151-180 for one sample: max-pool(2,2) onto the parent cells, un-pool, k-th value threshold."""
+        """layers.py:151-180 for one sample: max-pool onto the cells of `parent` -- the decoder's input level, tensor
+        stride 2^stages (max_stride_lossy_recon) --, un-pool, k-th value threshold."""
         v = pred.f.reshape(-1).numpy()
         q = pred.level.coords.copy()
         q[:, 1:] = q[:, 1:] // parent.stride * parent.stride
@@ -356,13 +357,13 @@ class OracleV2:
 
     def decoder(self, fea: Feature, points_num_list: List[List[int]]) -> np.ndarray:
         n_stage = len(self.cfg.decoder_channels)
+        parent = fea.level                      # every stage takes its local maxima inside the voxels of this level
         for i in range(n_stage):
             up = f'decoder.upsample_blocks.{i}'
             j = 0
             if i == n_stage - 1:
                 fea = self.conv_block(f'{up}.{j}', fea, 'k3')
                 j += 1
-            parent = fea.level
             fea = self.conv_block(f'{up}.{j}', fea, 'gen')
             j += 1
             if i != n_stage - 1:

@@ -288,3 +288,35 @@ def test_fixed_threshold_pruning(setup):
     parents_out = {tuple(p) for p in (rec >> 1).tolist()}
     assert parents_out == parents_in                      # the lossless part is exact; each of its cells keeps its maximum
     assert len(np.unique(rec, axis=0)) == len(rec)
+
+
+@pytest.mark.parametrize('enc,dec', [((16, 32, 32), (32, 16)), ((16, 32, 32, 32), (32, 32, 16))])
+def test_deeper_lossy_part_keeps_local_maxima_of_the_decoder_input_cells(enc, dec):
+    """baseline_r3 / baseline_r5 shapes (config/convolutional/lossy_coord_v2/baseline_r3.yaml:5-6, baseline_r5.yaml:5-6): with
+    two and three upsampling stages the local maxima of Decoder.get_keep are taken inside the voxels of the decoder's INPUT
+    level (layers.py:153-161, max_stride_lossy_recon = 2^stages), i.e. among 64 / 512 candidates, not among the 8 siblings"""
+    import dataclasses
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+    cfg = dataclasses.replace(baseline_r1(), encoder_channels=enc, decoder_channels=dec,
+                              geo_lossl_if_sample=(0, 1, 0, 1, 0, 1), geo_lossl_channels=(enc[-1], 32, 32, 32, 32, 32, 1),
+                              compressed_channels=(1,) * 7)
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, 3)
+    weights = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    model = model.cuda().eval()
+    xyz, coords = _cloud(5, 128, 30000, (1, 4, 0))
+    data = model.compress(torch.from_numpy(coords).to(torch.int32).cuda())
+    rec = model.decompress(data).cpu().numpy()
+    assert rec.shape == (len(xyz), 3) and len(np.unique(rec, axis=0)) == len(rec)
+    o = OracleV2(weights, cfg, conv='chain', order_fn=ME_order)
+    want = o.compress(coords)
+    assert data[:6 + 3 * (len(enc) - 1)] == want[:6 + 3 * (len(enc) - 1)]
+    rec_o = o.decompress(want)
+    assert rec_o.shape == rec.shape
+    same = len({tuple(r) for r in rec.tolist()} & {tuple(r) for r in rec_o.tolist()})
+    assert same >= 0.995 * len(rec)            # identical up to threshold ties that fp32 exp rounding of the logits may flip
+    pts = coords[:, 1:]                          # the cloud as coded (shifted); cells are aligned to its minimum corner
+    lo, stages = pts.min(0), len(dec)
+    assert {tuple(p) for p in ((rec - lo) >> stages).tolist()} == {tuple(p) for p in ((pts - lo) >> stages).tolist()}
