@@ -155,10 +155,18 @@ class OracleV2:
         return src._coarser
 
     def mlp_block(self, prefix: str, x: Feature, x2: Optional[Feature] = None, clip: float = 0.0) -> Feature:
-        w = self.P[prefix + '.mlp.linear.weight'].t().contiguous()      # [in, out]
+        weight = self.P[prefix + '.mlp.linear.weight']                    # [out, in]
         b = self.P.get(prefix + '.mlp.linear.bias')
         act, slope = self._slope(prefix + '.act.module.weight')
         n = x.level.n
+        if self.conv == 'mm':
+            # MinkowskiLinear is torch's linear on the feature matrix (lib/minkowski_sparse_conv_layers.py:38,43)
+            f = x.f if x2 is None else torch.cat((x.f, x2.f), 1)
+            out = sc._act(torch.nn.functional.linear(f, weight, b), act, slope, clip)
+            if self.keep_trace:
+                self.trace[prefix] = out.numpy().copy()
+            return Feature(out, x.level)
+        w = weight.t().contiguous()                                       # [in, out]
         kmap = [(np.arange(n), np.arange(n))]
         out = self._apply(prefix, 'mlp', x.f, None if x2 is None else x2.f, kmap, n, w.reshape(1, *w.shape), b, act, slope, clip)
         return Feature(out, x.level)
@@ -339,7 +347,7 @@ class OracleV2:
         return lower
 
     # ---- lossy decoder -------------------------------------------------------------------------------------------
-    def get_keep(self, pred: Feature, parent: oc.Level, target: int) -> np.ndarray:
+    def get_keep(self, pred: Feature, parent: oc.Level, target: Optional[int]) -> np.ndarray:
         """layers.py:151-180 for one sample: max-pool onto the cells of `parent` -- the decoder's input level, tensor
         stride 2^stages (max_stride_lossy_recon) --, un-pool, k-th value threshold."""
         v = pred.f.reshape(-1).numpy()
@@ -349,6 +357,8 @@ class OracleV2:
         cell_max = np.full(parent.n, -np.inf, dtype=np.float32)
         np.maximum.at(cell_max, cell, v)
         not_max = (v - cell_max[cell]) != 0
+        if target is None:                       # adaptive_pruning = False: fixed threshold 0 (layers.py:176-180)
+            return (v > 0) | ~not_max
         ranked = np.sort(v[not_max])
         kth = v.shape[0] - target
         assert v.shape[0] > target and 1 <= kth <= ranked.shape[0]
@@ -370,7 +380,7 @@ class OracleV2:
                 fea = self.conv_block(f'{up}.{j}', fea, 'k3')
             pred = self.conv_block(f'decoder.classify_blocks.{i}.0', fea, 'k1')
             pred = self.conv_block(f'decoder.classify_blocks.{i}.1', pred, 'k1')
-            keep = self.get_keep(pred, parent, points_num_list.pop()[0])
+            keep = self.get_keep(pred, parent, None if points_num_list is None else points_num_list.pop()[0])
             if i != n_stage - 1:
                 lvl = oc.Level(fea.level.coords[keep], fea.level.stride)
                 fea = Feature(fea.f[torch.from_numpy(keep)], lvl)

@@ -18,6 +18,8 @@ Sources of truth used:
   me_semantics.json  the reference's own statements about MinkowskiEngine / torchsparse conventions: child tables, identity
                  kernels of the fold convolutions, state_dict key / shape lists of its models built on a parameter-only stub engine
   hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
+  codec_v2.json  the reference's lossy_coord_v2 codec (layers / model / geo_lossl_em / ME wrapper layers + its rANS coders) executed on
+                 the CPU over a functional MinkowskiEngine stand-in built on oracle/coords.py + conv_mm: streams, reconstructions
   codec_v3.json  the reference's lossy_coord_v3 model executed on the CPU over a functional torchsparse stand-in (kernel-offset
                  enumeration restated, everything else the reference's code and coder): streams, side information, reconstructions
   codec_int.json the reference's integer LiDAR codec (cuda_ops.py + lossl_coord_int/model.py) executed on the CPU over a stand-in for
@@ -966,8 +968,298 @@ def make_codec_int():
     return {'runs': runs}
 
 
+def _functional_minkowski():
+    """A MinkowskiEngine stand-in that EVALUATES on the CPU: the API surface the reference's lossy_coord_v2 test path touches
+    (SparseTensor, CoordinateManager / CoordinateMapKey, the three convolutions, linear, activations, pruning, max pooling and
+    its transpose, cat) on top of oracle/coords.py (coordinate maps in Morton order, kernel offsets x fastest, strided /
+    generated / transposed maps) and oracle/sparse_conv.py:conv_mm (gather -> torch.mm -> index_add_ per kernel offset).
+    Those two files ARE the restatement of MinkowskiEngine's conventions and stay unpinned -- the
+    engine cannot be installed.  What a run over this stand-in pins is everything above the engine, executed from the
+    reference: lib/minkowski_sparse_conv_layers.py, lossy_coord_v2/{layers,model}.py, lossy_coord_lossy_color/geo_lossl_em.py
+    and the rANS coders (which level is predicted from which, what is coded in which order with which side information,
+    the framing, the adaptive pruning rule).  New coordinate maps get the empty string id (a '#n' suffix when taken),
+    pruned maps 'pruned': the reference's own lookups (layers.py:155-157, geo_lossl_em.py:272) rely on exactly that."""
+    import enum
+    import torch
+    import torch.nn as nn
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import coords as oc
+    from oracle import sparse_conv as sc
+    ME = types.ModuleType('MinkowskiEngine')
+    state = {'cm': None}
+    as3 = lambda v: (int(v),) * 3 if isinstance(v, int) else tuple(int(i) for i in v)
+
+    class CoordinateMapKey:
+        def __init__(self, tensor_stride, string_id=''):
+            self._stride, self._id = as3(tensor_stride), string_id
+
+        def get_tensor_stride(self):
+            return list(self._stride)
+
+        def get_key(self):
+            return list(self._stride), self._id
+
+        def __eq__(self, other):
+            return isinstance(other, CoordinateMapKey) and (self._stride, self._id) == (other._stride, other._id)
+
+        def __hash__(self):
+            return hash((self._stride, self._id))
+
+        def __repr__(self):
+            return f'CoordinateMapKey({list(self._stride)}, {self._id!r})'
+
+    class CoordinateManager:
+        def __init__(self, D=3, coordinate_map_type=None, minkowski_algorithm=None, **_):
+            self.levels, self._manager, self._cache = {}, self, {}
+
+        def register(self, level, string_id=''):
+            key, n = CoordinateMapKey((level.stride,) * 3, string_id), 0
+            while key in self.levels and self.levels[key] is not level:
+                n += 1
+                key = CoordinateMapKey((level.stride,) * 3, f'{string_id}#{n}')
+            self.levels[key] = level
+            return key
+
+        def derived(self, key, what):
+            """the strided / generated map of `key`, made once"""
+            if (key, what) not in self._cache:
+                fn = {'strided': oc.strided, 'generated': oc.generated}[what]
+                self._cache[(key, what)] = self.register(fn(self.levels[key]), '')
+            return self._cache[(key, what)]
+
+        def kmap(self, kind, src_key, dst_key):
+            tag = (kind, src_key, dst_key)
+            if tag not in self._cache:
+                src, dst = self.levels[src_key], self.levels[dst_key]
+                self._cache[tag] = oc.transposed_map(src, dst) if kind == 'T' else oc.kernel_map(src, dst, kind)
+            return self._cache[tag]
+
+        def get_coordinate_map_keys(self, tensor_stride):
+            return [k for k in self.levels if k._stride == as3(tensor_stride)]
+
+        def insert_and_map(self, coordinates, tensor_stride=1, string_id=''):
+            level = oc.Level(coordinates.cpu().numpy(), as3(tensor_stride)[0])
+            return self.register(level, string_id), (torch.from_numpy(level.order.copy()), None)
+
+        def kernel_map(self, in_key, out_key, stride=1, kernel_size=1, **_):
+            assert kernel_size == 1
+            src, dst = self.levels[in_key], self.levels[out_key]
+            rows = dst.rows_of(src.coords)
+            hit = np.nonzero(rows >= 0)[0]
+            return {0: torch.from_numpy(np.stack((hit, rows[hit]))).to(torch.int32)} if len(hit) else {}
+
+        def stride(self, key, stride):
+            for _ in range(as3(stride)[0].bit_length() - 1):
+                key = self.derived(key, 'strided')
+            return key
+
+    class SparseTensor:
+        def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_map_key=None, coordinate_manager=None,
+                     quantization_mode=None, **_):
+            cm = coordinate_manager if coordinate_manager is not None else state['cm']
+            if coordinates is not None:
+                coordinate_map_key, (rows, _) = cm.insert_and_map(coordinates, tensor_stride, '')
+                features = features[rows]
+            self.F, self.coordinate_map_key, self.coordinate_manager = features, coordinate_map_key, cm
+
+        level = property(lambda self: self.coordinate_manager.levels[self.coordinate_map_key])
+        C = property(lambda self: torch.from_numpy(self.level.coords).to(torch.int32))
+        tensor_stride = property(lambda self: self.coordinate_map_key.get_tensor_stride())
+        shape = property(lambda self: self.F.shape)
+        device = property(lambda self: self.F.device)
+        dtype = property(lambda self: self.F.dtype)
+
+        @property
+        def decomposition_permutations(self):
+            b = self.level.coords[:, 0]
+            return [torch.from_numpy(np.nonzero(b == i)[0]) for i in range(int(b.max()) + 1 if len(b) else 0)]
+
+        @property
+        def decomposed_coordinates(self):
+            return [self.C[p][:, 1:] for p in self.decomposition_permutations]
+
+    def like(x, f, key=None):
+        return SparseTensor(f, coordinate_map_key=key if key is not None else x.coordinate_map_key,
+                            coordinate_manager=x.coordinate_manager)
+
+    class KernelGenerator:
+        def __init__(self, kernel_size=-1, stride=1, dilation=1, region_type=None, dimension=3, **_):
+            self.kernel_size, self.kernel_stride, self.kernel_dilation = list(as3(kernel_size)), list(as3(stride)), list(as3(dilation))
+            self.kernel_volume, self.region_type, self.dimension = int(np.prod(self.kernel_size)), region_type, dimension
+
+    class _Conv(nn.Module):
+        MODE = 'conv'
+
+        def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                     kernel_generator=None, expand_coordinates=False, dimension=3, **_):
+            super().__init__()
+            kg = kernel_generator or KernelGenerator(kernel_size, stride, dilation, dimension=dimension)
+            assert len(set(kg.kernel_size)) == 1 and len(set(kg.kernel_stride)) == 1 and set(kg.kernel_dilation) == {1}
+            self.kernel_generator, self.in_channels, self.out_channels = kg, in_channels, out_channels
+            shape = (in_channels, out_channels) if kg.kernel_volume == 1 else (kg.kernel_volume, in_channels, out_channels)
+            self.kernel = nn.Parameter(torch.zeros(shape))
+            self.bias = nn.Parameter(torch.zeros(1, out_channels)) if bias else None
+
+        def forward(self, x, coordinates=None):
+            cm, key = x.coordinate_manager, x.coordinate_map_key
+            ks, st = self.kernel_generator.kernel_size[0], self.kernel_generator.kernel_stride[0]
+            n = x.F.shape[0]
+            if self.MODE == 'conv' and (ks, st) == (1, 1):
+                dst_key, kmap = key, [(np.arange(n), np.arange(n))]
+            elif self.MODE == 'conv' and st == 1:
+                dst_key, kmap = key, cm.kmap(ks, key, key)
+            elif self.MODE == 'conv' and (ks, st) == (2, 2):
+                dst_key = cm.derived(key, 'strided')
+                kmap = cm.kmap(2, key, dst_key)
+            elif self.MODE == 'transpose' and (ks, st) == (2, 2):
+                dst_key = coordinates
+                kmap = cm.kmap('T', key, dst_key)
+            elif self.MODE == 'generative' and (ks, st) == (2, 2):
+                dst_key = cm.derived(key, 'generated')
+                kmap = cm.kmap('T', key, dst_key)
+            else:
+                raise NotImplementedError((self.MODE, ks, st))
+            w = self.kernel.reshape(len(kmap), self.in_channels, self.out_channels)
+            out = sc.conv_mm(x.F, kmap, w, None if self.bias is None else self.bias.reshape(-1), cm.levels[dst_key].n)
+            return like(x, out, dst_key)
+
+    ME.MinkowskiConvolution = type('MinkowskiConvolution', (_Conv,), {})
+    ME.MinkowskiConvolutionTranspose = type('MinkowskiConvolutionTranspose', (_Conv,), {'MODE': 'transpose'})
+    ME.MinkowskiGenerativeConvolutionTranspose = type('MinkowskiGenerativeConvolutionTranspose', (_Conv,), {'MODE': 'generative'})
+
+    def wrap(name, attr, cls):
+        def init(self, *a, **k):
+            nn.Module.__init__(self)
+            k.pop('inplace', None) if cls in (nn.PReLU, nn.Sigmoid) else None
+            setattr(self, attr, cls(*a, **k))
+        return type(name, (nn.Module,), {'__init__': init, 'forward': lambda self, x: like(x, getattr(self, attr)(x.F))})
+
+    ME.MinkowskiLinear = wrap('MinkowskiLinear', 'linear', nn.Linear)
+    ME.MinkowskiBatchNorm = wrap('MinkowskiBatchNorm', 'bn', nn.BatchNorm1d)
+    for name, cls in (('MinkowskiReLU', nn.ReLU), ('MinkowskiPReLU', nn.PReLU), ('MinkowskiLeakyReLU', nn.LeakyReLU),
+                      ('MinkowskiSigmoid', nn.Sigmoid)):
+        setattr(ME, name, wrap(name, 'module', cls))
+
+    class MinkowskiPruning(nn.Module):
+        def forward(self, x, mask):
+            src = x.level
+            keep = mask.cpu().numpy().astype(bool)
+            key = x.coordinate_manager.register(oc.Level(src.coords[keep], src.stride), 'pruned')
+            return like(x, x.F[mask], key)
+
+    class _Pool(nn.Module):
+        def __init__(self, kernel_size, stride=1, dilation=1, kernel_generator=None, dimension=3, **_):
+            super().__init__()
+            assert as3(kernel_size) == as3(stride)
+
+    class MinkowskiMaxPooling(_Pool):
+        def forward(self, x, coordinates=None):
+            src, dst = x.level, x.coordinate_manager.levels[coordinates]
+            q = src.coords.copy()
+            q[:, 1:] = q[:, 1:] // dst.stride * dst.stride
+            rows = torch.from_numpy(dst.rows_of(q))
+            out = torch.full((dst.n, x.F.shape[1]), float('-inf'), dtype=x.F.dtype)
+            out.scatter_reduce_(0, rows[:, None].expand(-1, x.F.shape[1]), x.F, reduce='amax', include_self=True)
+            return like(x, out, coordinates)
+
+    class MinkowskiPoolingTranspose(_Pool):
+        def forward(self, x, coordinates):
+            src, dst = x.level, x.coordinate_manager.levels[coordinates]
+            q = dst.coords.copy()
+            q[:, 1:] = q[:, 1:] // src.stride * src.stride
+            return like(x, x.F[torch.from_numpy(src.rows_of(q))], coordinates)
+
+    def cat(*tensors):
+        if len(tensors) == 1 and isinstance(tensors[0], (tuple, list)):
+            tensors = tuple(tensors[0])
+        assert all(t.coordinate_map_key == tensors[0].coordinate_map_key for t in tensors)
+        return like(tensors[0], torch.cat([t.F for t in tensors], 1))
+
+    ME.MinkowskiPruning, ME.MinkowskiMaxPooling, ME.MinkowskiPoolingTranspose, ME.cat = MinkowskiPruning, MinkowskiMaxPooling, MinkowskiPoolingTranspose, cat
+    ME.SparseTensor, ME.CoordinateManager, ME.CoordinateMapKey, ME.KernelGenerator = SparseTensor, CoordinateManager, CoordinateMapKey, KernelGenerator
+    ME.RegionType = enum.Enum('RegionType', 'HYPER_CUBE HYPER_CROSS CUSTOM')
+    ME.MinkowskiAlgorithm = enum.Enum('MinkowskiAlgorithm', 'DEFAULT MEMORY_EFFICIENT SPEED_OPTIMIZED')
+    ME.CoordinateMapType = enum.Enum('CoordinateMapType', 'CPU CUDA')
+    ME.SparseTensorOperationMode = enum.Enum('SparseTensorOperationMode', 'SEPARATE_COORDINATE_MANAGER SHARE_COORDINATE_MANAGER')
+    ME.SparseTensorQuantizationMode = enum.Enum('SparseTensorQuantizationMode',
+                                                'RANDOM_SUBSAMPLE UNWEIGHTED_AVERAGE UNWEIGHTED_SUM NO_QUANTIZATION')
+    ME.set_sparse_tensor_operation_mode = lambda mode: None
+    ME.set_global_coordinate_manager = lambda cm: state.__setitem__('cm', cm)
+    ME.clear_global_coordinate_manager = lambda: state.__setitem__('cm', None)
+    mst = types.ModuleType('MinkowskiEngine.MinkowskiSparseTensor')
+    mst.SparseTensorQuantizationMode, mst.SparseTensor = ME.SparseTensorQuantizationMode, SparseTensor
+    ME.MinkowskiSparseTensor = mst
+    sys.modules['MinkowskiEngine'], sys.modules['MinkowskiEngine.MinkowskiSparseTensor'] = ME, mst
+    return ME
+
+
+def make_codec_v2():
+    """The reference's lossy_coord_v2 codec -- the headline path -- EXECUTED on the CPU over the MinkowskiEngine stand-in
+    above with the reference's own rANS coders (oracle/_ref): whole compress / decompress runs of seeded models on small
+    seeded clouds: streams, reconstructions, per-level point counts."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    _stub_engines()                                  # torchsparse / plyfile / open3d names for the imports below
+    _functional_minkowski()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossy_coord_v2.model import PCC
+        from models.convolutional.lossy_coord_v2.model_config import ModelConfig
+    finally:
+        ce.load = real
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    g = torch.Generator().manual_seed(13)
+    probe = torch.randn((301, 48), generator=g), torch.randn((48, 32), generator=g), torch.randn((32,), generator=g)
+    out = {'float_probe': {'seed': 13, 'mm_sha256': hashlib.sha256(torch.mm(probe[0], probe[1]).numpy().tobytes()).hexdigest(),
+                           'linear_sha256': hashlib.sha256(torch.nn.functional.linear(probe[0], probe[1].t().contiguous(), probe[2]).numpy().tobytes()).hexdigest(),
+                           'sigmoid_sha256': hashlib.sha256(torch.sigmoid(probe[0]).numpy().tobytes()).hexdigest()}}
+    runs = []
+    base = dict(activation='prelu', compressed_channels=(1,), skip_encoding_fea=1, adaptive_pruning=True)
+    for label, kw, seed, res, pts in (
+            ('r1_like', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1, 0, 1),
+                             geo_lossl_channels=(16, 32, 32, 32, 32, 32, 1)), 1, 64, 2500),
+            ('r3_like_two_stages', dict(encoder_channels=(8, 16, 16), decoder_channels=(16, 8), geo_lossl_if_sample=(0, 1, 0, 1),
+                                        geo_lossl_channels=(16, 32, 32, 32, 1)), 2, 64, 3000),
+            ('r5_like_three_stages', dict(encoder_channels=(8, 16, 16, 16), decoder_channels=(16, 16, 8), geo_lossl_if_sample=(0, 1, 0, 1),
+                                          geo_lossl_channels=(16, 16, 16, 16, 1)), 3, 128, 6000),
+            ('fixed_threshold', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1),
+                                     geo_lossl_channels=(16, 16, 16, 16, 1), adaptive_pruning=False), 4, 32, 900),
+            ('all_levels_coded', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(1, 1, 1),
+                                      geo_lossl_channels=(16, 32, 32, 1), skip_encoding_fea=-1), 5, 32, 900)):
+        cfg = ModelConfig()
+        for k, v in {**base, **kw}.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        cfg.check()
+        torch.manual_seed(0)
+        model = PCC(cfg)
+        enliven(model, seed)
+        model.eval()
+        xyz = surface_cloud(seed + 40, res, pts) + np.array([2, 0, 5], dtype=np.int32)
+        perm = np.random.default_rng(seed).permutation(len(xyz))
+        with torch.no_grad():
+            data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
+            rec = model.decompress(data)
+        runs.append({'label': label, 'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in {**base, **kw}.items()},
+                     'seed': seed, 'xyz': xyz[perm].tolist(),
+                     'param_abs_sum': float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)),
+                     'stream_hex': data.hex(), 'recon': rec.tolist()})
+        print('codec_v2', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
+    out['runs'] = runs
+    return out
+
+
 def main():
-    for name, fn in (('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

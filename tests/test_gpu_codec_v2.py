@@ -320,3 +320,35 @@ def test_deeper_lossy_part_keeps_local_maxima_of_the_decoder_input_cells(enc, de
     pts = coords[:, 1:]                          # the cloud as coded (shifted); cells are aligned to its minimum corner
     lo, stages = pts.min(0), len(dec)
     assert {tuple(p) for p in ((rec - lo) >> stages).tolist()} == {tuple(p) for p in ((pts - lo) >> stages).tolist()}
+
+
+def _golden_runs():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2.json')) as f:
+        return json.load(f)['runs']
+
+
+@pytest.mark.parametrize('run', _golden_runs(), ids=[r['label'] for r in _golden_runs()])
+def test_against_the_reference_run(run):
+    """tests/golden/codec_v2.json: the reference's own model code and coders executed by make_golden.py (CPU, torch GEMM
+    summation order).  The HIP path must write the same header (offsets, per-level point counts, bottom level) and a stream
+    of the same length up to fp32-rounding effects, and reconstruct (nearly) the same cloud."""
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import ModelConfig
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    data = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda())
+    want = bytes.fromhex(run['stream_hex'])
+    head = 6 + (3 * (len(cfg.encoder_channels) - 1) if cfg.adaptive_pruning else 0)
+    assert data[:head + 4] == want[:head + 4]
+    assert abs(len(data) - len(want)) <= 0.02 * len(want) + 4
+    rec = model.decompress(data).cpu().numpy()
+    ref = np.array(run['recon'])
+    if cfg.adaptive_pruning:
+        assert len(rec) == len(ref)
+    same = len({tuple(r) for r in rec.tolist()} & {tuple(r) for r in ref.tolist()})
+    assert same >= 0.97 * len(ref)
