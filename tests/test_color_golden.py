@@ -1,0 +1,52 @@
+"""lossy_coord_lossy_color against tests/golden/codec_color.json: the REFERENCE's own model code and coders executed on the
+CPU over the functional MinkowskiEngine stand-in of tests/golden/make_golden.py (see tests/test_v2_golden.py for what that
+pins and what stays restated)."""
+import json
+import os
+from dataclasses import fields
+
+import numpy as np
+import pytest
+import torch
+
+from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import ModelConfig
+from fastpcc_amd.synthetic import enliven
+from oracle.codec_color import OracleColor
+from test_v2_golden import same_float_behaviour
+
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color.json')) as f:
+    RUNS = json.load(f)['runs']
+
+
+def model_of(run):
+    known = {f.name for f in fields(ModelConfig)}
+    assert set(run['config']) <= known, set(run['config']) - known          # the reference's configuration fields exist here
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    return cfg, model
+
+
+@pytest.mark.parametrize('run', RUNS, ids=[r['label'] for r in RUNS])
+def test_reference_run(run):
+    cfg, model = model_of(run)
+    assert float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)) == \
+        pytest.approx(run['param_abs_sum'], rel=1e-12)
+    xyz = np.array(run['xyz'], dtype=np.int64)
+    coords = np.concatenate((np.zeros((len(xyz), 1), np.int64), xyz), 1)
+    color = np.array(run['color'], dtype=np.uint8)
+    want = bytes.fromhex(run['stream_hex'])
+    weights = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    oracle = OracleColor(weights, cfg, conv='mm')
+    data = oracle.compress(coords, color)
+    head = 6 + 3 * (len(cfg.encoder_channels) - 1)
+    assert data[:head + 4] == want[:head + 4]
+    if same_float_behaviour():
+        assert data == want
+        rec_xyz, rec_rgb = oracle.decompress(want)
+        assert rec_xyz.tolist() == run['recon_xyz']
+        assert np.asarray(rec_rgb).astype(int).tolist() == run['recon_rgb']
+    else:
+        assert abs(len(data) - len(want)) <= 0.02 * len(want) + 4

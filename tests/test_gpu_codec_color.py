@@ -52,3 +52,37 @@ def test_color_codec_against_oracle():
         assert (o_rgb == rec_rgb).all()
     else:
         assert abs(len(data) - len(want)) <= max(4, 0.002 * len(want))
+
+
+def _golden_runs():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color.json')) as f:
+        return json.load(f)['runs']
+
+
+@pytest.mark.parametrize('run', _golden_runs(), ids=[r['label'] for r in _golden_runs()])
+def test_against_the_reference_run(run):
+    """tests/golden/codec_color.json: the reference's own model code and coders executed by make_golden.py; the HIP path must
+    write the same header, a stream of the same length up to fp32-rounding effects, and (nearly) the same coloured cloud"""
+    from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+    from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import ModelConfig
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    color = np.array(run['color'], dtype=np.uint8)
+    data = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda(), torch.from_numpy(color).cuda())
+    want = bytes.fromhex(run['stream_hex'])
+    head = 6 + 3 * (len(cfg.encoder_channels) - 1)
+    assert data[:head + 4] == want[:head + 4]
+    assert abs(len(data) - len(want)) <= 0.02 * len(want) + 4
+    rec_xyz, rec_rgb = model.decompress(data)
+    rec_xyz, rec_rgb = rec_xyz.cpu().numpy(), rec_rgb.cpu().numpy()
+    ref = {tuple(p): c for p, c in zip(run['recon_xyz'], run['recon_rgb'])}
+    assert len(rec_xyz) == len(ref)
+    hits = [(tuple(p), c) for p, c in zip(rec_xyz.tolist(), rec_rgb.tolist()) if tuple(p) in ref]
+    assert len(hits) >= 0.97 * len(ref)
+    err = np.array([np.abs(np.array(c) - np.array(ref[p])).max() for p, c in hits])
+    assert np.mean(err <= 1) > 0.97                     # colours of the common points agree up to rounding of the last layer
