@@ -38,6 +38,8 @@ _ON_FEATURES_INT = (PReLUIn32Out32, RequantFxpToScaledInt8, LinearIn8W8Out8, Lin
 
 def linear(x: torch.Tensor, m: nn.Linear) -> torch.Tensor:
     """x @ W^T + b on the convolution kernel (one offset, identity map): a row's result does not depend on the other rows"""
+    if torch.is_grad_enabled() and (m.weight.requires_grad or x.requires_grad):
+        return F.linear(x.float(), m.weight, m.bias)                    # training: a plain library GEMM with autograd
     w = m.weight.detach().t().contiguous().reshape(1, 1, m.in_features, m.out_features)
     return ops.conv_f32(x.float().contiguous(), w, m.out_features, x.shape[0], bias=None if m.bias is None else m.bias.detach())
 

@@ -5,10 +5,13 @@ import torch
 
 def randomize_(model: torch.nn.Module, seed: int, gain: float = 1.0, latent_gain: float = 4.0) -> None:
     g = torch.Generator().manual_seed(seed)
+    g_prior = torch.Generator().manual_seed(seed + 1000)
     u = lambda shape: torch.rand(shape, generator=g) * 2 - 1
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if '.prior_' in name:                              # deep-factorised prior keeps make_parameters' init
+            if '.prior_' in name:                              # deep-factorised prior keeps make_parameters' init; its
+                if '.prior_biases.' in name:                   # biases (random there) come from their own seeded stream
+                    p.copy_((torch.rand(p.shape, generator=g_prior) - 0.5).to(p.device))
                 continue
             if name.endswith('.kernel'):
                 k, c_in = (p.shape[0], p.shape[1]) if p.dim() == 3 else (1, p.shape[0])

@@ -129,6 +129,55 @@ class OneScalePredictor(nn.Module):
         feats = f.reshape(f.shape[0], 8, f.shape[1] // 8)[pairs[:, 0], pairs[:, 1]]
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in cur_rec.stride))
 
+    # -- training path (:90-169) -----------------------------------------------------------------------------------
+    def forward(self, cur_rec: SparseTensor, cur_ref: SparseTensor, up_ref: SparseTensor, cur_bin: torch.Tensor,
+                points_num: List[int], bin2oct_kernel, unfold_kernel, warmup: bool):
+        """-> (features of the next level | None, latent rate terms, geometry loss of this level), all in bits per input
+        point averaged over the batch.  cur_bin [n, 8]: true child occupancy of every voxel of cur_rec (zero rows for
+        voxels a lossy level above kept in excess)."""
+        device = cur_rec.F.device
+        batch_size = len(points_num)
+        batch_of = cur_rec.C[:, 0].long()
+        per_row_points = torch.tensor(points_num, dtype=torch.float32, device=device)[batch_of]
+        cur_rec = self._trunk(cur_rec)
+        fea_losses = []
+        for to_latent_a, to_latent_b, widen, dec, prior in self.transforms:
+            ref = to_latent_a(cur_ref)
+            ref.F = torch.cat((ref.F, cur_rec.F), 1)
+            ref = to_latent_b(ref)
+            noisy, bits = prior(_Bound.apply(ref.F, torch.tensor(LATENT_BOUND, device=device)))
+            fea_losses.append((bits / per_row_points[:, None]).sum() * ((0.01 if warmup else 1.0) / batch_size))
+            ref.F = noisy
+            cur_rec = self._absorb(cur_rec, ref, widen, dec)
+        cur_pred = self.pred(cur_rec).F
+        if self.if_pred_oct_lossl:
+            symbols = _symbols_of(cur_bin, bin2oct_kernel).long()
+            geo_loss = (F.cross_entropy(cur_pred, symbols, reduction='none') / per_row_points).sum() * (log2_e / batch_size)
+            kept, children = cur_bin.bool(), up_ref.C
+        else:
+            # the normaliser of a lossy level is the point count of the level it reconstructs (:124-133)
+            if up_ref.stride[0] == 1:
+                per_row_up, up_points = per_row_points, points_num
+            else:
+                up_points = torch.bincount(up_ref.C[:, 0].long(), minlength=batch_size).tolist()
+                per_row_up = torch.tensor(up_points, dtype=torch.float32, device=device)[batch_of]
+            geo_loss = (F.binary_cross_entropy_with_logits(cur_pred, cur_bin, reduction='none').sum(1) / per_row_up).sum() \
+                * (self.coord_recon_loss_factor * log2_e / batch_size)
+            kept = children = None
+            if self.if_upsample:
+                with torch.no_grad():
+                    edges = torch.searchsorted(cur_rec.C[:, 0].contiguous(),
+                                               torch.arange(batch_size + 1, device=device, dtype=cur_rec.C.dtype)).tolist()
+                    kept = torch.cat([top_children(cur_pred[a:b], n) for a, b, n in zip(edges[:-1], edges[1:], up_points)], 0)
+                    kept |= cur_bin.bool()                                  # the true children always survive in training
+                    children = _children_of(cur_rec.C, unfold_kernel, kept)
+        if not self.if_upsample:
+            return None, fea_losses, geo_loss
+        nxt = self._expand(cur_rec, kept, children)
+        if self.if_pred_oct_lossl:
+            nxt._caches = cur_ref._caches            # same coordinates as the encoder's level: its kernel maps are reused
+        return nxt, fea_losses, geo_loss
+
     # -- test-time paths -------------------------------------------------------------------------------------------
     def compress(self, cur_rec: SparseTensor, cur_ref: SparseTensor, up_ref: SparseTensor, cur_bin: torch.Tensor,
                  bin2oct_kernel, if_upsample):
@@ -223,13 +272,50 @@ class Model(nn.Module):
     # ---------------------------------------------------------------------------------------------------------------
     def forward(self, pc_data: PCData):
         if self.training:
-            return self.train_forward(pc_data.xyz, pc_data.points_num, pc_data.training_step)
+            return self.train_forward(pc_data.xyz, pc_data.points_num, getattr(pc_data, 'training_step', 0))
         if pc_data.batch_size != 1:
             raise ValueError('Only supports batch size == 1 during testing.')
         return self.test_forward(pc_data)
 
-    def train_forward(self, xyz, points_num, training_step):
-        raise NotImplementedError('training of lossy_coord_v3 is not built')
+    def _true_bits_on(self, coarse: SparseTensor, fine: SparseTensor) -> torch.Tensor:
+        """[n, 8] float: which children of every voxel of `coarse` exist in `fine` (the reference re-runs its fold
+        convolution onto substituted output coordinates for this, :437-441)"""
+        from ...int_sparse_conv import _kernel_table
+        with torch.no_grad():
+            _, table = _kernel_table(fine.C, coarse.C, (2, 2, 2), (2, 2, 2), None)
+            return (table[:coarse.C.shape[0]] > 0).to(torch.float32)
+
+    def train_forward(self, xyz: torch.Tensor, points_num: List[int], training_step: int) -> dict:
+        """rate of the lossless levels + latent rates + weighted occupancy cross-entropy of the lossy levels, in bits per
+        input point (:411-455).  xyz int32 [N, 4], per sample Morton ('zyx') sorted and unique, samples in batch order."""
+        warmup = training_step < self.cfg.warmup_steps
+        org = self.get_init_pc(xyz.contiguous(), 1)
+        levels = self.max_downsample_times
+        bins = [org]
+        for _ in range(levels):
+            bins.append(self.get_bin(bins[-1]))
+        strided = [org, bins[1]] if len(self.blocks_enc) else [org]
+        for block in self.blocks_enc[1:]:
+            strided.append(block(strided[-1]))
+        strided += bins[len(strided):]
+        top = strided[-1]
+        cur_rec = SparseTensor(org.F[:top.C.shape[0]], top.C, (2 ** levels,) * 3)
+        cur_rec._caches = org._caches
+        exact = True                                    # cur_rec still sits on the true coordinates of its level
+        losses = {}
+        for idx in range(levels, 0, -1):
+            block = self._block(idx, self.blocks_dec)
+            cur_bin = bins[idx].F if exact else self._true_bits_on(cur_rec, strided[idx - 1])
+            cur_rec, fea_losses, geo_loss = block(cur_rec, strided[idx], strided[idx - 1], cur_bin, points_num,
+                                                  self.bin2oct_kernel, self.unfold_kernel, warmup)
+            exact = exact and block.if_pred_oct_lossl
+            losses[f'stride{2 ** idx}_geo_loss'] = geo_loss
+            for i, v in enumerate(fea_losses):
+                losses[f'stride{2 ** idx}_fea{i}_loss'] = v
+        total = sum(losses.values())
+        out = {k: v.item() for k, v in losses.items()}
+        out['loss'] = total
+        return out
 
     @staticmethod
     def get_init_pc(xyz: torch.Tensor, stride: int = 1) -> SparseTensor:

@@ -192,9 +192,35 @@ class Conv3d(nn.Module):
             out = part if out is None else out.add_(part)
         return out, hashmap_kv, in_out_maps
 
-    @torch.no_grad()
+    def _run_autograd(self, in_feats, in_coords, out_coords, in_out_maps, hashmap_kv, same):
+        """training path: the same lookup table, the convolution as an autograd function of fastpcc_amd/autograd.py (weight
+        and input gradients on the MFMA kernels); 3x3x3 on one coordinate set and 2x2x2 / stride 2 are what the models use"""
+        from .autograd import ConvSpec, sparse_conv
+        if in_out_maps is None:
+            with torch.no_grad():
+                hashmap_kv, in_out_maps = _kernel_table(in_coords, out_coords, self.kernel_size, self.stride, hashmap_kv)
+        n_in, n_out = in_coords.shape[0], out_coords.shape[0]
+        if self.kernel_size == (3, 3, 3) and same:
+            if not hasattr(in_out_maps, '_fpcc_offset_major'):       # [27][n] (row | -1): the layout the gradient kernels walk
+                in_out_maps._fpcc_offset_major = (in_out_maps[:n_out] - 1).t().contiguous()
+            spec = ConvSpec('k3', n_in, n_out, in_out_maps._fpcc_offset_major)
+        elif self.kernel_size == (2, 2, 2) and self.stride == (2, 2, 2):
+            if not hasattr(in_out_maps, '_fpcc_child_row'):
+                in_out_maps._fpcc_child_row = (in_out_maps[:n_out] - 1).contiguous()
+            spec = ConvSpec('k2s2', n_in, n_out, in_out_maps._fpcc_child_row)
+        else:
+            raise NotImplementedError(f'back-propagation through a {self.kernel_size} / stride {self.stride} convolution')
+        w = self.kernel.reshape(self.kernel_volume, self.in_channels, self.out_channels)
+        out = sparse_conv(in_feats.float(), w, spec)
+        if self.bias is not None:
+            out = out + self.bias
+        return out, hashmap_kv, in_out_maps
+
     def forward(self, input: 'SparseTensor') -> 'SparseTensor':
-        return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self._run)
+        if torch.is_grad_enabled() and (self.kernel.requires_grad or input.F.requires_grad):
+            return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self._run_autograd, unique=torch.unique_consecutive)
+        with torch.no_grad():
+            return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, self._run, unique=torch.unique_consecutive)
 
 
 class SparseTensorHistogramObserver(HistogramObserver):

@@ -856,6 +856,40 @@ def make_codec_v3():
                      'fea_in_coding_order': grabbed['fea'], 'recon': rec.tolist()})
         print('codec_v3', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
     out['runs'] = runs
+
+    # training objective (train_forward, :411-455) with the uniform noise of the latents replaced by zeros on both sides
+    # (the reference draws it from the CPU generator, the product from the device's): loss terms per level
+    real_uniform = torch.Tensor.uniform_
+    torch.Tensor.uniform_ = lambda self, *a, **k: self.zero_()
+    train = []
+    try:
+        for label, kw, seed, step in (
+                ('r1_like', dict(channels=8, max_stride=32, num_latents=(0, 0, 2, 1), lossl_geo_upsample=(0, 1, 1, 1),
+                                 coord_recon_loss_factor=2.0, warmup_steps=0), 1, 10),
+                ('r4_like_warmup', dict(channels=8, max_stride=64, num_latents=(0, 0, 2, 2, 0), lossl_geo_upsample=(0, 0, 1, 1, 1),
+                                        coord_recon_loss_factor=0.4, warmup_steps=100), 2, 10),
+                ('r7_like', dict(channels=8, max_stride=64, num_latents=(0, 0, 0, 2, 2), lossl_geo_upsample=(0, 0, 0, 1, 1),
+                                 coord_recon_loss_factor=0.1, warmup_steps=0), 3, 5)):
+            cfg = cfg_of(**kw)
+            model = ref_model.Model(cfg)
+            randomize_(model, seed)
+            model.train()
+            clouds = [surface_cloud(seed + 60, 32 if cfg.max_stride == 32 else 64, 900), surface_cloud(seed + 70, 32 if cfg.max_stride == 32 else 64, 600)]
+            parts = []
+            for b, xyz in enumerate(clouds):
+                xyz = xyz - xyz.min(0)
+                key = sum(((xyz[:, a].astype(np.int64) >> i) & 1) << (3 * i + (2 - a)) for i in range(8) for a in range(3))
+                xyz = xyz[np.argsort(key, kind='stable')]                 # Morton order, z on the lowest bit (x most significant)
+                parts.append(np.concatenate((np.full((len(xyz), 1), b), xyz), 1))
+            batch = torch.from_numpy(np.concatenate(parts, 0).astype(np.int32))
+            res = model.train_forward(batch, [len(p) for p in parts], step)
+            train.append({'label': label, 'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                          'seed': seed, 'training_step': step, 'xyz': batch.tolist(), 'points_num': [len(p) for p in parts],
+                          'loss': float(res['loss']), 'terms': {k: float(v) for k, v in res.items() if k != 'loss'}})
+            print('codec_v3 train', label, float(res['loss']))
+    finally:
+        torch.Tensor.uniform_ = real_uniform
+    out['train'] = train
     return out
 
 
