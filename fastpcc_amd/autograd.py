@@ -22,7 +22,8 @@ from . import hipops as ops
 
 
 class ConvSpec:
-    """row maps of one convolution call.  kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen'"""
+    """row maps of one convolution call.  kind: 'k1' | 'k3' | 'k2s2' | 'k2s2T' | 'gen' | 'tab' (any lookup table
+    [n_out][K] of input rows, -1 absent; weight gradient only -- used where the input carries no gradient)"""
     __slots__ = ('kind', 'n_in', 'n_out', 'table', 'row_order')
 
     def __init__(self, kind: str, n_in: int, n_out: int, table: Optional[torch.Tensor] = None,
@@ -64,7 +65,19 @@ def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
         return ops.conv_f32(x, w, c_out, s.n_in, groups=8, out_map=s.table, om_os=8, om_gs=1, out_rows=s.n_out)
     if s.kind == 'gen':
         return ops.conv_f32(x, w, c_out, s.n_in, groups=8)
+    if s.kind == 'tab':
+        k = s.table.shape[1]
+        out = None
+        for a in range(0, k, _TAB_CHUNK):
+            b = min(a + _TAB_CHUNK, k)
+            part = ops.conv_f32(x, w.reshape(k, c_in, c_out)[a:b].contiguous(), c_out, s.n_out,
+                                nbr=s.table[:, a:b].contiguous(), n_offsets=b - a, nbr_ks=1, nbr_os=b - a)
+            out = part if out is None else out.add_(part)
+        return out
     raise ValueError(s.kind)
+
+
+_TAB_CHUNK = 16       # kernel offsets per launch of the general-table path (a 4x4x4 kernel has 64)
 
 
 def _wide(call, wt: torch.Tensor, width: int, rows: int, device) -> torch.Tensor:
@@ -80,6 +93,8 @@ def _wide(call, wt: torch.Tensor, width: int, rows: int, device) -> torch.Tensor
 
 def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     c_in, c_out = w.shape[-2], w.shape[-1]
+    if s.kind == 'tab':
+        raise NotImplementedError('input gradient through a general lookup-table convolution')
     if s.kind == 'k1':
         return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out),
                      ops.transpose_weights(w, 1, c_in, c_out, flip=False).view(c_out, c_in), c_in, s.n_in, dy.device)
@@ -109,6 +124,11 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, s: ConvSpec
         dw = ops.conv_wgrad(x, dy, s.n_in, groups=8, out_map=s.table, om_os=8, om_gs=1)
     elif s.kind == 'gen':
         dw = ops.conv_wgrad(x, dy, s.n_in, groups=8)
+    elif s.kind == 'tab':
+        k = s.table.shape[1]
+        dw = torch.cat([ops.conv_wgrad(x, dy, s.n_out, nbr=s.table[:, a: a + _TAB_CHUNK].contiguous(),
+                                       n_offsets=min(_TAB_CHUNK, k - a), nbr_ks=1, nbr_os=min(_TAB_CHUNK, k - a))
+                        for a in range(0, k, _TAB_CHUNK)], 1)
     else:
         raise ValueError(s.kind)
     return dw.view(w.shape)

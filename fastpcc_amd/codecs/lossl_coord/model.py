@@ -14,9 +14,10 @@ The traversal (which level is predicted from which, what is appended where) is s
 (`codecs/lossl_coord_int/model.py`): the float predictors are subclasses that swap the operators and the encoding of the
 occupancy bits (1.0 instead of 1 << 23).  Convolutions and linears run on fpcc_conv_f32 over the same lookup tables as the
 integer operators; softmax -> 16-bit CDF is tensor arithmetic as in the reference (:465-472), the CDF rows go to the host
-coder whole (this is the calibration path, not the product path).  Training of this model (`train_forward`, :374-424) is
-not built."""
+coder whole (this is the calibration path, not the product path).  `train_forward` (:394-424) runs the same network pass with
+gradients: convolutions through fastpcc_amd/autograd.py, linears as library GEMMs."""
 import io
+import math
 from typing import List
 
 import numpy as np
@@ -233,6 +234,45 @@ class Model(int_model.Model):
 
     def get_init_pc(self, xyz: torch.Tensor, stride: int = 1) -> SparseTensor:
         return SparseTensor(self._ones(xyz.shape[0], xyz.device), xyz, (stride,) * 3)
+
+    # -- training (model.py:394-424) ---------------------------------------------------------------------------------------
+    def forward(self, pc_data):
+        if self.training:
+            return self.train_forward(pc_data.xyz, pc_data.points_num, getattr(pc_data, 'training_step', 0))
+        return super().forward(pc_data)
+
+    def train_forward(self, xyz: torch.Tensor, points_num: List[int], training_step: int = 0) -> dict:
+        """bits per input point of the 255-ary occupancy symbols of every level under the predicted distributions, averaged
+        over the batch.  xyz int32 [N, 4], per sample Morton ('zyx') sorted and unique, samples in batch order.  The network
+        pass is the encoder's (`compress` of the predictors) with gradients enabled; only the float model trains."""
+        if self.converted:
+            raise RuntimeError('the converted (integer) model does not train')
+        batch_size = len(points_num)
+        ones = self._ones(xyz.shape[0], xyz.device)
+        org = SparseTensor(ones, xyz.contiguous(), (1, 1, 1))
+        levels = self.max_downsample_times
+        strided = [org]
+        for _ in range(levels):
+            strided.append(self.get_bin(strided[-1], ones))
+        top = strided[-1]
+        cur_rec = SparseTensor(ones[:top.C.shape[0]], top.C, (2 ** levels,) * 3)
+        cur_rec._caches = org._caches
+        per_sample = torch.tensor(points_num, dtype=torch.float32, device=xyz.device)
+        losses = {}
+        for idx in range(levels, 0, -1):
+            block = self._block(idx, self.blocks_dec)
+            if isinstance(block, int_model.OneScalePredictor):
+                cur_rec, logits, symbols = block.compress(cur_rec, strided[idx - 1], strided[idx].F, self.bin2oct_kernel,
+                                                          if_upsample=block.if_upsample)
+            else:
+                cur_rec, logits, symbols = block.compress(cur_rec, strided[idx: idx + block.pred_steps], self.bin2oct_kernel)
+            per_row = per_sample[strided[idx].C[:, 0].long()]
+            losses[f'stride{2 ** idx}_geo_loss'] = (F.cross_entropy(logits, symbols.long(), reduction='none') / per_row).sum() \
+                * (math.log2(math.e) / batch_size)
+        total = sum(losses.values())
+        out = {k: v.item() for k, v in losses.items()}
+        out['loss'] = total
+        return out
 
     # -- post-training quantisation (model.py:633-642) -------------------------------------------------------------------
     def pre_test_hook(self):

@@ -209,7 +209,12 @@ class Conv3d(nn.Module):
                 in_out_maps._fpcc_child_row = (in_out_maps[:n_out] - 1).contiguous()
             spec = ConvSpec('k2s2', n_in, n_out, in_out_maps._fpcc_child_row)
         else:
-            raise NotImplementedError(f'back-propagation through a {self.kernel_size} / stride {self.stride} convolution')
+            # any other kernel (the 4x4x4 / stride-4 embedding of occupancy bits): weight gradient only
+            if in_feats.requires_grad:
+                raise NotImplementedError(f'input gradient through a {self.kernel_size} / stride {self.stride} convolution')
+            if not hasattr(in_out_maps, '_fpcc_rows'):
+                in_out_maps._fpcc_rows = (in_out_maps[:n_out] - 1).contiguous()
+            spec = ConvSpec('tab', n_in, n_out, in_out_maps._fpcc_rows)
         w = self.kernel.reshape(self.kernel_volume, self.in_channels, self.out_channels)
         out = sparse_conv(in_feats.float(), w, spec)
         if self.bias is not None:

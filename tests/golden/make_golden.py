@@ -1351,8 +1351,72 @@ def make_codec_color():
     return {'runs': runs}
 
 
+def make_codec_lossl():
+    """The reference's FLOAT LiDAR model (models/convolutional/lossl_coord: the model that is trained, calibrated and converted
+    into lossl_coord_int) EXECUTED on the CPU over the functional torchsparse stand-in: compress / decompress runs and the
+    loss terms of train_forward on a batch of two sweeps."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    _functional_torchsparse()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossl_coord import model as ref_model
+        from models.convolutional.lossl_coord.model_config import Config
+    finally:
+        ce.load = real
+    from fastpcc_amd.codecs.lossy_coord_v3.init_random import randomize_
+    from fastpcc_amd.synthetic import batched, lidar_cloud
+    torch.cuda.synchronize = lambda *a, **k: None
+    out = {'runs': [], 'train': []}
+    for label, kw, seed in (('c8', dict(channels=8), 1), ('c8_more_ch', dict(channels=8, use_more_ch_for_multi_step_pred=True), 2),
+                            ('c16_fea8', dict(channels=16, fea_stride=8, max_stride_wo_recurrent=512, max_stride=4096), 3)):
+        cfg = Config()
+        for k, v in kw.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        model = ref_model.Model(cfg)
+        randomize_(model, seed)
+        keys = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        model.eval()
+        xyz = lidar_cloud(seed + 80, beams=6, azimuths=128) + np.array([4, 0, 7], dtype=np.int32)
+        perm = np.random.default_rng(seed).permutation(len(xyz))
+        with torch.no_grad():
+            data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
+            rec = model.decompress(data)
+        assert sorted(map(tuple, rec.tolist())) == sorted(map(tuple, xyz.tolist())), 'the reference run is not lossless'
+        out['runs'].append({'label': label, 'config': kw, 'seed': seed, 'xyz': xyz[perm].tolist(), 'stream_hex': data.hex(),
+                            'state_dict_keys': keys,
+                            'param_abs_sum': float(sum(p.detach().double().abs().sum() for p in model.parameters()))})
+        print('codec_lossl', label, len(xyz), 'points ->', len(data), 'bytes')
+        # training objective on a batch of two sweeps (per sample Morton-sorted, z on the lowest bit)
+        model.train()
+        parts = []
+        for b, s2 in enumerate((seed + 90, seed + 95)):
+            c = lidar_cloud(s2, beams=5, azimuths=96)
+            c = c - c.min(0)
+            key = sum(((c[:, a].astype(np.int64) >> i) & 1) << (3 * i + (2 - a)) for i in range(17) for a in range(3))
+            c = c[np.argsort(key, kind='stable')]
+            parts.append(np.concatenate((np.full((len(c), 1), b), c), 1))
+        batch = torch.from_numpy(np.concatenate(parts, 0).astype(np.int32))
+        res = model.train_forward(batch, [len(p) for p in parts], 0)
+        out['train'].append({'label': label, 'config': kw, 'seed': seed, 'xyz': batch.tolist(), 'points_num': [len(p) for p in parts],
+                             'loss': float(res['loss']), 'terms': {k: float(v) for k, v in res.items() if k != 'loss'}})
+        print('codec_lossl train', label, float(res['loss']))
+    return out
+
+
 def main():
-    for name, fn in (('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()
