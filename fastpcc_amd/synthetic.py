@@ -114,9 +114,12 @@ def enliven(model: 'torch.nn.Module', seed: int, gain: float = 2.35) -> None:
     U(-1/sqrt(fan), 1/sqrt(fan)) init shrinks them to zero, which would make every parity test trivial)."""
     import torch
     g = torch.Generator().manual_seed(seed)
+    g_prior = torch.Generator().manual_seed(seed + 1000)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if '.prior_' in name:                       # deep-factorised prior: keep make_parameters' init
+            if '.prior_' in name:                       # deep-factorised prior: keep make_parameters' init; its biases
+                if '.prior_biases.' in name:            # (random there) come from their own seeded stream -- training only
+                    p.copy_((torch.rand(p.shape, generator=g_prior) - 0.5).to(p.device))
                 continue
             if name.endswith('module.weight'):          # PReLU slope
                 p.copy_(0.1 + 0.3 * torch.rand(p.shape, generator=g))

@@ -1289,6 +1289,47 @@ def make_codec_v2():
                      'stream_hex': data.hex(), 'recon': rec.tolist()})
         print('codec_v2', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
     out['runs'] = runs
+
+    # training objective (PCC.train_forward, model.py:144-183: rate of the lossless levels under the noisy deep-factorised
+    # bottleneck, occupancy cross-entropies, reconstruction losses of the lossy part, warm-up factors) on batches of clouds,
+    # with the bottleneck's uniform noise replaced by zeros on both sides (CPU generator there, device generator here)
+    real_uniform = torch.Tensor.uniform_
+    torch.Tensor.uniform_ = lambda self, *a, **k: self.zero_()
+    train = []
+    try:
+        for label, kw, seed, step in (
+                ('r1_like', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1, 0, 1),
+                                 geo_lossl_channels=(16, 32, 32, 32, 32, 32, 1), warmup_fea_loss_steps=5000, warmup_fea_loss_factor=0.01,
+                                 bits_loss_factor=0.4), 1, 100),
+                ('r1_like_after_warmup', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1),
+                                              geo_lossl_channels=(16, 32, 32, 32, 1), warmup_fea_loss_steps=50, warmup_fea_loss_factor=0.01,
+                                              bits_loss_factor=0.4), 2, 100),
+                ('linear_warmup_no_adaptive_pruning', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1),
+                                                           geo_lossl_channels=(16, 32, 32, 32, 1), warmup_fea_loss_steps=200,
+                                                           warmup_fea_loss_factor=0.05, linear_warmup=True, adaptive_pruning=False,
+                                                           coord_recon_loss_factor=0.7), 3, 60)):
+            cfg = ModelConfig()
+            for k, v in {**base, **kw}.items():
+                assert hasattr(cfg, k), k
+                setattr(cfg, k, v)
+            cfg.check()
+            torch.manual_seed(0)
+            model = PCC(cfg)
+            enliven(model, seed)
+            model.train()
+            parts = []
+            for b, (s2, n) in enumerate(((seed + 100, 1500), (seed + 110, 1100), (seed + 120, 800))):
+                c = surface_cloud(s2, 64, n)
+                parts.append(np.concatenate((np.full((len(c), 1), b), c), 1))
+            batch = torch.from_numpy(np.concatenate(parts, 0).astype(np.int32))
+            res = model.train_forward(batch, step, len(parts))
+            train.append({'label': label, 'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in {**base, **kw}.items()},
+                          'seed': seed, 'training_step': step, 'batch_size': len(parts), 'xyz': batch.tolist(),
+                          'loss': float(res['loss']), 'terms': {k: float(v) for k, v in res.items() if k != 'loss'}})
+            print('codec_v2 train', label, float(res['loss']))
+    finally:
+        torch.Tensor.uniform_ = real_uniform
+    out['train'] = train
     return out
 
 

@@ -156,3 +156,32 @@ def test_ddp_two_ranks_keep_parameters_identical():
         assert p.exitcode == 0
     assert got[0][1] != got[1][1]                       # different data -> different local losses
     assert (got[0][2] == got[1][2]).all()               # same parameters after the all-reduced update
+
+
+def _train_goldens():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2.json')) as f:
+        return json.load(f)['train']
+
+
+@pytest.mark.parametrize('run', _train_goldens(), ids=[r['label'] for r in _train_goldens()])
+def test_objective_equals_the_reference(run, monkeypatch):
+    """tests/golden/codec_v2.json['train']: the loss dictionary of the REFERENCE's PCC.train_forward (make_golden.py: its own
+    model / entropy-model code over the functional MinkowskiEngine stand-in, CPU) on batches of three clouds, with the
+    bottleneck's uniform noise replaced by zeros on both sides: rate terms, occupancy cross-entropies, reconstruction losses
+    of the lossy part and the warm-up factors (constant and linear) must agree term by term"""
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import ModelConfig
+    from util import enliven
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    model = model.cuda().train()
+    monkeypatch.setattr(torch.Tensor, 'uniform_', lambda self, *a, **k: self.zero_())
+    out = model.train_forward(torch.tensor(run['xyz'], dtype=torch.int32).cuda(), run['training_step'], run['batch_size'])
+    terms = {k: float(v) for k, v in out.items() if k != 'loss'}
+    assert set(terms) == set(run['terms'])
+    for k, want in run['terms'].items():
+        assert terms[k] == pytest.approx(want, rel=3e-3, abs=1e-3), k
+    assert float(out['loss']) == pytest.approx(run['loss'], rel=3e-3)
