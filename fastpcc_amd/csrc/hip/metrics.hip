@@ -95,6 +95,51 @@ __global__ __launch_bounds__(256) void k_sum_i64(const int64_t *__restrict__ v, 
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);   // integer: order independent
 }
 
+
+// K nearest neighbours of float points, brute force: a workgroup of 256 queries walks the candidate set in tiles of 1024
+// points staged through LDS (12 KB; every lane reads the same LDS address per step: a broadcast, no bank conflicts) and
+// keeps its K best (distance, index) pairs in registers, sorted by insertion.  O(P1 * P2) like the reference's kernel
+// (lib/knn3d/src/knn3d.cu:74-130); the codec itself never needs it (nearest voxels come from k_nn_dist2 on sorted keys).
+template <int K>
+__global__ __launch_bounds__(256) void k_knn3d(const float *__restrict__ p1, int64_t n1, const float *__restrict__ p2,
+                                               int64_t n2, int64_t *__restrict__ idx, float *__restrict__ dist2) {
+    constexpr int kTile = 1024;
+    __shared__ float s_pts[kTile * 3];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < n1;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (live) { qx = p1[3 * q]; qy = p1[3 * q + 1]; qz = p1[3 * q + 2]; }
+    float best[K];
+    int64_t who[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { best[k] = __builtin_inff(); who[k] = -1; }
+    for (int64_t base = 0; base < n2; base += kTile) {
+        const int count = (int)(n2 - base < kTile ? n2 - base : kTile);
+        for (int i = threadIdx.x; i < count * 3; i += 256) s_pts[i] = p2[3 * base + i];
+        __syncthreads();
+        if (live) {
+            for (int j = 0; j < count; ++j) {
+                const float dx = qx - s_pts[3 * j], dy = qy - s_pts[3 * j + 1], dz = qz - s_pts[3 * j + 2];
+                float d = dx * dx + dy * dy + dz * dz;
+                if (d < best[K - 1]) {                       // insert, keeping ascending order (ties: the earlier index stays first)
+                    int64_t w = base + j;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (d < best[k]) {
+                            const float td = best[k]; best[k] = d; d = td;
+                            const int64_t tw = who[k]; who[k] = w; w = tw;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { idx[q * K + k] = who[k]; dist2[q * K + k] = best[k]; }
+    }
+}
 }  // namespace
 }  // namespace fpcc
 
@@ -119,4 +164,20 @@ extern "C" int fpcc_sum_i64(const int64_t *values, int64_t n, uint64_t *sum_out,
     const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(n, 256), 1024);
     hipLaunchKernelGGL(k_sum_i64, dim3(blocks), dim3(256), 0, s, values, n, reinterpret_cast<unsigned long long *>(sum_out));
     return check_hip(hipGetLastError(), "k_sum_i64");
+}
+
+extern "C" int fpcc_knn3d(const float *p1, int64_t n1, const float *p2, int64_t n2, int k, int64_t *idx_out, float *dist2_out,
+                          void *stream) {
+    if (n1 < 0 || n2 < 0 || k < 1 || k > 16) return fail_arg("knn3d: sizes out of range (K 1..16)");
+    if (n1 == 0) return FPCC_OK;
+    if (!p1 || !idx_out || !dist2_out || (n2 > 0 && !p2)) return fail_arg("knn3d: null pointer");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(blocks_for(n1, 256)), block(256);
+    switch (k) {
+#define FPCC_KNN_CASE(KK) case KK: hipLaunchKernelGGL(k_knn3d<KK>, grid, block, 0, s, p1, n1, p2, n2, idx_out, dist2_out); break;
+        FPCC_KNN_CASE(1) FPCC_KNN_CASE(2) FPCC_KNN_CASE(3) FPCC_KNN_CASE(4) FPCC_KNN_CASE(5) FPCC_KNN_CASE(6) FPCC_KNN_CASE(7) FPCC_KNN_CASE(8)
+        FPCC_KNN_CASE(9) FPCC_KNN_CASE(10) FPCC_KNN_CASE(11) FPCC_KNN_CASE(12) FPCC_KNN_CASE(13) FPCC_KNN_CASE(14) FPCC_KNN_CASE(15) FPCC_KNN_CASE(16)
+#undef FPCC_KNN_CASE
+    }
+    return check_hip(hipGetLastError(), "k_knn3d");
 }

@@ -38,6 +38,7 @@ _SIGS = {
     'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
     'fpcc_conv_pack_weights_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_knn3d': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_transpose_weights_f32': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
@@ -380,6 +381,18 @@ def nn_dist2(keys: torch.Tensor, bits: int, query: torch.Tensor, want_rows: bool
     _ok(lib().fpcc_nn_dist2(_dev(keys, torch.int64, 'keys', keys.numel() == 0), keys.shape[0], bits, _dev(query, torch.int32, 'query'), n,
                             d.data_ptr(), None if rows is None else rows.data_ptr(), _stream()))
     return (d, rows) if want_rows else d
+
+
+def knn3d(p1: torch.Tensor, p2: torch.Tensor, K: int, version: int = -1):
+    """lib.knn3d.knn3d: (idx int64 [P1, K], dist2 float32 [P1, K]) of the K nearest points of p2 for every point of p1"""
+    if p1.dim() != 2 or p2.dim() != 2 or p1.shape[1] != 3 or p2.shape[1] != 3:
+        raise ValueError('points must be [n, 3]')
+    idx = torch.empty((p1.shape[0], K), dtype=torch.int64, device=p1.device)
+    dist = torch.empty((p1.shape[0], K), dtype=torch.float32, device=p1.device)
+    _ok(lib().fpcc_knn3d(_dev(p1.float().contiguous(), torch.float32, 'p1', p1.numel() == 0), p1.shape[0],
+                         _dev(p2.float().contiguous(), torch.float32, 'p2', p2.numel() == 0), p2.shape[0], int(K),
+                         idx.data_ptr(), dist.data_ptr(), _stream()))
+    return idx, dist
 
 
 def sum_i64(values: torch.Tensor) -> torch.Tensor:

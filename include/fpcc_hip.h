@@ -313,6 +313,11 @@ int fpcc_noisy_normal_bits_f32(const float *y, const float *index, int64_t n, fl
  * lib/metrics/pc_error_wrapper.py:40-107) and the brute-force KNN of lib/knn3d/src/knn3d.cu:74-130. */
 int fpcc_nn_dist2(const int64_t *keys, int64_t m, int bits, const int32_t *query, int64_t n, int64_t *dist2_out,
                   int32_t *nn_row_out, void *stream);
+/* K nearest neighbours (1 <= K <= 16) of every float point p1[n1][3] among p2[n2][3]: idx_out int64 [n1][K] (-1 where n2 < K),
+ * dist2_out float [n1][K] squared distances, ascending per row (the reference leaves the order unspecified); brute force.
+ * Replaces knn3d_ext.knn3d(p1, p2, K, version) (lib/knn3d/src/binding.cpp:5-7, knn3d.cu:74-130; the `version` argument picks
+ * among equivalent kernels there and has no counterpart). */
+int fpcc_knn3d(const float *p1, int64_t n1, const float *p2, int64_t n2, int k, int64_t *idx_out, float *dist2_out, void *stream);
 /* *sum_out (device) = sum of the non-negative entries; integer, so independent of the reduction order. */
 int fpcc_sum_i64(const int64_t *values, int64_t n, uint64_t *sum_out, void *stream);
 

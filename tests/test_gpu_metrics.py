@@ -95,3 +95,22 @@ def test_colour_psnr_of_identical_clouds_is_infinite():
     noisy = (col[perm] + 2).clamp(max=255)
     out = d1_metrics(xyz, xyz[perm], 64, col, noisy)
     assert 35 < out['c[0],PSNRF'] < 50
+
+
+@pytest.mark.parametrize('K', [1, 3, 8, 16])
+def test_knn3d_matches_a_dense_distance_matrix(K):
+    """fpcc_knn3d (lib.knn3d.knn3d's entry): the K smallest squared distances per query equal those of torch.cdist, and
+    every returned index really is at the returned distance"""
+    from fastpcc_amd import hipops as ops
+    g = torch.Generator().manual_seed(K)
+    p1 = (torch.rand((3000, 3), generator=g) * 100).cuda()
+    p2 = (torch.rand((2500, 3), generator=g) * 100).cuda()
+    idx, d2 = ops.knn3d(p1, p2, K)
+    ref = (torch.cdist(p1.double(), p2.double()) ** 2).topk(K, dim=1, largest=False).values
+    assert idx.shape == (3000, K) and idx.dtype == torch.int64 and (idx >= 0).all() and (idx < 2500).all()
+    assert torch.allclose(d2.double(), ref, rtol=1e-5, atol=1e-3)
+    assert (d2[:, 1:] >= d2[:, :-1]).all()
+    at = ((p1[:, None, :] - p2[idx]) ** 2).sum(-1)
+    assert torch.allclose(at, d2, rtol=1e-5, atol=1e-3)
+    few_idx, few_d = ops.knn3d(p1[:5], p2[:2], 3)                       # fewer candidates than K: -1 / inf fill
+    assert (few_idx[:, 2] == -1).all() and torch.isinf(few_d[:, 2]).all() and (few_idx[:, :2] >= 0).all()
