@@ -609,13 +609,14 @@ int launch_split(ConvArgs a, hipStream_t s) {
 }
 
 // Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
-enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobMfmaCfg = 5, kKnobCount = 6 };
-int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1};
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
+       kKnobCount = 7 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
         static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS",
-                                                "FPCC_MFMA_TILE"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, FPCC_SPLIT_MAX_ROWS, 0};
+                                                "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, FPCC_SPLIT_MAX_ROWS, 0, 32 * 1024};
         const char *e = getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
@@ -678,6 +679,127 @@ int launch_wave(const ConvArgs &a, const float *wp, hipStream_t s) {
     if (nbw >= 4) return launch_wave_cfg<4>(a, wp, nbt, s);
     if (nbw == 2) return launch_wave_cfg<2>(a, wp, nbt, s);
     return launch_wave_cfg<1>(a, wp, nbt, s);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-point layers (ONE kernel offset, identity row map: MinkowskiLinear, 1x1x1 convolutions) on large maps.  In k_conv_wave
+// such a layer is 4-8 stages per wave: the operand fetches of a 32-row unit are not amortised and the weights are streamed
+// from L2 once per unit.  Here a wave keeps the B operands of its NBW column blocks for ALL input channels in registers
+// (16 * NCH * NBW VGPRs) and walks many 32-row blocks: per block only the A rows are loaded (16-byte loads in MFMA operand
+// layout, rows are contiguous in memory) and the outputs stored.  Two to three waves per SIMD overlap one wave's loads with
+// another's MFMAs.  Same FMA chain per output element as k_conv_wave / k_conv_mfma (chunks ascending, groups of 8 channels
+// ascending, 0,4,1,5,2,6,3,7 inside a group): summation order 1, results bit-identical.
+template <int NBW, int NCH, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_pointwise_wave(ConvArgs a, const float *__restrict__ wp, int nbt, unsigned n_row_blocks,
+                                                           unsigned waves_per_cg) {
+    constexpr int AC = NCH < 4 ? NCH : 4;          // chunks of A held at a time (16 VGPRs each)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned n_cg = (unsigned)(nbt / NBW);
+    const unsigned w = blockIdx.x * 4u + (unsigned)wv;          // global wave: column group = w % n_cg, row blocks strided
+    const unsigned cg = w % n_cg, slot = w / n_cg;
+    if (slot >= waves_per_cg) return;
+
+    // B operands of this wave's column blocks, all chunks: wp[0][cc][g8][nb][h][i][j]
+    f32x4 rb[NCH][4][NBW];
+    {
+        const float *wpl = wp + ((int64_t)cg * NBW) * 256 + lane * 4;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+                    rb[cc][g8][nb] = *reinterpret_cast<const f32x4 *>(wpl + (((int64_t)cc * 4 + g8) * nbt + nb) * 256);
+    }
+    const int n1 = a.c1 / 32;                                   // chunks [0, n1) lie in x1, the rest in x2
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    float bias[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) bias[nb] = a.bias ? a.bias[32 * ((int)cg * NBW + nb) + li] : 0.0f;
+
+    for (unsigned rbk = slot; rbk < n_row_blocks; rbk += waves_per_cg) {
+        const int64_t row0 = (int64_t)rbk * 32;
+        int64_t row = row0 + li;
+        if (row >= a.n_out) row = a.n_out - 1;                  // tail block: re-read the last row, never stored
+        if (DBG & 1) row = lane & 1;                            // timing experiment: (almost) no A traffic
+        const float *const p1 = a.x1 + row * a.ld1 + 4 * lh;
+        const float *const p2 = a.x2 ? a.x2 + row * a.ld2 + 4 * lh : p1;
+        f32x16 acc[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+#pragma unroll
+        for (int part = 0; part < NCH; part += AC) {
+            f32x4 ra[AC][4];
+#pragma unroll
+            for (int c = 0; c < AC; ++c) {
+                const int cc = part + c;
+                const float *src = cc < n1 ? p1 + 32 * cc : p2 + 32 * (cc - n1);     // wave-uniform
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) ra[c][g8] = *reinterpret_cast<const f32x4 *>(src + 8 * g8);
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // all loads of the part in flight before the first MFMA
+#pragma unroll
+            for (int c = 0; c < AC; ++c)
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    const f32x4 av = ra[c][g8];
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, rb[part + c][g8][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, rb[part + c][g8][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, rb[part + c][g8][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[part + c][g8][nb].w, acc[nb], 0, 0, 0);
+                }
+        }
+        // register r holds row (r & 3) + 8 (r >> 2) + 4 h of the block, column li of each column block
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t o = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (o >= a.n_out) continue;
+            if ((DBG & 4) && acc[0][reg] != 12345.678f) continue;   // timing experiment: no stores
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                a.out[o * a.ldo + 32 * ((int)cg * NBW + nb) + li] = finish(acc[nb][reg], bias[nb], a.act, slope, a.clip);
+        }
+    }
+}
+
+// rows from which the persistent per-point kernel is used (below, a launch has too few 32-row blocks for every wave to reuse
+// its weights several times and k_conv_wave's finer units fill the chip better): knob 6 / FPCC_POINTWISE_MIN_ROWS, 0 = never
+
+template <int NBW, int NCH>
+int launch_pointwise_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
+    const unsigned row_blocks = (unsigned)((a.n_out + 31) / 32);
+    const unsigned n_cg = (unsigned)(nbt / NBW);
+    unsigned waves_per_cg = (256u * 4u * 2u) / n_cg;            // two waves per SIMD on the whole chip
+    if (waves_per_cg > row_blocks) waves_per_cg = row_blocks;
+    const unsigned waves = waves_per_cg * n_cg;
+    const int dbg = (NBW == 2 && NCH == 4) ? knob(kKnobWaveDbg) : 0;       // experiments on the 128 -> 128 shape only
+    if (dbg == 1) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 1>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
+    else if (dbg == 4) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 4>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
+    else if (dbg == 5) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 5>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
+    else hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
+    return check_hip(hipGetLastError(), "k_pointwise_wave");
+}
+
+// -1: shape not covered
+int launch_pointwise(const ConvArgs &a, const float *wp, hipStream_t s) {
+    const int nbt = a.c_out / 32, nch = (a.c1 + a.c2) / 32;
+    switch (nch) {
+        case 1: return nbt % 4 == 0 ? launch_pointwise_cfg<4, 1>(a, wp, nbt, s) : nbt % 2 == 0 ? launch_pointwise_cfg<2, 1>(a, wp, nbt, s)
+                                                                                                : launch_pointwise_cfg<1, 1>(a, wp, nbt, s);
+        case 2: return nbt % 4 == 0 ? launch_pointwise_cfg<4, 2>(a, wp, nbt, s) : nbt % 2 == 0 ? launch_pointwise_cfg<2, 2>(a, wp, nbt, s)
+                                                                                                : launch_pointwise_cfg<1, 2>(a, wp, nbt, s);
+        case 4: return nbt % 2 == 0 ? launch_pointwise_cfg<2, 4>(a, wp, nbt, s) : launch_pointwise_cfg<1, 4>(a, wp, nbt, s);
+        case 8: return launch_pointwise_cfg<1, 8>(a, wp, nbt, s);
+        default: return -1;
+    }
 }
 
 template <int JB>
@@ -787,7 +909,14 @@ extern "C" int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x
         return c_out == 64 ? launch_mfma_cfg<2, 48, 4, 1>(a, s) : launch_mfma_cfg<1, 48, 4, 1>(a, s);
     if (ch == 32 && w_packed) {
         if (!aligned16(w_packed)) return fail_arg("conv_f32: packed weights must be 16-byte aligned");
-        if (knob(kKnobWaveOn)) return launch_wave(a, w_packed, s);
+        if (knob(kKnobWaveOn)) {
+            const int64_t pw_rows = knob(kKnobPointwiseRows);
+            if (n_offsets == 1 && !nbr && !row_order && groups == 1 && !out_map && pw_rows > 0 && n_out >= pw_rows) {
+                const int rc = launch_pointwise(a, w_packed, s);
+                if (rc != -1) return rc;
+            }
+            return launch_wave(a, w_packed, s);
+        }
     }
     if (ch == 32) {
         if (c_out == 128) return launch_mfma<4, 32>(a, s);

@@ -302,7 +302,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
     return out
 
 
-KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS, KNOB_MFMA_TILE = 0, 1, 2, 3, 4, 5
+KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 4, 5, 6
 
 
 def numerics_version() -> int:

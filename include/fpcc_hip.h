@@ -165,6 +165,8 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *   2  1 = the next stage's address arithmetic may be scheduled between the MFMAs, 0 = nothing crosses the load points
  *   3  timing experiments only (results are WRONG): 1 = no gather traffic, 2 = weights from one chunk, 3 = both; 0 = off
  *   5  row tile of the workgroup-tiled kernel: 0 = by map size, 1 | 2 | 3 = 128 | 64 | 32 rows
+ *   6  rows from which per-point layers (one offset, identity map) run on the persistent kernel that keeps the weights in
+ *      registers (FPCC_POINTWISE_MIN_ROWS, default 32768); 0 = never
  *   4  (NOT result-neutral) rows up to which multi-offset maps are evaluated offset-split = summation order 2; default 8192 */
 int fpcc_conv_set_tuning(int which, int value);
 int fpcc_conv_pack_weights_f32(const float *w, int64_t n_mats, int c_in, int c_out, float *w_packed, void *stream);

@@ -406,3 +406,29 @@ def test_packed_weights_follow_in_place_updates(knobs):
     w.mul_(2.0)                                     # same storage, new version: the packed copy must be rebuilt
     b = ops.conv_f32(x, w, 64, 300, pack=True)
     assert torch.equal(b, ops.conv_f32(x, w, 64, 300)) and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize('n', [1, 33, 4999, 70001])
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (128, 128, 128), (64, 0, 128), (128, 0, 64), (64, 0, 64), (32, 0, 32), (32, 0, 128),
+                                         (64, 64, 32), (256, 0, 128), (128, 0, 32), (64, 0, 96)])
+def test_persistent_pointwise_kernel_equals_the_other_kernels(knobs, n, c1, c2, c_out):
+    """per-point layers on large maps run on k_pointwise_wave (weights in registers, many row blocks per wave): forced on for
+    every row count here, it must give the bits of the workgroup-tiled kernel, with bias / PReLU / clamp and two sources"""
+    ops = knobs
+    rng = np.random.default_rng(n + c1 + 3 * c2 + 5 * c_out)
+    x1 = _cuda(rng.normal(size=(n, c1)).astype(np.float32))
+    x2 = _cuda(rng.normal(size=(n, c2)).astype(np.float32)) if c2 else None
+    w = _cuda((rng.normal(size=(c1 + c2, c_out)) / np.sqrt(c1 + c2)).astype(np.float32))
+    b = _cuda(rng.normal(size=c_out).astype(np.float32))
+    slope = torch.tensor([0.15], device='cuda')
+    kw = dict(x2=x2, bias=b, act=ops.ACT_PRELU, slope=slope, clip=2.0)
+    base = ops.conv_f32(x1, w, c_out, n, **kw).cpu().numpy()                       # workgroup-tiled kernel (unpacked weights)
+    before = ops.conv_set_tuning(ops.KNOB_POINTWISE_ROWS, 1)
+    try:
+        got = ops.conv_f32(x1, w, c_out, n, pack=True, **kw).cpu().numpy()
+        ops.conv_set_tuning(ops.KNOB_POINTWISE_ROWS, 0)
+        wave = ops.conv_f32(x1, w, c_out, n, pack=True, **kw).cpu().numpy()
+    finally:
+        ops.conv_set_tuning(ops.KNOB_POINTWISE_ROWS, before)
+    assert (_bits(wave) == _bits(base)).all()
+    assert (_bits(got) == _bits(base)).all()
