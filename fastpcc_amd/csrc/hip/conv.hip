@@ -739,7 +739,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_wave(ConvArgs a, const flo
                 const int cc = part + c;
                 const float *src = cc < n1 ? p1 + 32 * cc : p2 + 32 * (cc - n1);     // wave-uniform
 #pragma unroll
-                for (int g8 = 0; g8 < 4; ++g8) ra[c][g8] = *reinterpret_cast<const f32x4 *>(src + 8 * g8);
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    if (DBG & 8) { const float v = (float)(lane + g8 + cc + (int)rbk); ra[c][g8] = f32x4{v, v + 1.0f, v + 2.0f, v + 3.0f}; }
+                    else ra[c][g8] = *reinterpret_cast<const f32x4 *>(src + 8 * g8);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);                  // all loads of the part in flight before the first MFMA
 #pragma unroll
@@ -784,6 +787,7 @@ int launch_pointwise_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_
     if (dbg == 1) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 1>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
     else if (dbg == 4) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 4>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
     else if (dbg == 5) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 5>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
+    else if (dbg == 12) hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH, 12>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
     else hipLaunchKernelGGL((k_pointwise_wave<NBW, NCH>), dim3((waves + 3) / 4), dim3(256), 0, s, a, wp, nbt, row_blocks, waves_per_cg);
     return check_hip(hipGetLastError(), "k_pointwise_wave");
 }

@@ -37,7 +37,7 @@ wave = timed('wave', pack=True)
 ops.conv_set_tuning(ops.KNOB_POINTWISE_ROWS, 1)
 pw = timed('persistent', pack=True)
 assert torch.equal(base, wave) and torch.equal(base, pw)
-for dbg, what in ((1, 'no A traffic'), (4, 'no stores'), (5, 'neither')):
+for dbg, what in ((1, 'no A traffic'), (4, 'no stores'), (5, 'neither'), (12, 'no loads at all, no stores')):
     ops.conv_set_tuning(ops.KNOB_WAVE_DBG, dbg)
     timed('persistent, ' + what, pack=True)
 ops.conv_set_tuning(ops.KNOB_WAVE_DBG, 0)
