@@ -694,6 +694,8 @@ template <int NBW, int NCH, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_pointwise_wave(ConvArgs a, const float *__restrict__ wp, int nbt, unsigned n_row_blocks,
                                                            unsigned waves_per_cg) {
     constexpr int AC = NCH < 4 ? NCH : 4;          // chunks of A held at a time (16 VGPRs each)
+    constexpr int TW = 32 * NBW + 4;               // row pitch of the output tile in LDS (floats; +4: rows start on different banks)
+    __shared__ float s_tile[4][32 * TW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const unsigned n_cg = (unsigned)(nbt / NBW);
@@ -719,57 +721,88 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_wave(ConvArgs a, const flo
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) bias[nb] = a.bias ? a.bias[32 * ((int)cg * NBW + nb) + li] : 0.0f;
 
+    // Operand stream: stage t = (row block of this wave, chunk); the AC chunk slots of `ra` form a ring -- right after the MFMAs
+    // of a group of 8 channels have consumed ra[slot][g8] the same registers are reloaded with stage t + AC (the same chunk of
+    // the wave's NEXT row block when all chunks are resident), so every load has a whole row block of MFMAs to land.
+    auto row_ptrs = [&](unsigned rbk, const float *&q1, const float *&q2) {
+        int64_t row = (int64_t)rbk * 32 + li;
+        if (row >= a.n_out) row = a.n_out - 1;                  // tail block / past the end: re-read the last row, never stored
+        if (DBG & 1) row = lane & 1;                            // timing experiment: (almost) no A traffic
+        q1 = a.x1 + row * a.ld1 + 4 * lh;
+        q2 = a.x2 ? a.x2 + row * a.ld2 + 4 * lh : q1;
+    };
+    auto fetch = [&](const float *q1, const float *q2, int cc, int g8) -> f32x4 {
+        if (DBG & 8) { const float v = (float)(lane + g8 + cc); return f32x4{v, v + 1.0f, v + 2.0f, v + 3.0f}; }
+        const float *src = cc < n1 ? q1 + 32 * cc : q2 + 32 * (cc - n1);             // wave-uniform
+        return *reinterpret_cast<const f32x4 *>(src + 8 * g8);
+    };
+    const float *c1p, *c2p, *n1p, *n2p;
+    row_ptrs(slot, c1p, c2p);
+    f32x4 ra[AC][4];
+#pragma unroll
+    for (int c = 0; c < AC; ++c)
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8) {
+            __builtin_amdgcn_sched_barrier(0);
+            ra[c][g8] = fetch(c1p, c2p, c, g8);
+        }
+    __builtin_amdgcn_sched_barrier(0);
     for (unsigned rbk = slot; rbk < n_row_blocks; rbk += waves_per_cg) {
         const int64_t row0 = (int64_t)rbk * 32;
-        int64_t row = row0 + li;
-        if (row >= a.n_out) row = a.n_out - 1;                  // tail block: re-read the last row, never stored
-        if (DBG & 1) row = lane & 1;                            // timing experiment: (almost) no A traffic
-        const float *const p1 = a.x1 + row * a.ld1 + 4 * lh;
-        const float *const p2 = a.x2 ? a.x2 + row * a.ld2 + 4 * lh : p1;
+        row_ptrs(rbk + waves_per_cg, n1p, n2p);                 // (clamped past the end: loaded, never used)
         f32x16 acc[NBW];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 #pragma unroll
-        for (int part = 0; part < NCH; part += AC) {
-            f32x4 ra[AC][4];
+        for (int cc = 0; cc < NCH; ++cc) {
+            constexpr int kNone = 0;
+            (void)kNone;
+            const int sl = cc % AC;
+            const bool wraps = cc + AC >= NCH;                  // compile-time after unrolling
+            const int cn = (cc + AC) % NCH;
 #pragma unroll
-            for (int c = 0; c < AC; ++c) {
-                const int cc = part + c;
-                const float *src = cc < n1 ? p1 + 32 * cc : p2 + 32 * (cc - n1);     // wave-uniform
+            for (int g8 = 0; g8 < 4; ++g8) {
+                const f32x4 av = ra[sl][g8];
 #pragma unroll
-                for (int g8 = 0; g8 < 4; ++g8) {
-                    if (DBG & 8) { const float v = (float)(lane + g8 + cc + (int)rbk); ra[c][g8] = f32x4{v, v + 1.0f, v + 2.0f, v + 3.0f}; }
-                    else ra[c][g8] = *reinterpret_cast<const f32x4 *>(src + 8 * g8);
-                }
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, rb[cc][g8][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, rb[cc][g8][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, rb[cc][g8][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[cc][g8][nb].w, acc[nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0x6);
+                ra[sl][g8] = wraps ? fetch(n1p, n2p, cn, g8) : fetch(c1p, c2p, cn, g8);       // stage t + AC
+                __builtin_amdgcn_sched_barrier(0x6);
             }
-            __builtin_amdgcn_sched_barrier(0);                  // all loads of the part in flight before the first MFMA
-#pragma unroll
-            for (int c = 0; c < AC; ++c)
-#pragma unroll
-                for (int g8 = 0; g8 < 4; ++g8) {
-                    const f32x4 av = ra[c][g8];
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, rb[part + c][g8][nb].x, acc[nb], 0, 0, 0);
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, rb[part + c][g8][nb].y, acc[nb], 0, 0, 0);
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, rb[part + c][g8][nb].z, acc[nb], 0, 0, 0);
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[part + c][g8][nb].w, acc[nb], 0, 0, 0);
-                }
         }
-        // register r holds row (r & 3) + 8 (r >> 2) + 4 h of the block, column li of each column block
+        c1p = n1p;
+        c2p = n2p;
+        // Epilogue through a private LDS tile: the accumulator layout (register r = row (r & 3) + 8 (r >> 2) + 4 h, lane = column)
+        // would store one dword per lane, 256 bytes per instruction; transposed through LDS every lane stores 16 bytes and an
+        // instruction writes whole 128-byte lines of four rows (a quarter of the store instructions).
+        float *tile = s_tile[wv];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int64_t o = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (o >= a.n_out) continue;
-            if ((DBG & 4) && acc[0][reg] != 12345.678f) continue;   // timing experiment: no stores
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb)
-                a.out[o * a.ldo + 32 * ((int)cg * NBW + nb) + li] = finish(acc[nb][reg], bias[nb], a.act, slope, a.clip);
+            for (int nb = 0; nb < NBW; ++nb) tile[r * TW + 32 * nb + li] = finish(acc[nb][reg], bias[nb], a.act, slope, a.clip);
         }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int LPR = 8 * NBW;                            // lanes per row (16 bytes each)
+        constexpr int RPI = 64 / LPR;                           // rows per store instruction
+        const int qr = lane / LPR, qc = lane % LPR;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+            const int r = r0 + qr;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + r * TW + 4 * qc);
+            const int64_t o = row0 + r;
+            if (o < a.n_out && !((DBG & 4) && v.x != 12345.678f))
+                *reinterpret_cast<f32x4 *>(a.out + o * a.ldo + 32 * (int)cg * NBW + 4 * qc) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -915,7 +948,8 @@ extern "C" int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x
         if (!aligned16(w_packed)) return fail_arg("conv_f32: packed weights must be 16-byte aligned");
         if (knob(kKnobWaveOn)) {
             const int64_t pw_rows = knob(kKnobPointwiseRows);
-            if (n_offsets == 1 && !nbr && !row_order && groups == 1 && !out_map && pw_rows > 0 && n_out >= pw_rows) {
+            if (n_offsets == 1 && !nbr && !row_order && groups == 1 && !out_map && pw_rows > 0 && n_out >= pw_rows && aligned16(out) &&
+                ldo % 4 == 0) {                                   // 16-byte output stores
                 const int rc = launch_pointwise(a, w_packed, s);
                 if (rc != -1) return rc;
             }
