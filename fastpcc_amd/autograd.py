@@ -31,6 +31,13 @@ class ConvSpec:
         self.kind, self.n_in, self.n_out, self.table, self.row_order = kind, n_in, n_out, table, row_order
 
 
+# Weights change every step, so a packed copy for the wave / persistent kernels would have to be made per call ('fresh': one small
+# launch per convolution).  Measured on the cfg#5 step (tools/r02/train_ab.sh, back-to-back on one box): 59.5 / 57.3 ms packed against
+# 57.8 / 58.9 ms on the workgroup-tiled kernel -- no gain, the step is bound by the weight-gradient kernels and launch count; off.
+import os as _os
+PACK = 'fresh' if _os.environ.get('FPCC_TRAIN_PACK', 'off') in ('fresh', '1') else False
+
+
 def _mfma(c_in: int, c_out: int) -> bool:
     return ops.conv_order(c_in, 0, c_out) != 0
 
@@ -42,7 +49,7 @@ def _k3_one_channel(x: torch.Tensor, w: torch.Tensor, s: ConvSpec, **epilogue) -
     c_in = w.shape[-2]
     wt = torch.zeros((c_in, 32), dtype=w.dtype, device=w.device)
     wt[:, :27] = w.detach().reshape(27, c_in).t()
-    y = ops.conv_f32(x, wt, 32, s.n_in)
+    y = ops.conv_f32(x, wt, 32, s.n_in, pack=PACK)
     return ops.gather_sum(y, s.table, 27, s.n_in, 1, s.n_in, **epilogue)
 
 
@@ -53,12 +60,12 @@ def _one_channel_ok(c_in: int, c_out: int) -> bool:
 def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     c_in, c_out = w.shape[-2], w.shape[-1]
     if s.kind == 'k1':
-        return ops.conv_f32(x, w.reshape(c_in, c_out), c_out, s.n_in)
+        return ops.conv_f32(x, w.reshape(c_in, c_out), c_out, s.n_in, pack=PACK)
     if s.kind == 'k3' and _one_channel_ok(c_in, c_out):
         return _k3_one_channel(x, w, s)
     if s.kind == 'k3':
         return ops.conv_f32(x, w, c_out, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
-                            row_order=s.row_order if _mfma(c_in, c_out) else None)
+                            row_order=s.row_order if _mfma(c_in, c_out) else None, pack=PACK)
     if s.kind == 'k2s2':
         return ops.conv_f32(x, w, c_out, s.n_out, nbr=s.table, n_offsets=8, nbr_ks=1, nbr_os=8)
     if s.kind == 'k2s2T':
@@ -96,12 +103,12 @@ def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     if s.kind == 'tab':
         raise NotImplementedError('input gradient through a general lookup-table convolution')
     if s.kind == 'k1':
-        return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out),
+        return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out, pack=PACK),
                      ops.transpose_weights(w, 1, c_in, c_out, flip=False).view(c_out, c_in), c_in, s.n_in, dy.device)
     if s.kind == 'k3':
         wt = ops.transpose_weights(w, 27, c_in, c_out, flip=True)         # W'[k] = W[26-k]^T
         return _wide(lambda wk, c, out: ops.conv_f32(dy, wk, c, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,
-                                                     row_order=s.row_order if _mfma(c_out, c) else None, out=out),
+                                                     row_order=s.row_order if _mfma(c_out, c) else None, out=out, pack=PACK),
                      wt, c_in, s.n_in, dy.device)
     wt = ops.transpose_weights(w, 8, c_in, c_out, flip=False)               # [8][c_out][c_in]
     if s.kind == 'k2s2':                                                   # children <- parents: transposed form
@@ -170,12 +177,12 @@ class SparseConvActFn(torch.autograd.Function):
         b = None if bias is None else bias.reshape(-1)
         kw = dict(bias=b, act=act, slope=slope)
         if spec.kind == 'k1':
-            y = ops.conv_f32(x, w.reshape(c_in, c_out), c_out, spec.n_in, **kw)
+            y = ops.conv_f32(x, w.reshape(c_in, c_out), c_out, spec.n_in, pack=PACK, **kw)
         elif spec.kind == 'k3' and _one_channel_ok(c_in, c_out):
             y = _k3_one_channel(x, w, spec, **kw)
         elif spec.kind == 'k3':
             y = ops.conv_f32(x, w, c_out, spec.n_in, nbr=spec.table, n_offsets=27, nbr_ks=spec.n_in, nbr_os=1,
-                             row_order=spec.row_order if _mfma(c_in, c_out) else None, **kw)
+                             row_order=spec.row_order if _mfma(c_in, c_out) else None, pack=PACK, **kw)
         elif spec.kind == 'k2s2':
             y = ops.conv_f32(x, w, c_out, spec.n_out, nbr=spec.table, n_offsets=8, nbr_ks=1, nbr_os=8, **kw)
         elif spec.kind == 'k2s2T':

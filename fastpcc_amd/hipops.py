@@ -285,10 +285,15 @@ _PACKED: 'collections.OrderedDict' = collections.OrderedDict()
 _PACKED_MAX = 1024
 
 
-def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int, groups: int) -> Optional[torch.Tensor]:
-    """packed copy of w [groups, n_offsets, c1 + c2, c_out] for fpcc_conv_f32_pk, or None when the shape has no wave kernel"""
+def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int, groups: int, fresh: bool = False) -> Optional[torch.Tensor]:
+    """packed copy of w [groups, n_offsets, c1 + c2, c_out] for fpcc_conv_f32_pk, or None when the shape has no wave kernel.
+    fresh: pack now and do not cache (weights that change every step: training)"""
     if not lib().fpcc_conv_packed_floats(c1, c2, c_out, n_offsets, groups):
         return None
+    if fresh:
+        out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        _ok(lib().fpcc_conv_pack_weights_f32(w.data_ptr(), groups * n_offsets, c1 + c2, c_out, out.data_ptr(), _stream()))
+        return out
     key = (w.data_ptr(), w.numel(), c1 + c2, c_out)
     ent = _PACKED.get(key)
     if ent is not None and ent[1] == w._version:
@@ -327,8 +332,8 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
              act: int = ACT_NONE, slope: Optional[torch.Tensor] = None, clip: float = 0.0,
              row_order: Optional[torch.Tensor] = None, pack: bool = False) -> torch.Tensor:
     """out[dst(o,g)] = act(sum_k X[nbr[k*nbr_ks + o*nbr_os]] @ w[g][k] + bias); see include/fpcc_hip.h.
-    pack: keep a packed copy of `w` (packed_weights) and run the shapes that have one on the wave-autonomous kernel --
-    for weights that stay put between calls (inference)."""
+    pack: True = keep a packed copy of `w` (packed_weights) and run the shapes that have one on the wave-autonomous / persistent
+    per-point kernels -- for weights that stay put between calls (inference); 'fresh' = pack for this call only (training)."""
     p1, c1, ld1 = _rows2d(x1, 'x1')
     if x2 is not None:
         p2, c2, ld2 = _rows2d(x2, 'x2')
@@ -350,7 +355,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
-    wp = packed_weights(w, c1, c2, c_out, n_offsets, groups) if pack and not ws_bytes else None
+    wp = packed_weights(w, c1, c2, c_out, n_offsets, groups, fresh=(pack == 'fresh')) if pack and not ws_bytes else None
     trace = CONV_TRACE
     if trace is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
