@@ -20,6 +20,8 @@ Sources of truth used:
   hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
   codec_v2.json  the reference's lossy_coord_v2 codec (layers / model / geo_lossl_em / ME wrapper layers + its rANS coders) executed on
                  the CPU over a functional MinkowskiEngine stand-in built on oracle/coords.py + conv_mm: streams, reconstructions
+  codec_color.json / codec_lossl.json  likewise the reference's lossy_coord_lossy_color codec (over the MinkowskiEngine stand-in) and its
+                 float LiDAR model lossl_coord incl. train_forward (over the torchsparse stand-in)
   codec_v3.json  the reference's lossy_coord_v3 model executed on the CPU over a functional torchsparse stand-in (kernel-offset
                  enumeration restated, everything else the reference's code and coder): streams, side information, reconstructions
   codec_int.json the reference's integer LiDAR codec (cuda_ops.py + lossl_coord_int/model.py) executed on the CPU over a stand-in for
