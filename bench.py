@@ -62,7 +62,7 @@ def pmc_traffic():
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    mfma = [v for k, v in data.items() if k.startswith('k_conv_mfma') or k.startswith('k_conv_wave')]
+    mfma = [v for k, v in data.items() if k.startswith(('k_conv_mfma', 'k_conv_wave', 'k_pointwise_wave'))]
     launches = sum(v['launches'] for v in mfma)
     total = sum(v['fetch_bytes'] + v['write_bytes'] for v in mfma)
     if not launches:
