@@ -406,8 +406,8 @@ def main():
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE)',
                          'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': round(bytes_fused / max(n_launch, 1)),
-                         'kernel': 'k_conv_wave / k_conv_mfma (fp32 gather->MFMA sparse convolution: wave-autonomous kernel, workgroup-tiled '
-                                   'kernel for the offset-split small maps and the narrow shapes)',
+                         'kernel': 'k_conv_wave / k_pointwise_wave / k_conv_mfma (fp32 gather->MFMA sparse convolution: wave-autonomous kernel, '
+                                   'persistent per-point kernel, workgroup-tiled kernel for the offset-split small maps and the narrow shapes)',
                          'launches_per_step': n_launch // trace_steps,
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),
