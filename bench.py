@@ -325,6 +325,7 @@ def main():
     # of the timed region (the last); its launches are what `roofline` is computed from.
     trace_steps = 1
     t_enc = t_dec = 0.0
+    hipops.reserve_trace_events(1200 * trace_steps)        # before the timed region: the traced step only records
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):

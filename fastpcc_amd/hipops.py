@@ -323,6 +323,18 @@ def conv_set_tuning(which: int, value: int) -> int:
 # When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
 # bench.py to time the dominant kernel inside the timed region (events only, no synchronisation).
 CONV_TRACE = None
+_EVENT_POOL: list = []
+
+
+def reserve_trace_events(n: int) -> None:
+    """create n timing events ahead of a traced step, so that the step itself records into existing events (creating an event
+    per launch slows the host enough that the GPU waits for it, and those waits end up inside the measured intervals)"""
+    while len(_EVENT_POOL) < n:
+        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+
+
+def _trace_event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
 
 
 def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: Optional[torch.Tensor] = None,
@@ -358,7 +370,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     wp = packed_weights(w, c1, c2, c_out, n_offsets, groups, fresh=(pack == 'fresh')) if pack and not ws_bytes else None
     trace = CONV_TRACE
     if trace is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0 = _trace_event()
         ev0.record()
     _ok(lib().fpcc_conv_f32_pk(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
                                w.data_ptr(), None if wp is None else wp.data_ptr(),
@@ -368,7 +380,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
                                _dev(row_order, torch.int32, 'row_order', True),
                                None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
     if trace is not None:
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1 = _trace_event()
         ev1.record()
         trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
                                  'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
