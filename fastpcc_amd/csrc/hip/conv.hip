@@ -1012,6 +1012,60 @@ __global__ __launch_bounds__(256) void k_conv_tile_keys(const uint32_t *__restri
     if (lane == 0) keys[g] = ((int64_t)(n_off - __popc(m)) << 32) | g;
 }
 
+// Permutation that sorts <= 16384 group keys (fpcc_conv_tile_keys: (lacking offsets) << 32 | group) -- i.e. a STABLE counting sort
+// of the groups by their <= 33 possible weights.  One workgroup, three barriers; replaces a 64-bit merge sort of ~10 launches
+// per coordinate map (rocprim sorts arrays this small with block sort + log2(n / block) merge passes).
+__global__ __launch_bounds__(1024) void k_group_counting_order(const int64_t *__restrict__ keys, int n, int32_t *__restrict__ perm) {
+    constexpr int kBins = 34, kPer = 16;
+    __shared__ uint16_t s_wave[16][kBins];
+    __shared__ uint32_t s_base[kBins];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n + 1023) / 1024;                           // consecutive groups per thread (<= 16)
+    const int g0 = t * per;
+    uint8_t bin[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int g = g0 + j;
+        bin[j] = (j < per && g < n) ? (uint8_t)min((int)(keys[g] >> 32), kBins - 1) : 255;
+    }
+    uint16_t before[kBins];                                      // groups of this bin in earlier threads of my wave
+#pragma unroll
+    for (int b = 0; b < kBins; ++b) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) c += bin[j] == b;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        before[b] = (uint16_t)(incl - c);
+        if (lane == 63) s_wave[wv][b] = (uint16_t)incl;
+    }
+    __syncthreads();
+    if (t < kBins) {                                             // per bin: exclusive prefix over the 16 waves, and the bin's total
+        uint32_t run = 0;
+        for (int w = 0; w < 16; ++w) { const uint32_t c = s_wave[w][t]; s_wave[w][t] = (uint16_t)run; run += c; }
+        s_base[t] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < kBins; ++b) { const uint32_t c = s_base[b]; s_base[b] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        if (bin[j] == 255) continue;
+        uint32_t pos = 0;
+#pragma unroll
+        for (int b = 0; b < kBins; ++b)
+            if (bin[j] == b) { pos = s_base[b] + s_wave[wv][b] + before[b]; before[b] += 1; }
+        perm[pos] = g0 + j;
+    }
+}
+
 __global__ void k_conv_regroup_rows(const int32_t *__restrict__ row_order, const int32_t *__restrict__ group_perm, int64_t n,
                                     int group, int64_t n_groups, int32_t *__restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1032,6 +1086,14 @@ extern "C" int fpcc_conv_tile_keys(const uint32_t *row_masks, int n_offsets, con
     hipLaunchKernelGGL(k_conv_tile_keys, dim3(blocks_for(n_groups, 4)), dim3(256), 0, as_stream(stream), row_masks, n_offsets,
                        row_order, n, group, n_groups, keys_out);
     return check_hip(hipGetLastError(), "k_conv_tile_keys");
+}
+
+extern "C" int fpcc_conv_group_order(const int64_t *group_keys, int64_t n_groups, int32_t *perm_out, void *stream) {
+    if (n_groups < 0 || n_groups > 16384) return fail_arg("conv_group_order: at most 16384 groups");
+    if (n_groups == 0) return FPCC_OK;
+    if (!group_keys || !perm_out) return fail_arg("conv_group_order: null pointer");
+    hipLaunchKernelGGL(k_group_counting_order, dim3(1), dim3(1024), 0, as_stream(stream), group_keys, (int)n_groups, perm_out);
+    return check_hip(hipGetLastError(), "k_group_counting_order");
 }
 
 extern "C" int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *group_perm, int64_t n, int group,

@@ -52,6 +52,7 @@ _SIGS = {
     'fpcc_deep_factorized_bits_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_tile_keys': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     'fpcc_conv_regroup_rows': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    'fpcc_conv_group_order': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_conv_row_keys': (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     'fpcc_conv_f32_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
@@ -532,7 +533,8 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
         return order
     gkeys = torch.empty(n_groups, dtype=torch.int64, device=nbr.device)
     _ok(L.fpcc_conv_tile_keys(masks.data_ptr(), n_offsets, order.data_ptr(), n, group, gkeys.data_ptr(), _stream()))
-    gperm = sort_keys(gkeys, 32 + 6)[1]
+    gperm = torch.empty(n_groups, dtype=torch.int32, device=nbr.device)
+    _ok(L.fpcc_conv_group_order(gkeys.data_ptr(), n_groups, gperm.data_ptr(), _stream()))
     out = torch.empty_like(order)
     _ok(L.fpcc_conv_regroup_rows(order.data_ptr(), gperm.data_ptr(), n, group, out.data_ptr(), _stream()))
     return out

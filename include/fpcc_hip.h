@@ -193,6 +193,9 @@ int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_
  * up, 32 below) the launch ends with its lightest tiles instead of whichever came last. */
 int fpcc_conv_tile_keys(const uint32_t *row_masks, int n_offsets, const int32_t *row_order, int64_t n, int group,
                         int64_t *keys_out, void *stream);
+/* perm_out[i] = the group with the i-th smallest key of fpcc_conv_tile_keys (n_groups <= 16384): a stable counting sort by the
+ * keys' upper halves in one launch -- same permutation as fpcc_sort_keys on these keys. */
+int fpcc_conv_group_order(const int64_t *group_keys, int64_t n_groups, int32_t *perm_out, void *stream);
 int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *group_perm, int64_t n, int group, int32_t *row_order_out,
                            void *stream);
 /* Workspace the shape needs (0 for most).  Multi-offset convolutions (8 <= n_offsets <= 27, groups == 1, C_out in

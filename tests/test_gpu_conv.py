@@ -432,3 +432,19 @@ def test_persistent_pointwise_kernel_equals_the_other_kernels(knobs, n, c1, c2, 
         ops.conv_set_tuning(ops.KNOB_POINTWISE_ROWS, before)
     assert (_bits(wave) == _bits(base)).all()
     assert (_bits(got) == _bits(base)).all()
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 1023, 1024, 1025, 4999, 16384])
+def test_group_counting_order_equals_a_sort(ops, n):
+    """fpcc_conv_group_order: the stable one-launch counting sort of the heaviest-first tile order gives the permutation of a
+    64-bit sort of the same keys ((lacking offsets) << 32 | group)"""
+    g = torch.Generator().manual_seed(n)
+    lack = torch.randint(0, 28, (n,), generator=g)
+    if n > 10:
+        lack[: n // 3] = 5                                             # long runs of equal weights: stability matters
+    keys = ((lack.to(torch.int64) << 32) | torch.arange(n, dtype=torch.int64)).cuda()
+    perm = torch.empty(n, dtype=torch.int32, device='cuda')
+    from fastpcc_amd.hipops import lib, _ok, _stream
+    _ok(lib().fpcc_conv_group_order(keys.data_ptr(), n, perm.data_ptr(), _stream()))
+    want = torch.argsort(keys)
+    assert torch.equal(perm.long(), want)
