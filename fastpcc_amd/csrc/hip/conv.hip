@@ -1015,12 +1015,13 @@ __global__ __launch_bounds__(256) void k_conv_tile_keys(const uint32_t *__restri
 // Permutation that sorts <= 16384 group keys (fpcc_conv_tile_keys: (lacking offsets) << 32 | group) -- i.e. a STABLE counting sort
 // of the groups by their <= 33 possible weights.  One workgroup, three barriers; replaces a 64-bit merge sort of ~10 launches
 // per coordinate map (rocprim sorts arrays this small with block sort + log2(n / block) merge passes).
+template <int kPer>
 __global__ __launch_bounds__(1024) void k_group_counting_order(const int64_t *__restrict__ keys, int n, int32_t *__restrict__ perm) {
-    constexpr int kBins = 34, kPer = 16;
+    constexpr int kBins = 34;
     __shared__ uint16_t s_wave[16][kBins];
     __shared__ uint32_t s_base[kBins];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (n + 1023) / 1024;                           // consecutive groups per thread (<= 16)
+    const int per = (n + 1023) / 1024;                           // consecutive groups per thread (<= kPer)
     const int g0 = t * per;
     uint8_t bin[kPer];
 #pragma unroll
@@ -1092,7 +1093,10 @@ extern "C" int fpcc_conv_group_order(const int64_t *group_keys, int64_t n_groups
     if (n_groups < 0 || n_groups > 16384) return fail_arg("conv_group_order: at most 16384 groups");
     if (n_groups == 0) return FPCC_OK;
     if (!group_keys || !perm_out) return fail_arg("conv_group_order: null pointer");
-    hipLaunchKernelGGL(k_group_counting_order, dim3(1), dim3(1024), 0, as_stream(stream), group_keys, (int)n_groups, perm_out);
+    const int per = (int)((n_groups + 1023) / 1024);
+    if (per <= 2) hipLaunchKernelGGL(k_group_counting_order<2>, dim3(1), dim3(1024), 0, as_stream(stream), group_keys, (int)n_groups, perm_out);
+    else if (per <= 5) hipLaunchKernelGGL(k_group_counting_order<5>, dim3(1), dim3(1024), 0, as_stream(stream), group_keys, (int)n_groups, perm_out);
+    else hipLaunchKernelGGL(k_group_counting_order<16>, dim3(1), dim3(1024), 0, as_stream(stream), group_keys, (int)n_groups, perm_out);
     return check_hip(hipGetLastError(), "k_group_counting_order");
 }
 
