@@ -37,6 +37,15 @@ bool cdf_well_formed(const uint32_t *c, int64_t len) {
 }
 
 // Writes a stream backwards into [base, base + cap).
+struct RcpTable {
+    uint64_t m[65537];
+    RcpTable() {
+        m[0] = 0;
+        for (uint32_t d = 1; d <= 65536u; ++d) m[d] = ((uint64_t(1) << 47) + d - 1) / d;      // ceil(2^47 / d)
+    }
+};
+static const RcpTable kRcp;
+
 class BackWriter {
 public:
     BackWriter(uint8_t *base, int64_t cap) : base_(base), cur_(base + cap), end_(base + cap), state_(kLow) {}
@@ -51,7 +60,11 @@ public:
             *--cur_ = static_cast<uint8_t>(x);
             x >>= 8;
         }
-        const uint32_t q = x / freq;
+        // x / freq without a divide on the state's dependency chain: x < 2^31 (it is below the ceiling) and freq <= 2^16, so
+        // floor(x * ceil(2^47 / freq) / 2^47) == floor(x / freq) exactly (the error term is < 2^-16 <= 1 / freq); the
+        // reciprocal comes from a 65537-entry table (512 KB, fetched off the chain -- it depends on the symbol, not on x)
+        const uint32_t q = freq <= 65536u ? static_cast<uint32_t>((static_cast<unsigned __int128>(x) * kRcp.m[freq]) >> 47)
+                                          : x / freq;
         state_ = (q << BITS) + (x - q * freq) + start;
     }
 
