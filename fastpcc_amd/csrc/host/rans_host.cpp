@@ -65,7 +65,7 @@ public:
         // reciprocal comes from a 65537-entry table (512 KB, fetched off the chain -- it depends on the symbol, not on x)
         const uint32_t q = freq <= 65536u ? static_cast<uint32_t>((static_cast<unsigned __int128>(x) * kRcp.m[freq]) >> 47)
                                           : x / freq;
-        state_ = (q << BITS) + (x - q * freq) + start;
+        state_ = x + start + q * ((1u << BITS) - freq);           // == (q << BITS) + (x - q * freq) + start, one multiply-add on the chain
     }
 
     // emit the state and return the stream length, or a negative code
@@ -339,14 +339,23 @@ int64_t fpcc_rans_binary_decode(const uint8_t *stream, int64_t stream_len, const
     uint32_t x = uint32_t(stream[0]) | uint32_t(stream[1]) << 8 | uint32_t(stream[2]) << 16 | uint32_t(stream[3]) << 24;
     if (x < kLow && n > 0) return FPCC_HOST_E_ARG;                    // not a state any encoder flushes
     for (int64_t i = 0; i < n; ++i) {
+        // both successor states are formed side by side and the comparison picks one: the dependency chain through x is
+        // shift -> multiply -> add -> select instead of compare -> select frequency -> multiply -> add
         const uint32_t p1 = prob1[i];
         const uint32_t split = kProbOne - p1;
-        const uint32_t slot = x & (kProbOne - 1u);
-        const uint32_t one = slot >= split;                       // 0 / 1
-        const uint32_t mask = 0u - one;                           // 0 / ~0
-        const uint32_t freq = (p1 & mask) | (split & ~mask);
-        const uint32_t start = split & mask;
-        x = freq * (x >> kProbBits) + slot - start;
+        const uint32_t slot = x & (kProbOne - 1u), hi = x >> kProbBits;
+        const uint32_t x0 = split * hi + slot;                    // a zero: range [0, split)
+        const uint32_t x1 = p1 * hi + (slot - split);             // a one:  range [split, 65536)
+        const bool one = slot >= split;
+        // a conditional move, not a branch: the symbol is a coin flip for the predictor wherever the model is unsure
+        // (gcc turns `one ? x1 : x0` into a branch with a multiply on either side)
+#if defined(__x86_64__)
+        uint32_t nx = x0;
+        __asm__("cmp %[split], %[slot]\n\tcmovae %[x1], %[nx]" : [nx] "+r"(nx) : [x1] "r"(x1), [slot] "r"(slot), [split] "r"(split) : "cc");
+        x = nx;
+#else
+        x = x0 ^ ((x0 ^ x1) & (0u - uint32_t(one)));
+#endif
         bits_out[i] = static_cast<uint8_t>(one);
         for (int r = 0; r < kMaxRefill && x < kLow; ++r) {        // bounded: see FrontReader::take
             const uint32_t b = p < end ? *p : 0u;                 // past the end: zeros (garbage out, never out of bounds)

@@ -2,7 +2,8 @@
 """Host binary rANS coder, ns per symbol on occupancy-like probabilities (CPU only; used to judge coder changes).  Round 1, build
 container's CPU: a tabulated-reciprocal quotient and a branch-free refill both measured slower than the divide / the byte loop.
 Round 2, the GPU box's EPYC 9575F: quotient by a 128-bit multiply with a tabulated ceil(2^47 / freq) 2.90 -> 2.30 ns per encoded
-symbol (same bytes); decode 2.44 ns."""
+symbol (same bytes); decode 2.44 -> 1.52 ns by forming both successor states side by side and picking one with a conditional
+move (the chain through the state becomes shift -> multiply -> add -> cmov)."""
 import sys, time, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fastpcc_amd._native import host, host_check
