@@ -56,11 +56,13 @@ __device__ __forceinline__ int32_t table_find(const unsigned long long *keys, co
     return found;
 }
 
+// BF: rows are (batch, x, y, z) -- the layout of the models' coordinate tensors -- instead of the extension's (x, y, z, batch)
+template <bool BF>
 __global__ void k_hash_insert_coords(unsigned long long *keys, int32_t *vals, int cap, const int4 *__restrict__ coords, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int4 c = coords[i];
-    table_insert(keys, vals, cap, coord_hash(c.x, c.y, c.z, c.w), i + 1);
+    table_insert(keys, vals, cap, BF ? coord_hash(c.y, c.z, c.w, c.x) : coord_hash(c.x, c.y, c.z, c.w), i + 1);
 }
 
 __global__ void k_hash_insert_keys(unsigned long long *keys, int32_t *vals, int cap, const int64_t *__restrict__ in, int n) {
@@ -80,6 +82,7 @@ struct I3 { int v[3]; };
 
 // one thread per (output point, kernel offset); offset order of the reference: odd kernel volume -> first axis fastest,
 // even -> last axis fastest; offsets (k % ks) - (ks - 1) / 2
+template <bool BF>
 __global__ void k_hash_lookup_coords(const unsigned long long *keys, const int32_t *vals, int cap,
                                      const int4 *__restrict__ coords, int n, I3 ks, I3 st, int volume,
                                      int32_t *__restrict__ out) {
@@ -88,7 +91,8 @@ __global__ void k_hash_lookup_coords(const unsigned long long *keys, const int32
     if (i >= n) return;
     const int k = (int)(t - i * volume);
     const int4 c = coords[i];
-    const int base[3] = {c.x, c.y, c.z};
+    const int base[3] = {BF ? c.y : c.x, BF ? c.z : c.y, BF ? c.w : c.z};
+    const int batch = BF ? c.x : c.w;
     int q[3];
     int rem = k;
     if (volume & 1) {
@@ -98,7 +102,7 @@ __global__ void k_hash_lookup_coords(const unsigned long long *keys, const int32
 #pragma unroll
         for (int a = 2; a >= 0; --a) { q[a] = base[a] * st.v[a] + rem % ks.v[a] - (ks.v[a] - 1) / 2; rem /= ks.v[a]; }
     }
-    out[i * volume + k] = table_find(keys, vals, cap, coord_hash(q[0], q[1], q[2], c.w));
+    out[i * volume + k] = table_find(keys, vals, cap, coord_hash(q[0], q[1], q[2], batch));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -597,7 +601,7 @@ extern "C" int fpcc_hash_insert_coords(int64_t *table_keys, int32_t *table_vals,
     if (capacity < 1 || capacity > INT32_MAX || n < 0 || n > capacity) return fail_arg("hash_insert_coords: bad capacity / n");
     if (n == 0) return FPCC_OK;
     if (!table_keys || !table_vals || !coords || !aligned16(coords)) return fail_arg("hash_insert_coords: null or unaligned pointer");
-    hipLaunchKernelGGL(k_hash_insert_coords, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(k_hash_insert_coords<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
                        reinterpret_cast<unsigned long long *>(table_keys), table_vals, (int)capacity,
                        reinterpret_cast<const int4 *>(coords), (int)n);
     FPCC_LAUNCHED(k_hash_insert_coords);
@@ -619,7 +623,41 @@ extern "C" int fpcc_hash_lookup_coords(const int64_t *table_keys, const int32_t 
     }
     if (n == 0) return FPCC_OK;
     if (!table_keys || !table_vals || !coords || !out || !aligned16(coords)) return fail_arg("hash_lookup_coords: null or unaligned pointer");
-    hipLaunchKernelGGL(k_hash_lookup_coords, dim3(blocks_for(n * volume, kThreads)), dim3(kThreads), 0, as_stream(stream),
+    hipLaunchKernelGGL(k_hash_lookup_coords<false>, dim3(blocks_for(n * volume, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned long long *>(table_keys), table_vals, (int)capacity,
+                       reinterpret_cast<const int4 *>(coords), (int)n, ks, st, volume, out);
+    FPCC_LAUNCHED(k_hash_lookup_coords);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_insert_coords_bxyz(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int32_t *coords,
+                                       int64_t n, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0 || n > capacity) return fail_arg("hash_insert_coords: bad capacity / n");
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !coords || !aligned16(coords)) return fail_arg("hash_insert_coords: null or unaligned pointer");
+    hipLaunchKernelGGL(k_hash_insert_coords<true>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(table_keys), table_vals, (int)capacity,
+                       reinterpret_cast<const int4 *>(coords), (int)n);
+    FPCC_LAUNCHED(k_hash_insert_coords);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_hash_lookup_coords_bxyz(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity,
+                                       const int32_t *coords, int64_t n, const int32_t *kernel_sizes_host,
+                                       const int32_t *strides_host, int32_t *out, void *stream) {
+    if (capacity < 1 || capacity > INT32_MAX || n < 0 || !kernel_sizes_host || !strides_host)
+        return fail_arg("hash_lookup_coords: bad arguments");
+    I3 ks, st;
+    int volume = 1;
+    for (int a = 0; a < 3; ++a) {
+        ks.v[a] = kernel_sizes_host[a];
+        st.v[a] = strides_host[a];
+        if (ks.v[a] < 1 || st.v[a] < 1) return fail_arg("hash_lookup_coords: kernel sizes and strides must be positive");
+        volume *= ks.v[a];
+    }
+    if (n == 0) return FPCC_OK;
+    if (!table_keys || !table_vals || !coords || !out || !aligned16(coords)) return fail_arg("hash_lookup_coords: null or unaligned pointer");
+    hipLaunchKernelGGL(k_hash_lookup_coords<true>, dim3(blocks_for(n * volume, kThreads)), dim3(kThreads), 0, as_stream(stream),
                        reinterpret_cast<const unsigned long long *>(table_keys), table_vals, (int)capacity,
                        reinterpret_cast<const int4 *>(coords), (int)n, ks, st, volume, out);
     FPCC_LAUNCHED(k_hash_lookup_coords);

@@ -68,6 +68,8 @@ _SIGS = {
     'fpcc_int_init': (_i32, []),
     'fpcc_hash_insert_coords': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
     'fpcc_hash_lookup_coords': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'fpcc_hash_insert_coords_bxyz': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    'fpcc_hash_lookup_coords_bxyz': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     'fpcc_hash_insert_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
     'fpcc_hash_lookup_keys': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_conv_i8': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
@@ -666,14 +668,16 @@ def _mul_u32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def hash_insert_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor) -> None:
-    _ok(lib().fpcc_hash_insert_coords(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+def hash_insert_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor, batch_first: bool = False) -> None:
+    """batch_first: rows are (batch, x, y, z) instead of the extension's (x, y, z, batch); same table either way"""
+    fn = lib().fpcc_hash_insert_coords_bxyz if batch_first else lib().fpcc_hash_insert_coords
+    _ok(fn(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
                                       table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), coords_xyzb.shape[0],
                                       _stream()))
 
 
 def hash_lookup_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor, kernel_size,
-                       stride) -> torch.Tensor:
+                       stride, batch_first: bool = False) -> torch.Tensor:
     """-> int32 [ceil(n/128)*128, volume], entry = input row + 1 or 0 (rows past n are zero), as the reference returns"""
     n = coords_xyzb.shape[0]
     ks = (C.c_int32 * 3)(*[int(v) for v in kernel_size])
@@ -681,9 +685,9 @@ def hash_lookup_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coord
     volume = int(kernel_size[0]) * int(kernel_size[1]) * int(kernel_size[2])
     rows = (n + 127) // 128 * 128
     out = torch.zeros((rows, volume), dtype=torch.int32, device=coords_xyzb.device)
-    _ok(lib().fpcc_hash_lookup_coords(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
-                                      table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), n, ks, st,
-                                      out.data_ptr(), _stream()))
+    fn = lib().fpcc_hash_lookup_coords_bxyz if batch_first else lib().fpcc_hash_lookup_coords
+    _ok(fn(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
+           table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), n, ks, st, out.data_ptr(), _stream()))
     return out
 
 

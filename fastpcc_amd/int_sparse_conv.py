@@ -91,9 +91,9 @@ def _kernel_table(in_coords: torch.Tensor, out_coords: torch.Tensor, kernel_size
         cap = 2 * in_coords.shape[0]
         keys = torch.zeros(cap, dtype=torch.int64, device=in_coords.device)
         vals = torch.zeros(cap, dtype=torch.int32, device=in_coords.device)
-        ops.hash_insert_coords(keys, vals, in_coords.roll(-1, 1))
+        ops.hash_insert_coords(keys, vals, in_coords.contiguous(), batch_first=True)
         hashmap_kv = (keys, vals)
-    table = ops.hash_lookup_coords(hashmap_kv[0], hashmap_kv[1], out_coords.roll(-1, 1), kernel_size, stride)
+    table = ops.hash_lookup_coords(hashmap_kv[0], hashmap_kv[1], out_coords.contiguous(), kernel_size, stride, batch_first=True)
     return hashmap_kv, table
 
 

@@ -347,6 +347,13 @@ int fpcc_hash_insert_coords(int64_t *table_keys, int32_t *table_vals, int64_t ca
 int fpcc_hash_lookup_coords(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, const int32_t *coords,
                             int64_t n, const int32_t *kernel_sizes_host, const int32_t *strides_host, int32_t *out,
                             void *stream);
+/* the same two operations on rows laid out (batch, x, y, z) -- the layout of the models' coordinate tensors; the keys and
+ * therefore the tables are identical (no re-ordering pass over the coordinates) */
+int fpcc_hash_insert_coords_bxyz(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int32_t *coords, int64_t n,
+                                 void *stream);
+int fpcc_hash_lookup_coords_bxyz(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, const int32_t *coords,
+                                 int64_t n, const int32_t *kernel_sizes_host, const int32_t *strides_host, int32_t *out,
+                                 void *stream);
 int fpcc_hash_insert_keys(int64_t *table_keys, int32_t *table_vals, int64_t capacity, const int64_t *keys, int64_t n,
                           void *stream);
 int fpcc_hash_lookup_keys(const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, const int64_t *keys,
