@@ -77,6 +77,7 @@ class PCC(nn.Module):
         ones = torch.ones((xyz.shape[0], 1), dtype=torch.float32, device=xyz.device)
         pc = ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+        pc._fpcc_all_ones = True        # lets the first 3x3x3 layer work from neighbour-presence masks (engine.py)
         # all coarser maps the encoder + lossless pyramid will ask for, built while the stream is still empty
         cm.build_pyramid(pc.coordinate_map_key, len(self.cfg.encoder_channels) - 1 + sum(self.cfg.geo_lossl_if_sample))
         return pc

@@ -839,6 +839,40 @@ int launch_pointwise(const ConvArgs &a, const float *wp, hipStream_t s) {
     }
 }
 
+
+// 3x3x3 convolution of a CONSTANT-ONE one-channel input (the codec's first layer: every voxel carries the feature 1): the sum
+// over the neighbours that exist of w[k][j], in ascending offset order -- the same chain the general kernel evaluates with
+// x = 1 (fmaf(1, w, acc) == acc + w), so the result is bit-identical -- read from the row's 27-bit presence mask instead of
+// the 108-byte neighbour row.  One thread per (row, 4 output columns); weights through LDS.
+__global__ __launch_bounds__(256) void k_conv_ones_k3(const uint32_t *__restrict__ masks, int64_t n, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, int c_out, int act,
+                                                      const float *__restrict__ slope, float clip, float *__restrict__ out, int ldo) {
+    __shared__ float s_w[27 * 32];
+    for (int e = threadIdx.x; e < 27 * c_out; e += 256) s_w[e] = w[e];
+    __syncthreads();
+    const int q4 = c_out / 4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * q4) return;
+    const int64_t o = e / q4;
+    const int j0 = 4 * (int)(e - o * q4);
+    const uint32_t m = masks[o];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        if (m >> k & 1u) {
+            const float *wk = s_w + k * c_out + j0;
+            a0 = fmaf(1.0f, wk[0], a0); a1 = fmaf(1.0f, wk[1], a1); a2 = fmaf(1.0f, wk[2], a2); a3 = fmaf(1.0f, wk[3], a3);
+        }
+    }
+    const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
+    f32x4 r;
+    r.x = finish(a0, bias ? bias[j0] : 0.0f, act, sl, clip);
+    r.y = finish(a1, bias ? bias[j0 + 1] : 0.0f, act, sl, clip);
+    r.z = finish(a2, bias ? bias[j0 + 2] : 0.0f, act, sl, clip);
+    r.w = finish(a3, bias ? bias[j0 + 3] : 0.0f, act, sl, clip);
+    *reinterpret_cast<f32x4 *>(out + o * ldo + j0) = r;
+}
+
 template <int JB>
 int launch_valu(const ConvArgs &a, hipStream_t s) {
     const int n_jb = (a.c_out + JB - 1) / JB;
@@ -873,6 +907,17 @@ extern "C" int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, 
 }
 
 extern "C" int fpcc_numerics_version(void) { return FPCC_NUMERICS_VERSION; }
+
+extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const float *w, const float *bias, int c_out, int act,
+                                     const float *slope, float clip, float *out, int ldo, void *stream) {
+    if (n < 0 || c_out < 4 || c_out > 32 || c_out % 4 || ldo < c_out || ldo % 4) return fail_arg("conv_ones_k3: 4 <= c_out <= 32, multiple of 4");
+    if (n == 0) return FPCC_OK;
+    if (!masks || !w || !out || !aligned16(out)) return fail_arg("conv_ones_k3: null or unaligned pointer");
+    if (act == FPCC_ACT_PRELU && !slope) return fail_arg("conv_ones_k3: PReLU needs a slope pointer");
+    hipLaunchKernelGGL(k_conv_ones_k3, dim3(blocks_for(n * (c_out / 4), 256)), dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out,
+                       act, slope, clip, out, ldo);
+    return check_hip(hipGetLastError(), "k_conv_ones_k3");
+}
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
     if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");

@@ -222,6 +222,9 @@ __global__ void k_nbr27_search(const int64_t *__restrict__ keys, int64_t n, int 
     }
 }
 
+// MASK_ONLY: instead of the 27 neighbour rows, one word per row with bit d set where neighbour d exists (all a convolution of
+// a constant input needs): 4 bytes written per row instead of 108
+template <bool MASK_ONLY>
 __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
                                     const int32_t *__restrict__ pnbr, int64_t m, const int32_t *__restrict__ child_row,
                                     int32_t *__restrict__ nbr) {
@@ -251,6 +254,7 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
             for (int c = 0; c < 8; ++c) kids[(b * 8 + c) * kThreads] = q >= 0 ? q * 8 + c : -1;
         }
     }
+    uint32_t bits = 0;
 #pragma unroll
     for (int d = 0; d < 27; ++d) {
         const int tx = ox + (d % 3) - 1, ty = oy + (d / 3) % 3 - 1, tz = oz + d / 9 - 1;   // in {-1,0,1,2}
@@ -258,8 +262,11 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
         const int bx = (tx + 2) / 2 - ox, by = (ty + 2) / 2 - oy, bz = (tz + 2) / 2 - oz;  // in {0, 1}
         const int b = bx | (by << 1) | (bz << 2);
         const int co = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-        nbr[(int64_t)d * n + i] = kids[(b * 8 + co) * kThreads];
+        const int32_t v = kids[(b * 8 + co) * kThreads];
+        if (MASK_ONLY) bits |= (uint32_t)(v >= 0) << d;
+        else nbr[(int64_t)d * n + i] = v;
     }
+    if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }
 
 template <typename InIt>
@@ -487,8 +494,21 @@ extern "C" int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent
     if (!parent_of && !(child_row == nullptr && n == 8 * m))
         return fail_arg("nbr27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (n == 0) return FPCC_OK;
-    hipLaunchKernelGGL(k_nbr27_from_parent, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+    hipLaunchKernelGGL(k_nbr27_from_parent<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
                        parent_of, n, parent_nbr, m, child_row, nbr);
+    FPCC_LAUNCHED(k_nbr27_from_parent);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_mask27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr,
+                                       int64_t m, const int32_t *child_row, uint32_t *masks_out, void *stream) {
+    if (n < 0 || m < 0 || (n > 0 && (!parent_nbr || !masks_out))) return fail_arg("mask27_from_parent: null pointer");
+    if (!keys && (parent_of || child_row)) return fail_arg("mask27_from_parent: keys may only be omitted for a full generated set");
+    if (!parent_of && !(child_row == nullptr && n == 8 * m))
+        return fail_arg("mask27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_nbr27_from_parent<true>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+                       parent_of, n, parent_nbr, m, child_row, reinterpret_cast<int32_t *>(masks_out));
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
 }

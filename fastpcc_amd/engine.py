@@ -130,7 +130,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key', 'row_order')
+                 'gen_child', 'key', 'row_order', 'mask27')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -139,6 +139,7 @@ class _Map:
         self.child_row: Optional[torch.Tensor] = None     # [parent.n, 8] row of (parent, octant) in THIS map or -1
         self.generated = False                            # all 8 children of every parent row, row = 8p + octant
         self.nbr27: Optional[torch.Tensor] = None
+        self.mask27: Optional[torch.Tensor] = None        # [n] 27-bit neighbour presence (first layer on a constant input)
         self.row_order = False                            # False: not decided; None: natural order; tensor: permutation
         self.coords: Optional[torch.Tensor] = None
         self.gen_child: Optional['_Map'] = None
@@ -281,6 +282,19 @@ class CoordinateManager:
                 else:
                     m.nbr27 = ops.nbr27_search(m.keys, m.bits)
         return m.nbr27
+
+    def _mask27(self, m: _Map) -> Optional[torch.Tensor]:
+        """int32 [n]: which of the 27 neighbours of every row exist, derived from the parent level without building the row table;
+        None where the map has no parent to derive it from (the small top of the pyramid)"""
+        if m.mask27 is None:
+            if m.generated or m.nbr27 is not None:       # the table exists already: the general kernel may as well use it
+                return None
+            if m.parent is None and m.n > self.ROOT_ROWS and m.bits > 1:
+                self._ensure_parent(m)
+            if m.parent is None:
+                return None
+            m.mask27 = ops.mask27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+        return m.mask27
 
     # maps with more rows than this run their 3x3x3 convolutions in neighbour-pattern order (fpcc_conv_row_keys)
     ROW_ORDER_MIN_ROWS = int(os.environ.get('FPCC_ROW_ORDER_MIN_ROWS', '8192'))
@@ -746,6 +760,12 @@ class _ConvBase(nn.Module):
                                    clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None, pack=True)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
+            elif x2 is None and x1.shape[1] == 1 and getattr(x, '_fpcc_all_ones', False) and 4 <= c_out <= 32 and c_out % 4 == 0 \
+                    and ops.conv_order(1, 0, c_out) == 0 and cm._mask27(src) is not None:
+                # the codec's first layer: every voxel carries the feature 1, so a row's sum only depends on WHICH neighbours
+                # exist -- evaluated from 27-bit masks (same FMA chain, same bits); the 108-byte-per-row neighbour table of the
+                # finest level is then never built
+                out = ops.conv_ones_k3(cm._mask27(src), w, c_out, bias=kw['bias'], act=act.kind, slope=act.slope, clip=clip)
             else:
                 mfma = ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out) != 0
                 out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1,

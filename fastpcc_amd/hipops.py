@@ -29,6 +29,8 @@ _SIGS = {
     'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_mask27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_conv_ones_k3_f32': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, C.c_float, _vp, _i32, _vp]),
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
                              _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_f32_pk': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32,
@@ -270,6 +272,31 @@ def nbr27_from_parent(keys: Optional[torch.Tensor], parent_of: Optional[torch.Te
                                      n, _dev(parent_nbr, torch.int32, 'parent_nbr'), m,
                                      _dev(child_row, torch.int32, 'child_row', True), nbr.data_ptr(), _stream()))
     return nbr
+
+
+def mask27_from_parent(keys: Optional[torch.Tensor], parent_of: Optional[torch.Tensor], parent_nbr: torch.Tensor,
+                       child_row: Optional[torch.Tensor], n: Optional[int] = None) -> torch.Tensor:
+    """int32 [n]: bit d set where neighbour d of the row exists (nbr27_from_parent without the table)"""
+    m = parent_nbr.shape[1]
+    n = (8 * m if n is None else n) if keys is None else keys.shape[0]
+    masks = torch.empty(n, dtype=torch.int32, device=parent_nbr.device)
+    _ok(lib().fpcc_mask27_from_parent(_dev(keys, torch.int64, 'keys', True), _dev(parent_of, torch.int32, 'parent_of', True),
+                                      n, _dev(parent_nbr, torch.int32, 'parent_nbr'), m,
+                                      _dev(child_row, torch.int32, 'child_row', True), masks.data_ptr(), _stream()))
+    return masks
+
+
+def conv_ones_k3(masks: torch.Tensor, w: torch.Tensor, c_out: int, *, bias: Optional[torch.Tensor] = None, act: int = 0,
+                 slope: Optional[torch.Tensor] = None, clip: float = 0.0) -> torch.Tensor:
+    """3x3x3 convolution [27, 1, c_out] of the constant-one input from the rows' presence masks (fpcc_conv_ones_k3_f32)"""
+    n = masks.shape[0]
+    if w.numel() != 27 * c_out or not w.is_contiguous():
+        raise ValueError('weights must be contiguous [27, 1, c_out]')
+    out = torch.empty((n, c_out), dtype=torch.float32, device=masks.device)
+    _ok(lib().fpcc_conv_ones_k3_f32(_dev(masks, torch.int32, 'masks'), n, _dev(w, torch.float32, 'w'),
+                                    _dev(bias, torch.float32, 'bias', True), c_out, act, _dev(slope, torch.float32, 'slope', True),
+                                    float(clip), out.data_ptr(), c_out, _stream()))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -99,6 +99,9 @@ int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_
 int fpcc_nbr27_search(const int64_t *keys, int64_t n, int bits, int32_t *nbr, void *stream);
 int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr,
                            int64_t m, const int32_t *child_row, int32_t *nbr, void *stream);
+/* the same derivation, keeping only WHICH of the 27 neighbours exist: masks_out[i] bit d = neighbour d of row i exists */
+int fpcc_mask27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr, int64_t m,
+                            const int32_t *child_row, uint32_t *masks_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Sparse convolution, fp32, output-stationary gather -> MFMA GEMM (no scatter, no atomics, bitwise reproducible) */
@@ -169,6 +172,12 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *      registers (FPCC_POINTWISE_MIN_ROWS, default 32768); 0 = never
  *   4  (NOT result-neutral) rows up to which multi-offset maps are evaluated offset-split = summation order 2; default 8192 */
 int fpcc_conv_set_tuning(int which, int value);
+/* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
+ * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks
+ * (fpcc_mask27_from_parent / fpcc_conv_row_keys) -- the chain of fpcc_conv_f32 with x = 1, bit for bit, without the 27-entry
+ * neighbour rows.  4 <= c_out <= 32, multiple of 4. */
+int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const float *w, const float *bias, int c_out, int act,
+                          const float *slope, float clip, float *out, int ldo, void *stream);
 int fpcc_conv_pack_weights_f32(const float *w, int64_t n_mats, int c_in, int c_out, float *w_packed, void *stream);
 int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2,
                      const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,

@@ -448,3 +448,30 @@ def test_group_counting_order_equals_a_sort(ops, n):
     _ok(lib().fpcc_conv_group_order(keys.data_ptr(), n, perm.data_ptr(), _stream()))
     want = torch.argsort(keys)
     assert torch.equal(perm.long(), want)
+
+
+@pytest.mark.parametrize('c_out', [16, 32, 8])
+def test_constant_one_first_layer_from_presence_masks(ops, scene, c_out):
+    """fpcc_conv_ones_k3_f32 + fpcc_mask27_from_parent: the codec's first layer (every voxel carries the feature 1) evaluated
+    from 27-bit neighbour masks equals the general kernel on the neighbour table bit for bit; the masks equal the table's"""
+    rng = np.random.default_rng(c_out)
+    lvl, table = scene['lvl'], scene['k3']
+    n = lvl.n
+    nbr = _cuda(table)
+    masks = torch.zeros(n, dtype=torch.int32, device='cuda')
+    for k in range(27):
+        masks |= (nbr[k] >= 0).to(torch.int32) << k
+    w = _cuda((rng.normal(size=(27, 1, c_out)) / 4).astype(np.float32))
+    b = _cuda(rng.normal(size=c_out).astype(np.float32))
+    slope = torch.tensor([0.3], device='cuda')
+    ones = torch.ones((n, 1), device='cuda')
+    want = ops.conv_f32(ones, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, bias=b, act=ops.ACT_PRELU, slope=slope)
+    got = ops.conv_ones_k3(masks, w, c_out, bias=b, act=ops.ACT_PRELU, slope=slope)
+    assert (_bits(got.cpu().numpy()) == _bits(want.cpu().numpy())).all()
+    # masks from the parent level == masks of the table
+    from fastpcc_amd import engine as ME
+    cm = ME.CoordinateManager(D=3)
+    key, _ = cm.insert_and_map(torch.from_numpy(lvl.coords.astype(np.int32)).cuda(), 1)
+    m = cm._map(key)
+    derived = cm._mask27(m)
+    assert derived is not None and torch.equal(derived, masks)
