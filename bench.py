@@ -210,6 +210,7 @@ def secondary(device):
     try:
         from fastpcc_amd.codecs.lossl_coord_int import Config, Model
         from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+        torch.cuda.empty_cache()        # every secondary workload starts from its own allocations, not the previous one's cached blocks
         model = Model(Config(), 'cuda'); randomize_(model, 1); model = model.to(device).eval()
         xyz = lidar_cloud(3)
         frame = torch.from_numpy(batched(xyz)).to(device)
@@ -224,7 +225,8 @@ def secondary(device):
         from fastpcc_amd.codecs.lossy_coord_lossy_color import Model as ColorModel
         from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import baseline_r1 as color_cfg
         torch.manual_seed(0)
-        model = ColorModel(color_cfg()); enliven(model, 3, gain=2.3); model = model.to(device).eval()
+        torch.cuda.empty_cache()                    # this frame is twice the headline's size: start from the allocator's own blocks,
+        model = ColorModel(color_cfg()); enliven(model, 3, gain=2.3); model = model.to(device).eval()   # not the previous workload's
         xyz = body_cloud(2048, SCALE[2048], seed=4)
         rng = np.random.default_rng(1)
         base = 127 + 90 * np.stack((np.sin(xyz[:, 0] / 90.0), np.cos(xyz[:, 1] / 70.0), np.sin((xyz[:, 2] + xyz[:, 0]) / 110.0)), 1)
@@ -242,6 +244,7 @@ def secondary(device):
         from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
         from fastpcc_amd.train import TrainConfig, Trainer, synthetic_batches
         tcfg = TrainConfig()
+        torch.cuda.empty_cache()
         torch.manual_seed(0)
         trainer = Trainer(V2(baseline_r1()), tcfg, device)
         data = synthetic_batches(0, 1, tcfg, device, 128)
