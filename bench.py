@@ -225,8 +225,8 @@ def secondary(device):
         from fastpcc_amd.codecs.lossy_coord_lossy_color import Model as ColorModel
         from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import baseline_r1 as color_cfg
         torch.manual_seed(0)
-        torch.cuda.empty_cache()                    # this frame is twice the headline's size: start from the allocator's own blocks,
-        model = ColorModel(color_cfg()); enliven(model, 3, gain=2.3); model = model.to(device).eval()   # not the previous workload's
+        torch.cuda.empty_cache()
+        model = ColorModel(color_cfg()); enliven(model, 3, gain=2.3); model = model.to(device).eval()
         xyz = body_cloud(2048, SCALE[2048], seed=4)
         rng = np.random.default_rng(1)
         base = 127 + 90 * np.stack((np.sin(xyz[:, 0] / 90.0), np.cos(xyz[:, 1] / 70.0), np.sin((xyz[:, 2] + xyz[:, 0]) / 110.0)), 1)

@@ -72,7 +72,12 @@ def set_global_coordinate_manager(cm: 'CoordinateManager'):
 
 
 def clear_global_coordinate_manager():
+    """Drops the global manager.  Its maps are released by reference counting right here (the links that would form reference
+    cycles are cut): left to Python's cyclic collector, the previous frame's tables -- gigabytes on a 2 M-voxel frame -- stay
+    allocated while the next frame is coded, the caching allocator has to grow (a hipMalloc costs 10-25 ms) and its reserve creeps up."""
     global _global_cm
+    if _global_cm is not None:
+        _global_cm._break_cycles()
     _global_cm = None
 
 
@@ -156,9 +161,19 @@ class CoordinateManager:
             raise NotImplementedError('3-D only')
         self._maps: Dict[CoordinateMapKey, _Map] = {}
         self._bits0 = bits            # bits per axis at level 0; fixed on the first insertion
-        self._manager = self          # the reference reaches into `coordinate_manager._manager`
         self._n_batch: Optional[int] = None
         self.device = None
+
+    @property
+    def _manager(self) -> 'CoordinateManager':
+        # the reference reaches into `coordinate_manager._manager` (a property, not an attribute: no self-reference cycle)
+        return self
+
+    def _break_cycles(self) -> None:
+        """a map and the generated set of its children point at each other; cutting the downward link leaves plain parent
+        chains, which reference counting frees as soon as the last tensor on them goes"""
+        for m in self._maps.values():
+            m.gen_child = None
 
     # -- key bookkeeping --------------------------------------------------------------------------------------------
     def _register(self, m: _Map, string_id: str = '') -> CoordinateMapKey:
