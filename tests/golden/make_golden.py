@@ -20,6 +20,8 @@ Sources of truth used:
   hilbert.json   keys of the reference's Hilbert state machine (table read from hilbert3d.cu, loop evaluated on the host)
   codec_v2.json  the reference's lossy_coord_v2 codec (layers / model / geo_lossl_em / ME wrapper layers + its rANS coders) executed on
                  the CPU over a functional MinkowskiEngine stand-in built on oracle/coords.py + conv_mm: streams, reconstructions
+  get_keep.json  the reference's Decoder.get_keep (lossy_coord_v2/layers.py:151-180) executed over the same stand-in on seeded
+                 candidate sets: logits, requested point counts, the keep masks it returned
   codec_color.json / codec_lossl.json  likewise the reference's lossy_coord_lossy_color codec (over the MinkowskiEngine stand-in) and its
                  float LiDAR model lossl_coord incl. train_forward (over the torchsparse stand-in)
   codec_v3.json  the reference's lossy_coord_v3 model executed on the CPU over a functional torchsparse stand-in (kernel-offset
@@ -1335,6 +1337,67 @@ def make_codec_v2():
     return out
 
 
+def make_get_keep():
+    """The reference's adaptive pruning rule `Decoder.get_keep` (models/convolutional/lossy_coord_v2/layers.py:151-180) EXECUTED
+    over the MinkowskiEngine stand-in on the situation the decoder is in when it calls it: logits on the generated children of
+    a PRUNED stride-2 map whose stride-4 parents exist too.  The fixture is data: coordinates, logits, requested point counts
+    and the keep masks the reference returned (candidates listed with their coordinates, so a consumer matches rows by
+    coordinate and does not depend on any row order)."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    _stub_engines()
+    ME = _functional_minkowski()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossy_coord_v2.layers import Decoder
+    finally:
+        ce.load = real
+    from fastpcc_amd.synthetic import surface_cloud
+    dec = Decoder(8, (8,), 'HYPER_CUBE', 'prelu').eval()
+    cases = []
+    for label, seed, batch in (('one_cloud_a', 1, 1), ('one_cloud_b', 2, 1), ('two_clouds', 7, 2)):
+        g = torch.Generator().manual_seed(seed)
+        clouds = [np.concatenate((np.full((len(x), 1), b), x), 1) for b, x in
+                  enumerate(np.unique(surface_cloud(seed + b, 32, 900) // 4 * 4, axis=0) for b in range(batch))]
+        top_c = torch.from_numpy(np.concatenate(clouds)).to(torch.int32)
+        cm = ME.CoordinateManager(D=3)
+        top = ME.SparseTensor(torch.ones((len(top_c), 1)), coordinates=top_c, tensor_stride=4, coordinate_manager=cm)
+        up = ME.MinkowskiGenerativeConvolutionTranspose(1, 1, 2, 2, bias=False, dimension=3)
+        with torch.no_grad():
+            mid = up(top)                                                         # all 8 children at stride 2: key (2, '')
+            mask = torch.rand(mid.F.shape[0], generator=g) < 0.4
+            mask[::8] = True                                                      # every parent keeps a child
+            mid = ME.MinkowskiPruning()(mid, mask)                                # key (2, 'pruned')
+            cand = up(mid)                                                        # candidates at stride 1
+        logits = torch.randn((cand.F.shape[0], 1), generator=g)
+        pred = ME.SparseTensor(logits, coordinate_map_key=cand.coordinate_map_key, coordinate_manager=cm)
+        assert sorted(k.get_key()[1] for k in cm.get_coordinate_map_keys([2, 2, 2])) == ['', 'pruned']
+        n = logits.shape[0]
+        if batch == 1:
+            targets = [[mid.F.shape[0]], [n // 3], [n - 9], None]
+        else:
+            sizes = [p.numel() for p in pred.decomposition_permutations]
+            targets = [[sizes[0] // 4, sizes[1] // 2], None]
+        keeps = []
+        for t in targets:
+            keep = dec.get_keep(pred, None if t is None else [list(t)], [2, 2, 2])
+            keeps.append({'points_num': t, 'keep': np.packbits(keep.numpy().astype(np.uint8)).tobytes().hex(), 'kept': int(keep.sum())})
+        i16 = lambda t: np.ascontiguousarray(t.numpy().astype('<i2')).tobytes().hex()        # [n, 4] (batch, x, y, z), little-endian int16
+        cases.append({'label': label, 'seed': seed, 'batch': batch, 'top_coords_i16': i16(top_c), 'mid_coords_i16': i16(mid.C),
+                      'cand_coords_i16': i16(pred.C), 'logits_f32': np.ascontiguousarray(logits.view(-1).numpy().astype('<f4')).tobytes().hex(),
+                      'queries': keeps})
+        print('get_keep', label, n, 'candidates', [q['kept'] for q in keeps])
+    return {'cases': cases}
+
+
 def make_codec_color():
     """The reference's joint geometry + colour codec (models/convolutional/lossy_coord_lossy_color) EXECUTED on the CPU over the
     MinkowskiEngine stand-in of make_codec_v2 with the reference's rANS coders: streams and reconstructions of seeded runs."""
@@ -1459,7 +1522,7 @@ def make_codec_lossl():
 
 
 def main():
-    for name, fn in (('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

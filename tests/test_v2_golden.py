@@ -59,3 +59,24 @@ def test_reference_run(run):
         assert abs(len(oracle.decompress(data)) - len(run['recon'])) <= 0.02 * len(run['recon'])
     if cfg.adaptive_pruning:
         assert len(run['recon']) == len(xyz)
+
+
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'get_keep.json')) as f:
+    KEEP = json.load(f)['cases']
+
+
+@pytest.mark.parametrize('case', [c for c in KEEP if c['batch'] == 1], ids=[c['label'] for c in KEEP if c['batch'] == 1])
+def test_oracle_pruning_rule_equals_the_reference_masks(case):
+    """oracle get_keep against the masks the reference's Decoder.get_keep (layers.py:151-180) returned (get_keep.json)"""
+    from oracle import coords as oc
+    from oracle.codec_v2 import Feature
+    i16 = lambda h: np.frombuffer(bytes.fromhex(h), dtype='<i2').reshape(-1, 4).astype(np.int64)
+    cand_c = i16(case['cand_coords_i16'])
+    cand, cells = oc.Level(cand_c, 1), oc.Level(i16(case['mid_coords_i16']), 2)
+    logits = np.frombuffer(bytes.fromhex(case['logits_f32']), dtype='<f4')
+    pred = Feature(torch.from_numpy(logits[cand.order].copy()).view(-1, 1), cand)
+    oracle = OracleV2.__new__(OracleV2)                       # the rule needs no weights
+    for q in case['queries']:
+        want = np.unpackbits(np.frombuffer(bytes.fromhex(q['keep']), dtype=np.uint8))[:len(logits)].astype(bool)[cand.order]
+        got = oracle.get_keep(pred, cells, None if q['points_num'] is None else q['points_num'][0])
+        assert (got == want).all() and int(got.sum()) == q['kept']
