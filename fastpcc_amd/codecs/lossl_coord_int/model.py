@@ -343,7 +343,10 @@ class Model(nn.Module):
         if self.device_decoder:
             # the CDF rows stay where they were made: one wave decodes the level's symbols on the device, 4 bytes come back
             sym, children = ops.simple_dec_pop_dev(self._dev_state, self._dev_stream, self._dev_stream_len, rows_d)
-            sym._fpcc_children = int(children.item())
+            count, status = children.tolist()                 # the level's one read-back: children + the decoder's status word
+            if status != 0:
+                raise ValueError(f'corrupt occupancy stream (device decoder status {status})')
+            sym._fpcc_children = int(count)
             return sym
         rows_h = torch.empty(rows_d.shape, dtype=rows_d.dtype, pin_memory=True)
         out_h = torch.empty(n, dtype=torch.int16, pin_memory=True)

@@ -608,7 +608,9 @@ int launch_split(ConvArgs a, hipStream_t s) {
     return check_hip(hipGetLastError(), "k_split_reduce");
 }
 
-// Tuning knobs (fpcc_conv_set_tuning; initial values from the environment): none of them changes a result.
+// Tuning knobs (fpcc_conv_set_tuning; initial values from the environment).  None of them changes a result EXCEPT
+// kKnobSplitRows, which selects summation order 2 vs 1 and is therefore part of the stream format: it has no environment
+// variable, and fpcc_conv_set_tuning refuses it unless the process runs with FPCC_EXPERIMENT=1.
 enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
        kKnobCount = 7 };
 int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1};
@@ -617,7 +619,7 @@ int knob(int k) {
         static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS",
                                                 "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS"};
         static const int defaults[kKnobCount] = {1, 0, 1, 0, FPCC_SPLIT_MAX_ROWS, 0, 32 * 1024};
-        const char *e = getenv(names[k]);
+        const char *e = k == kKnobSplitRows ? nullptr : getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
     return g_knob[k];
@@ -886,8 +888,8 @@ int launch_valu(const ConvArgs &a, hipStream_t s) {
 using namespace fpcc;
 
 // rows up to which multi-offset convolutions are evaluated offset-split (workspace: n_offsets * n_out * c_out floats).
-// NOT a tuning knob in production: it selects summation order 2 vs 1, i.e. the bits of the result (FPCC_SPLIT_MAX_ROWS /
-// knob 4 exist for experiments; encoder and decoder must agree on it).
+// NOT a tuning knob in production: it selects summation order 2 vs 1, i.e. the bits of the result (knob 4 exists for
+// experiments under FPCC_EXPERIMENT=1; encoder and decoder must agree on it).
 #define kSplitMaxRows ((int64_t)knob(kKnobSplitRows))
 
 static bool use_split(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
@@ -921,6 +923,11 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
     if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");
+    if (which == kKnobSplitRows) {
+        const char *e = getenv("FPCC_EXPERIMENT");
+        if (!e || atoi(e) != 1)
+            return fail_arg("conv_set_tuning: the offset-split threshold is part of the stream format (FPCC_EXPERIMENT=1 to override)");
+    }
     const int before = knob(which);
     g_knob[which] = value < 0 ? 0 : value;
     return before;

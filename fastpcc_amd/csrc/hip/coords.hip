@@ -16,6 +16,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
+#include <atomic>
 
 namespace fpcc {
 namespace {
@@ -332,12 +333,20 @@ extern "C" int fpcc_hilbert3d_encode(const int32_t *coords, int64_t n, int64_t r
         return fail_arg("hilbert3d_encode: column outside the row");
     if (n == 0) return FPCC_OK;
     if (!coords || !keys_out) return fail_arg("hilbert3d_encode: null pointer");
-    static const int ready = [] {
-        uint8_t tab[96];
-        build_hilbert_table(tab);
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hilbert), tab, sizeof(tab));
-    }();
-    if (ready != (int)hipSuccess) return check_hip((hipError_t)ready, "hilbert table upload");
+    // g_hilbert is one symbol PER DEVICE: upload on first use on each device, stream-ordered before the kernel
+    static std::atomic<bool> uploaded[64];
+    static uint8_t tab[96];
+    static const bool built = (build_hilbert_table(tab), true);
+    (void)built;
+    int dev = 0;
+    if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    if (dev < 0 || dev >= 64) return fail_arg("hilbert3d_encode: device index out of range");
+    if (!uploaded[dev].load(std::memory_order_acquire)) {
+        if (int rc = check_hip(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_hilbert), tab, sizeof(tab), 0, hipMemcpyHostToDevice, as_stream(stream)),
+                               "hilbert table upload")) return rc;
+        if (int rc = check_hip(hipStreamSynchronize(as_stream(stream)), "hilbert table upload")) return rc;
+        uploaded[dev].store(true, std::memory_order_release);
+    }
     hipLaunchKernelGGL(k_hilbert, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), coords, n, row_stride,
                        col_x, col_y, col_z, bits, keys_out);
     FPCC_LAUNCHED(k_hilbert);

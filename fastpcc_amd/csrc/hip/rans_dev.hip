@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64) void k_simple_dec_pop(int32_t *__restrict__ sta
     uint32_t cur[4], nxt[4];
     load_row(0, cur);
     int children = 0;
+    // sticky status word state[3]: 1 = state below the renormalisation bound on entry (not a rANS state), 2 = a CDF row that is
+    // not increasing at the decoded symbol, 4 = read past the end of the stream (beyond the zero slack a valid stream may touch)
+    int bad = x < kLow ? 1 : 0;
     uint32_t sym_keep = 0;                               // lane (i % 64) keeps symbol i until the 64-wide store
     for (int64_t i = 0; i < n; ++i) {
         load_row(i + 1, nxt);
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(64) void k_simple_dec_pop(int32_t *__restrict__ sta
             lo = va;
             hi = vb;
         }
+        bad |= hi <= lo ? 2 : 0;
         x = (hi - lo) * (x >> 16) + slot - lo;
 #pragma unroll 1
         for (int r = 0; r < 3 && x < kLow; ++r) {
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(64) void k_simple_dec_pop(int32_t *__restrict__ sta
         state[0] = (int32_t)x;
         state[1] = (int32_t)(uint32_t)pos;
         state[2] = (int32_t)(uint32_t)(pos >> 32);
-        if (children_out) *children_out = children;
+        state[3] |= bad | (pos > stream_len + 4 ? 4 : 0);
+        if (children_out) { children_out[0] = children; children_out[1] = state[3]; }
     }
 }
 

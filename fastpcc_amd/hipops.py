@@ -393,7 +393,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     if om_os == 0:
         om_os = groups
     ws, ws_bytes = None, 0
-    if n_offsets >= 8 and nbr is not None and n_out <= 65536:
+    if nbr is not None:                                        # the library alone decides which shapes are evaluated offset-split
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
@@ -436,8 +436,11 @@ def knn3d(p1: torch.Tensor, p2: torch.Tensor, K: int, version: int = -1):
         raise ValueError('points must be [n, 3]')
     idx = torch.empty((p1.shape[0], K), dtype=torch.int64, device=p1.device)
     dist = torch.empty((p1.shape[0], K), dtype=torch.float32, device=p1.device)
-    _ok(lib().fpcc_knn3d(_dev(p1.float().contiguous(), torch.float32, 'p1', p1.numel() == 0), p1.shape[0],
-                         _dev(p2.float().contiguous(), torch.float32, 'p2', p2.numel() == 0), p2.shape[0], int(K),
+    # the converted copies must outlive the launch: a temporary freed after taking its address can be handed out again by the
+    # caching allocator for the second conversion
+    p1f, p2f = p1.float().contiguous(), p2.float().contiguous()
+    _ok(lib().fpcc_knn3d(_dev(p1f, torch.float32, 'p1', p1f.numel() == 0), p1f.shape[0],
+                         _dev(p2f, torch.float32, 'p2', p2f.numel() == 0), p2f.shape[0], int(K),
                          idx.data_ptr(), dist.data_ptr(), _stream()))
     return idx, dist
 
@@ -854,11 +857,11 @@ def rans_binary_decode_dev(stream: torch.Tensor, stream_len: int, prob16: torch.
 
 
 def simple_dec_pop_dev(state: torch.Tensor, stream: torch.Tensor, stream_len: int, rows: torch.Tensor):
-    """rows int16 [n, width] (uint16 CDF rows of fpcc_logits_to_cdf16) -> (symbols int16 [n], children int32 [1]) on the
-    device; `state` (int32 [4]) is advanced"""
+    """rows int16 [n, width] (uint16 CDF rows of fpcc_logits_to_cdf16) -> (symbols int16 [n], int32 [2] = {children, sticky
+    status word (0 = fine)}) on the device; `state` (int32 [4]) is advanced"""
     n, width = rows.shape
     sym = torch.empty(n, dtype=torch.int16, device=rows.device)
-    children = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    children = torch.zeros(2, dtype=torch.int32, device=rows.device)
     _ok(lib().fpcc_simple_dec_pop_dev(_dev(state, torch.int32, 'state'), _dev(stream, torch.uint8, 'stream'), int(stream_len),
                                       _dev(rows, torch.int16, 'rows', n == 0), n, width, sym.data_ptr(), n, children.data_ptr(), _stream()))
     return sym, children

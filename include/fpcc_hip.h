@@ -437,9 +437,11 @@ int fpcc_rans_binary_decode_dev(const uint8_t *stream, int64_t stream_len, const
                                 uint8_t *bits_out, int32_t *ones_out, int32_t *status, void *hip_stream);
 /* RansDecoder.decode of simple_rans_ext_cpp (models/convolutional/lossy_coord_v3/rans_coder/simple_rans_wrapper.cpp:206-239)
  * on the device: rows uint16 [n | 1][width <= 256] as fpcc_logits_to_cdf16 writes them, state int32[4] = {x, position low,
- * position high, -} carried from launch to launch (initialise from fpcc_simple_dec_tell of libfpcc_host or from the
- * stream's first four bytes with position 4).  children_out[0] (may be NULL) = sum of popcount(symbol + 1), the number of
- * occupied children of the level. */
+ * position high, status} carried from launch to launch (initialise from fpcc_simple_dec_tell of libfpcc_host or from the
+ * stream's first four bytes with position 4, status 0).  children_out (int32[2], may be NULL): [0] = sum of
+ * popcount(symbol + 1), the number of occupied children of the level; [1] = the sticky status word state[3]: 0 fine, bit 0 the
+ * state on entry is not a rANS state (< 2^23), bit 1 a CDF row does not increase at the decoded symbol, bit 2 the decoder read
+ * past the end of the stream. */
 int fpcc_simple_dec_pop_dev(int32_t *state, const uint8_t *stream, int64_t stream_len, const uint16_t *rows,
                             int64_t n_rows, int64_t width, uint16_t *symbols_out, int64_t n, int32_t *children_out,
                             void *hip_stream);

@@ -114,3 +114,19 @@ def test_knn3d_matches_a_dense_distance_matrix(K):
     assert torch.allclose(at, d2, rtol=1e-5, atol=1e-3)
     few_idx, few_d = ops.knn3d(p1[:5], p2[:2], 3)                       # fewer candidates than K: -1 / inf fill
     assert (few_idx[:, 2] == -1).all() and torch.isinf(few_d[:, 2]).all() and (few_idx[:, :2] >= 0).all()
+
+
+def test_knn3d_takes_integer_and_strided_inputs():
+    """inputs that need a conversion copy (int32 voxel coordinates, a non-contiguous view): the copies must stay alive until
+    the launch -- same sizes on both sides make the caching allocator most likely to hand one block out twice otherwise"""
+    from fastpcc_amd import hipops as ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(0, 200, (2000, 3), generator=g, dtype=torch.int32).cuda()
+    b = torch.randint(0, 200, (2000, 3), generator=g, dtype=torch.int32).cuda()
+    idx, d2 = ops.knn3d(a, b, 4)
+    ref = (torch.cdist(a.double(), b.double()) ** 2).topk(4, dim=1, largest=False).values
+    assert torch.equal(d2.double(), ref)                                    # integer coordinates: exact
+    wide = torch.randint(0, 200, (2000, 6), generator=g, dtype=torch.int32).cuda()
+    idx2, d3 = ops.knn3d(wide[:, ::2], wide[:, 1::2], 2)
+    ref2 = (torch.cdist(wide[:, ::2].double(), wide[:, 1::2].double()) ** 2).topk(2, dim=1, largest=False).values
+    assert torch.equal(d3.double(), ref2)

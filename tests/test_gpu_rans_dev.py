@@ -76,7 +76,7 @@ def test_row_decoder_on_the_reference_golden_streams():
                 rows = np.repeat(rows, len(blk['symbols']), 0)
             sym, children = ops.simple_dec_pop_dev(state, dev_stream, len(stream), torch.from_numpy(rows.view(np.int16)).cuda())
             assert sym.cpu().numpy().view(np.uint16).tolist() == blk['symbols']
-            assert int(children.item()) == sum(bin((s + 1) & 255).count('1') for s in blk['symbols'])
+            assert children.tolist() == [sum(bin((s + 1) & 255).count('1') for s in blk['symbols']), 0]      # count, status word
             done += 1
     assert done > 0
 
@@ -109,8 +109,16 @@ def test_row_decoder_continues_a_host_decoder_mid_stream(n):
     state = torch.tensor([x - (1 << 32) if x >= 1 << 31 else x, pos, 0, 0], dtype=torch.int32).cuda()
     dev_stream = ops.stream_to_device(stream, 'cuda')
     for rows, want in (blocks[1], blocks[0]):
-        sym, _ = ops.simple_dec_pop_dev(state, dev_stream, len(stream), torch.from_numpy(rows.view(np.int16)).cuda())
-        assert (sym.cpu().numpy().view(np.uint16) == want).all()
+        sym, info = ops.simple_dec_pop_dev(state, dev_stream, len(stream), torch.from_numpy(rows.view(np.int16)).cuda())
+        assert (sym.cpu().numpy().view(np.uint16) == want).all() and int(info[1]) == 0
+    # a state that is not a rANS state, and a CDF row that does not increase: flagged in the sticky status word, no crash
+    bad_state = torch.tensor([5, 4, 0, 0], dtype=torch.int32).cuda()
+    _, info = ops.simple_dec_pop_dev(bad_state, dev_stream, len(stream), torch.from_numpy(blocks[0][0].view(np.int16)).cuda())
+    assert int(info[1]) & 1 and int(bad_state[3]) & 1
+    flat = np.full((200, 255), 20000, dtype=np.uint16)      # a third of the slots fall between two equal edges
+    flat[:, 0] = 40000
+    _, info = ops.simple_dec_pop_dev(_state(stream, ops), dev_stream, len(stream), torch.from_numpy(flat.view(np.int16)).cuda())
+    assert int(info[1]) & 2
 
 
 def test_v2_decompress_with_the_device_decoder_reconstructs_the_same_cloud():
