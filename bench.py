@@ -32,7 +32,9 @@ def parse():
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing on rank 0')
     ap.add_argument('--cpu-resolution', type=int, default=512, help='resolution of the CPU sample (same generator; 1024 = the benchmarked frame itself)')
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
-    ap.add_argument('--secondary', type=int, default=1, help='0 skips the cfg#3 / #4 / #5 figures reported next to the headline (N = 1 only)')
+    ap.add_argument('--secondary', type=int, default=1, help='0 skips the figures reported next to the headline: cfg#3 / #4 / #5 at N = 1, '
+                                                             'the cfg#5 DDP training step over all N ranks at N > 1')
+    ap.add_argument('--ddp-steps', type=int, default=10, help='optimisation steps of the cfg#5 DDP figure (N > 1)')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
 
@@ -356,6 +358,23 @@ def main():
     from fastpcc_amd.evaluators import d1_metrics
     quality = d1_metrics(frame[:, 1:], rec, args.resolution)
 
+    # N > 1: the training configuration (cfg#5) shards over the same ranks -- global batch 8 split 8 / N, gradients
+    # all-reduced over RCCL by DDP -- so the driver's own `bench.py --gpus N` runs produce the DDP curve next to the replica
+    # curve.  Collective over all ranks, after (outside) the timed region of the headline metric.
+    ddp_record = None
+    if args.secondary and world > 1:
+        n_bytes = len(data)
+        del model, rec
+        ME.clear_global_coordinate_manager()
+        torch.cuda.empty_cache()
+        from fastpcc_amd.train import ddp_training_record
+        try:
+            ddp_record = ddp_training_record(args.ddp_steps, 3, device)
+        except Exception as e:                                           # the headline number must survive a secondary failure
+            ddp_record = {'error': repr(e)[:200]}
+    else:
+        n_bytes = len(data)
+
     if rank == 0:
         # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
         cache = {}
@@ -401,7 +420,7 @@ def main():
                                    f'body-surface frame per GPU (cfg#2), seeded random-init weights',
                        'parallelism': f'replicas x{world} (independent frames)' if world > 1 else 'single GPU',
                        'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
-                       'bytes': len(data), 'bpp': round(8 * len(data) / n_points, 4),
+                       'bytes': n_bytes, 'bpp': round(8 * n_bytes / n_points, 4),
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
                        'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -421,6 +440,8 @@ def main():
         if args.secondary and world == 1:
             del model, frame
             out['config']['secondary'] = secondary(device)
+        elif ddp_record is not None:
+            out['config']['secondary'] = {'cfg5_training_ddp': ddp_record}
         if cpu_job is not None:
             out['cpu_baseline'] = cpu_job.result()
         print(json.dumps(out))

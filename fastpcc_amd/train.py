@@ -177,22 +177,13 @@ def synthetic_batches(rank: int, world: int, cfg: TrainConfig, device: torch.dev
         yield PCData(xyz=coords, batch_size=per_rank, resolution=[resolution] * per_rank)
 
 
-def bench(steps: int, warmup: int, gpus: int, resolution: int = 128, cfg: Optional[TrainConfig] = None) -> Optional[dict]:
-    """times `steps` optimisation steps of lossy_coord_v2/baseline_r1 on synthetic ShapeNet-like batches; rank 0 returns
-    the result record, other ranks None"""
-    from .codecs.lossy_coord_v2 import Model
-    from .codecs.lossy_coord_v2.model_config import baseline_r1
-    cfg = cfg or TrainConfig()
-    rank, world, local = replicas.env_rank()
-    if world != gpus:
-        raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={world}')
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    replicas.init('nccl')
-    torch.manual_seed(0)                                  # same initial weights on every rank
-    trainer = Trainer(Model(baseline_r1()), cfg, device)
-    data = synthetic_batches(rank, world, cfg, device, resolution)
-    torch.manual_seed(1000 + rank)                        # different bottleneck noise per rank
+def ddp_bench(trainer: Trainer, data: Iterator[PCData], steps: int, warmup: int, device: torch.device,
+              units_per_step: float) -> Tuple[float, float, Optional[float], Optional[Dict[str, float]]]:
+    """Times `steps` optimisation steps of an already constructed (DDP-wrapped when world > 1) trainer on EVERY rank of the
+    process group: barrier, K steps, barrier, max over ranks.  Then -- when gradients are all-reduced -- the same steps once
+    more under `no_sync`, which prices the communication that the overlap with the backward pass does not hide.  Collective:
+    all ranks must call it.  Returns (seconds of the timed region (max over ranks), voxels summed over ranks and steps,
+    exposed all-reduce ms per step | None, the last step's logged terms)."""
     voxels = 0
     for _ in range(warmup):
         trainer.step(next(data))
@@ -201,12 +192,10 @@ def bench(steps: int, warmup: int, gpus: int, resolution: int = 128, cfg: Option
     last = None
     for _ in range(steps):
         batch = next(data)
-        voxels += batch.xyz.shape[0]
+        voxels += batch.xyz.shape[0] if batch.xyz.dim() == 2 else 0
         last = trainer.step(batch)
     replicas.barrier(device)
-    elapsed = time.perf_counter() - t0
-    elapsed_max, total_voxels = replicas.aggregate(elapsed, float(voxels), device)
-    # exposed communication: the same steps with the gradient all-reduce switched off
+    elapsed_max, total_voxels = replicas.aggregate(time.perf_counter() - t0, float(voxels), device)
     comm_ms = None
     if isinstance(trainer.model, DDP):
         replicas.barrier(device)
@@ -223,16 +212,59 @@ def bench(steps: int, warmup: int, gpus: int, resolution: int = 128, cfg: Option
         comm_ms = max(0.0, (elapsed_max - local_only) / steps * 1e3)
     if dist.is_initialized():
         dist.barrier()
+    return elapsed_max, total_voxels, comm_ms, last
+
+
+def ddp_training_record(steps: int, warmup: int, device: torch.device, resolution: int = 128,
+                        cfg: Optional[TrainConfig] = None) -> Optional[dict]:
+    """cfg#5 on the ranks of the EXISTING process group (bench.py --gpus N calls this after its replica timing, so the
+    driver's own scaling command produces the DDP figure too): lossy_coord_v2/baseline_r1, global batch 8 split 8 / N per
+    rank, gradients all-reduced over RCCL by DDP.  Collective; rank 0 returns the record, other ranks None."""
+    from .codecs.lossy_coord_v2 import Model
+    from .codecs.lossy_coord_v2.model_config import baseline_r1
+    cfg = cfg or TrainConfig()
+    rank, world, _ = replicas.env_rank()
+    if cfg.batch_size % world:
+        return {'skipped': f'global batch {cfg.batch_size} does not divide over {world} ranks'} if rank == 0 else None
+    torch.manual_seed(0)                                  # same initial weights on every rank
+    trainer = Trainer(Model(baseline_r1()), cfg, device)
+    data = synthetic_batches(rank, world, cfg, device, resolution)
+    torch.manual_seed(1000 + rank)                        # different bottleneck noise per rank
+    elapsed_max, total_voxels, comm_ms, last = ddp_bench(trainer, data, steps, warmup, device, cfg.batch_size)
     if rank != 0:
         return None
     n_param = sum(p.numel() for p in unwrap(trainer.model).parameters())
-    return {'metric': 'training clouds/sec, lossy_coord_v2 baseline_r1 (DDP)', 'value': round(cfg.batch_size * steps / elapsed_max, 3),
+    return {'workload': f'lossy_coord_v2/baseline_r1 optimisation step, global batch {cfg.batch_size} ShapeNet-like clouds at '
+                        f'{resolution}^3 (cfg#5), {cfg.batch_size // world} per rank, forward + backward + all-reduce + AdamW',
+            'ranks': world, 'parallelism': f'ddp{world}', 'ms_per_step': round(elapsed_max / steps * 1e3, 2),
+            'clouds_per_s': round(cfg.batch_size * steps / elapsed_max, 3), 'voxels_per_step': round(total_voxels / steps),
+            'exposed_allreduce_ms_per_step': None if comm_ms is None else round(comm_ms, 2),
+            'parameters': n_param, 'gradient_bytes': 4 * n_param, 'steps': steps, 'warmup': warmup,
+            'last_loss': None if last is None else round(last['loss'], 2)}
+
+
+def bench(steps: int, warmup: int, gpus: int, resolution: int = 128, cfg: Optional[TrainConfig] = None) -> Optional[dict]:
+    """times `steps` optimisation steps of lossy_coord_v2/baseline_r1 on synthetic ShapeNet-like batches; rank 0 returns
+    the result record, other ranks None"""
+    cfg = cfg or TrainConfig()
+    rank, world, local = replicas.env_rank()
+    if world != gpus:
+        raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    replicas.init('nccl')
+    rec = ddp_training_record(steps, warmup, device, resolution, cfg)
+    if rank != 0:
+        return None
+    if 'skipped' in rec:
+        raise SystemExit(rec['skipped'])
+    return {'metric': 'training clouds/sec, lossy_coord_v2 baseline_r1 (DDP)', 'value': rec['clouds_per_s'],
             'unit': 'clouds/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
-            'ms_per_step': round(elapsed_max / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
+            'ms_per_step': rec['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'lossy_coord_v2/baseline_r1 training, global batch {cfg.batch_size} ShapeNet-like clouds at '
                                    f'{resolution}^3 (cfg#5), {cfg.batch_size // world} per rank',
-                       'parallelism': f'ddp{world}', 'voxels_per_step': round(total_voxels / steps),
-                       'parameters': n_param, 'gradient_bytes': 4 * n_param,
-                       'exposed_allreduce_ms_per_step': None if comm_ms is None else round(comm_ms, 2),
-                       'last_loss': None if last is None else round(last['loss'], 2)}}
+                       'parallelism': f'ddp{world}', 'voxels_per_step': rec['voxels_per_step'],
+                       'parameters': rec['parameters'], 'gradient_bytes': rec['gradient_bytes'],
+                       'exposed_allreduce_ms_per_step': rec['exposed_allreduce_ms_per_step'],
+                       'last_loss': rec['last_loss']}}

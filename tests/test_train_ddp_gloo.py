@@ -88,6 +88,43 @@ def test_two_rank_ddp_step():
     assert any((g0[k] != g1[k]).any() for k in g0)     # ... although their local gradients differed
 
 
+def _bench_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import itertools
+    import torch.distributed as dist
+    from fastpcc_amd import replicas
+    from fastpcc_amd.train import TrainConfig, Trainer, ddp_bench
+    replicas.init('gloo')
+    torch.manual_seed(0)
+    tr = Trainer(Toy(), TrainConfig(batch_size=2, max_grad_norm=(0.0, 0.0)), torch.device('cpu'))
+    data = (_data(rank, i) for i in itertools.count())
+    elapsed, units, comm_ms, last = ddp_bench(tr, data, steps=3, warmup=1, device=torch.device('cpu'), units_per_step=2)
+    q.put((rank, elapsed, comm_ms, last['loss'], tr.optimisation_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bench_is_one_collective_measurement_over_all_ranks():
+    """what `bench.py --gpus N` (N > 1) runs for the cfg#5 figure: every rank times the same K steps between barriers, the
+    maximum over ranks is the step time, and the steps are repeated without gradient synchronisation to price the all-reduce"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, e0, c0, l0, s0), (_, e1, c1, l1, s1) = got
+    assert e0 == e1 > 0                                # the max over ranks, identical on both
+    assert c0 is not None and c0 == c1 and c0 >= 0     # exposed all-reduce time: measured because the model is DDP-wrapped
+    assert s0 == s1 == 4                               # 1 warm-up + 3 timed optimisation steps (the no_sync pass does not update)
+    assert isinstance(l0, float) and isinstance(l1, float)
+
+
 def test_single_process_trainer_updates_and_schedules():
     from fastpcc_amd.train import TrainConfig, Trainer
     torch.manual_seed(0)
