@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from ... import engine as ME
 from ... import hipops as ops
 from ...sparse_conv_layers import ConvBlock, ConvTransBlock, GenConvTransBlock, MEMLPBlock, \
-    NNSequentialWithConvBlockArgs, NNSequentialWithConvTransBlockArgs
+    NNSequentialWithConvBlockArgs, NNSequentialWithConvTransBlockArgs, mlp_chain_forward
 
 
 def _run(seq: nn.Sequential, x, last_clip: float = 0.0):
@@ -276,6 +276,10 @@ class SubDecoderGeoLossl(nn.Module):
                                      MEMLPBlock(out_ch, out_ch, act=act))
 
     def forward(self, x, y: ME.SparseTensor):
+        # inference: the four per-point layers and the concatenation as one launch (activations stay in LDS; same bits)
+        fused = mlp_chain_forward([*self.residual_decoder, *self.decoder], x, y, cat_layer=len(self.residual_decoder))
+        if fused is not None:
+            return ME.SparseTensor(fused, coordinate_map_key=y.coordinate_map_key, coordinate_manager=y.coordinate_manager)
         if isinstance(x, torch.Tensor):
             x = ME.SparseTensor(x, coordinate_map_key=y.coordinate_map_key, coordinate_manager=y.coordinate_manager)
         return self.decoder(ME.cat(self.residual_decoder(x), y))
@@ -287,6 +291,9 @@ class SubDecoderGeoLossl2(nn.Module):
         self.decoder = nn.Sequential(MEMLPBlock(in_ch2, out_ch, act=act), MEMLPBlock(out_ch, out_ch, act=act))
 
     def forward(self, x):
+        fused = mlp_chain_forward(list(self.decoder), x)
+        if fused is not None:
+            return ME.SparseTensor(fused, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
         return self.decoder(x)
 
 

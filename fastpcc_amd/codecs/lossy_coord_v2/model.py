@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import engine as ME
+from ... import hipops
 from ...data import PCData
 from ...evaluators import PCCEvaluator
 from ..geo_lossl_em import GeoLosslessEntropyModel
@@ -119,6 +120,8 @@ class PCC(nn.Module):
         feature, points_num_list = self.encoder(sparse_pc)
         em_bytes = self.em_lossless_based.compress(feature, 1)
         with io.BytesIO() as bs:
+            if self.cfg.numerics_version_in_header:
+                bs.write(bytes([hipops.numerics_version()]))
             for v in coord_offset.tolist():
                 bs.write(int(v).to_bytes(2, 'little', signed=False))
             if self.cfg.adaptive_pruning:
@@ -136,6 +139,11 @@ class PCC(nn.Module):
     def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
         dev = next(self.parameters()).device
         with io.BytesIO(compressed_bytes) as bs:
+            if self.cfg.numerics_version_in_header:
+                written_by = bs.read(1)[0]
+                if written_by != hipops.numerics_version():
+                    raise ValueError(f'stream written with numerics version {written_by}, this build decodes version '
+                                     f'{hipops.numerics_version()} (the fp32 summation orders are part of the format)')
             coord_offset = [int.from_bytes(bs.read(2), 'little', signed=False) for _ in range(3)]
             points_num_list = None
             if self.cfg.adaptive_pruning:

@@ -32,6 +32,10 @@ class ModelConfig:
     warmup_fea_loss_steps: int = 1
     warmup_fea_loss_factor: float = 0.4
     linear_warmup: bool = False
+    # not a key of the reference's config: True prepends one byte, the numerics version of the build that wrote the stream
+    # (include/fpcc_hip.h), so that a decoder with other summation-order rules refuses the stream instead of decoding garbage.
+    # Default False = the reference's byte layout exactly.
+    numerics_version_in_header: bool = False
 
     def __post_init__(self):
         for f in fields(self):

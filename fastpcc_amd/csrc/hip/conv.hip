@@ -16,11 +16,12 @@
 //                 sched_barrier pinning the load issue points (hipcc otherwise sinks them to their first use).
 //   k_conv_mfma   workgroup-tiled: 4 waves own RT*32 rows and all output columns, X rows and W chunks go through
 //                 double-buffered XOR-swizzled LDS.  Used when weights are not packed (training, changing weights),
-//                 for 16-channel chunks, for grouped/transposed maps (out_map) and for the offset-split path.
+//                 for 16-channel chunks and for transposed maps (out_map).
 //   k_conv_valu   shapes MFMA tiles do not cover (C_out in {1, 8, 16}, C_in = 1 ...): one thread per output row and
 //                 <= 16 output channels, weights through the scalar cache.  Bandwidth-bound, tiny in this codec.
-// Maps with <= FPCC_SPLIT_MAX_ROWS rows run one launch per kernel offset into a workspace and k_split_reduce adds the
-// partial sums in offset order (summation order 2 -- part of the stream format, see FPCC_NUMERICS_VERSION).
+// Multi-offset layers with 32-multiple channel counts are evaluated GROUPED (summation order 3 -- part of the stream format, see
+// FPCC_NUMERICS_VERSION): the kernel offsets form four fixed groups, one wave of a workgroup each, partial sums added in group
+// order (k_conv_wave<..., OG = 4>).
 //
 // Roofline: 2 * pairs * C_in * C_out algorithmic flop against the fp32 MFMA peak.  Measured limits of this design are in
 // profiles/r02/wave_kernel_sweeps.md: each VMEM instruction costs ~30 SIMD cycles of issue that more waves do not hide,
@@ -42,7 +43,6 @@ struct ConvArgs {
     const int32_t *out_map; int64_t om_os; int64_t om_gs; float *out; int ldo; int64_t n_out;
     int act; const float *slope; float clip;
     const int32_t *row_order;  // tile position -> output row (NULL: identity); see fpcc_conv_row_keys
-    float *ws; int split;      // split != 0: blockIdx.y selects ONE kernel offset; raw partial sums go to ws[offset][row][col]
 };
 
 __device__ float g_zero_row[64];   // 256 bytes of zeros: the source of every absent neighbour
@@ -167,13 +167,12 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
     // heavy -- tiles land on different XCDs and the light tiles fill the tail of the launch (longest-processing-time-first:
     // 272 K-row layer 1193 -> 1132 us, 70 K-row 429 -> 390 us, 18 K-row 213 -> 200 us against a strided deal).
     const unsigned tile = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int g = a.split ? 0 : blockIdx.y;
-    const int k_base = a.split ? blockIdx.y : 0;           // split: this workgroup evaluates kernel offset k_base only
-    const int n_off = a.split ? 1 : a.n_off;
+    const int g = blockIdx.y;
+    const int n_off = a.n_off;
     const int64_t row0 = (int64_t)tile * TM;
     const int c_in = a.c1 + a.c2;
     const int n_chunks = c_in / CH;
-    const float *wg = a.w + ((int64_t)g * a.n_off + k_base) * c_in * C_OUT;
+    const float *wg = a.w + (int64_t)g * a.n_off * c_in * C_OUT;
 
     for (int r = tid; r < TM; r += C::THREADS)
         s_row[r] = row0 + r < a.n_out ? (a.row_order ? a.row_order[row0 + r] : (int32_t)(row0 + r)) : -1;
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
         int32_t v = -1;
         if (row0 + r < a.n_out) {
             const int64_t row = a.row_order ? (int64_t)a.row_order[row0 + r] : row0 + r;
-            v = a.nbr ? a.nbr[(int64_t)(k + k_base) * a.nbr_ks + row * a.nbr_os] : (int32_t)row;
+            v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + row * a.nbr_os] : (int32_t)row;
         }
         s_nbr[e] = v;
     }
@@ -238,17 +237,6 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
         }
     }
 
-    if (a.split) {
-        float *part = a.ws + (int64_t)k_base * a.n_out * C_OUT;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t o = s_row[wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh];
-            if (o < 0) continue;
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) part[o * C_OUT + 32 * (wc * NBW + nb) + li] = acc[nb][reg];
-        }
-        return;
-    }
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -369,11 +357,20 @@ struct WaveCfg {
 // 30-50 % slower on every map size: profiles/r02/wave_kernel_sweeps.md.)
 // DBG (timing experiments only, results are wrong): bit 0 = every gathered row is row 0 (no gather traffic), bit 1 = every
 // stage reads the weights of chunk 0 (B stream stays in the vector L1)
-template <int NBW, int CH, int SB, int DBG = 0>
+// OG = 4 ("grouped" evaluation, summation order 3): the four waves of a workgroup share ONE unit and split its kernel offsets into
+// the four fixed contiguous groups of offset_group_begin(); each wave runs the order-1 chain of its group from zero, the partial
+// sums meet in LDS and are added as ((g0 + g1) + g2) + g3, then bias / activation.  A unit's serial chain of (offset, chunk)
+// stages is four times shorter and the launch has four times the waves: what maps of a few thousand to a few ten thousand rows
+// lack (one partial round of waves, each latency-bound on its own chain).  The groups are a function of the offset index alone,
+// so a row's result does not depend on which rows share its block.
+__host__ __device__ __forceinline__ int offset_group_begin(int g, int n_off) { return (g * n_off + 3) / 4; }
+
+template <int NBW, int CH, int SB, int DBG = 0, int OG = 1>
 __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
                                                                                          int nbt, unsigned n_units) {
     constexpr int G8 = CH / 8;
     __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
+    __shared__ float s_part[OG == 4 ? 4 * 16 * NBW * 64 : 1];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -381,8 +378,8 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
     // unit = (32-row block, column group); the column groups of one row block are adjacent units (same workgroup: their A
     // rows hit the CU's vector L1).  Natural order: contiguous unit ranges per XCD; with a row order: dispatch order.
     const unsigned blk = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned unit = blk * 4u + (unsigned)wv;
-    if (unit >= n_units) return;                    // no barrier below: a wave may leave on its own
+    const unsigned unit = OG == 4 ? blk : blk * 4u + (unsigned)wv;
+    if (unit >= n_units) return;                    // OG == 1: no barrier below, a wave may leave on its own (OG == 4: whole workgroups)
     const unsigned rb_ = unit / n_cg, cg = unit - rb_ * n_cg;
     const int g = blockIdx.y;
     const int64_t row0 = (int64_t)rb_ * 32;
@@ -394,11 +391,12 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
     if (row0 + li < a.n_out) my_row = a.row_order ? a.row_order[row0 + li] : (int32_t)(row0 + li);
     // neighbour rows of my 32 output rows -> this wave's LDS slice; lane half h takes the offsets of parity h
     unsigned wmask = 0;
-    for (int k0 = 0; k0 < a.n_off; k0 += 2) {
+    const int k_lo = OG == 4 ? offset_group_begin(wv, a.n_off) : 0, k_hi = OG == 4 ? offset_group_begin(wv + 1, a.n_off) : a.n_off;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 2) {
         const int k = k0 + lh;
         int32_t v = -1;
-        if (k < a.n_off && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
-        if (k < a.n_off) s_nbr[k * 32 + li] = v;
+        if (k < k_hi && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
+        if (k < k_hi) s_nbr[k * 32 + li] = v;
         const unsigned long long b = __ballot(v >= 0);
         if (b & 0xffffffffull) wmask |= 1u << k0;
         if (b >> 32) wmask |= 1u << (k0 + 1);
@@ -503,6 +501,33 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
 
     // output rows of my accumulator registers: register r holds row (r & 3) + 8 (r >> 2) + 4 h of the block
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    if (OG == 4) {
+        // partial sums of the four offset groups -> LDS; wave q then finishes accumulator registers [4q, 4q + 4) of every column
+        // block: ((g0 + g1) + g2) + g3 in that order, whatever the groups held
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s_part[((wv * NBW + nb) * 16 + reg) * 64 + lane] = acc[nb][reg];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int reg = 4 * wv + q;
+            const int64_t o = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+            if (o < 0) continue;
+            const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+            if (dst < 0) continue;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const float *p = s_part + (nb * 16 + reg) * 64 + lane;
+                constexpr int kStride = NBW * 16 * 64;
+                const float v = ((p[0] + p[kStride]) + p[2 * kStride]) + p[3 * kStride];
+                const int col = 32 * ((int)cg * NBW + nb) + li;
+                const float b = a.bias ? a.bias[col] : 0.0f;
+                a.out[dst * a.ldo + col] = finish(v, b, a.act, slope, a.clip);
+            }
+        }
+        return;
+    }
     int32_t orow[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)              // lane rr (< 32) holds that row's output index; all lanes active here
@@ -518,6 +543,155 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
             const int col = 32 * ((int)cg * NBW + nb) + li;
             const float b = a.bias ? a.bias[col] : 0.0f;
             a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64 x 64 wave tile ("2 x 2"): the wave-autonomous kernel with TWO 32-row blocks and TWO 32-column blocks per wave.  Every A
+// fragment (16 bytes per lane, gathered) and every B fragment (16 bytes per lane, packed weights) feeds two MFMAs per k-step
+// instead of one resp. two: 4 vector-memory instructions per 16 MFMAs and 256 bytes of operands per MFMA, against 3 per 8 and
+// 384 bytes in the 32 x 64 unit -- the operand stream out of L1 / L2, not the matrix pipe, is what bounds the 32 x 64 unit on the
+// large maps (profiles/r03/wave22_sweeps.md).  Four independent accumulators per wave.  The price: a 64-row unit executes every
+// kernel offset that any of its 64 rows has (in neighbour-pattern row order adjacent blocks have like patterns), and a
+// launch has half as many units -- so this tile is for maps with many row blocks.  Same FMA chain per output element (order 1).
+template <int SB>
+__global__ __launch_bounds__(256, 3) void k_conv_wave22(ConvArgs a, const float *__restrict__ wp, int nbt, unsigned n_units) {
+    constexpr int CH = 32, G8 = 4;
+    __shared__ int32_t s_nbr_all[4][kMaxOffsets * 64];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned n_cg = (unsigned)(nbt / 2);
+    const unsigned blk = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned unit = blk * 4u + (unsigned)wv;
+    if (unit >= n_units) return;                    // no barrier below: a wave may leave on its own
+    const unsigned rb_ = unit / n_cg, cg = unit - rb_ * n_cg;
+    const int g = blockIdx.y;
+    const int64_t row0 = (int64_t)rb_ * 64;
+    const int c_in = a.c1 + a.c2;
+    const int n_chunks = c_in / CH;
+    int32_t *s_nbr = s_nbr_all[wv];
+
+    // lane = position `lane` of the unit's 64 rows here (one neighbour-table entry per lane and offset); in the MFMA phase lane
+    // (i, h) serves rows i (first block) and 32 + i (second block)
+    int32_t my_row = -1;
+    if (row0 + lane < a.n_out) my_row = a.row_order ? a.row_order[row0 + lane] : (int32_t)(row0 + lane);
+    unsigned wmask = 0;
+    for (int k = 0; k < a.n_off; ++k) {
+        int32_t v = -1;
+        if (my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
+        s_nbr[k * 64 + lane] = v;
+        if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.0f;
+
+    const int n_stages = __popc(wmask) * n_chunks;
+    if (n_stages > 0) {
+        const int64_t chunk_floats = (int64_t)G8 * nbt * 256;
+        const float *wp_g = wp + (int64_t)g * a.n_off * n_chunks * chunk_floats + ((int64_t)cg * 2) * 256 + lane * 4;
+        const float *const zero = (const float *)g_zero_row + 4 * lh;
+        const float *const x1b = a.x1 + 4 * lh, *const x2b = a.x2 ? a.x2 + 4 * lh : zero;
+        const int64_t ld1 = a.ld1, ld2 = a.ld2;
+        const int n1 = a.c1 / CH;
+        const float *a1[2], *a2[2], *bpk;
+        int step[2];
+        auto set_offset = [&](int k) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int32_t idx = s_nbr[k * 64 + 32 * rb + li];
+                const int32_t neg = idx >> 31;
+                const uint64_t m = (uint64_t)(int64_t)neg, z = reinterpret_cast<uint64_t>(zero) & m;
+                const int64_t row = idx & ~neg;
+                a1[rb] = reinterpret_cast<const float *>((reinterpret_cast<uint64_t>(x1b + row * ld1) & ~m) | z);
+                a2[rb] = reinterpret_cast<const float *>((reinterpret_cast<uint64_t>(x2b + row * ld2) & ~m) | z);
+                step[rb] = CH & ~neg;
+            }
+            bpk = wp_g + (int64_t)k * n_chunks * chunk_floats;
+        };
+        unsigned rest = wmask;
+        int cc_f = 0;
+        set_offset(__ffs(rest) - 1);
+        const float *ap[2], *bp;
+        auto next_stage = [&]() {
+            const bool in1 = cc_f < n1;                           // wave-uniform
+            const int c = in1 ? cc_f : cc_f - n1;
+            ap[0] = (in1 ? a1[0] : a2[0]) + c * step[0];
+            ap[1] = (in1 ? a1[1] : a2[1]) + c * step[1];
+            bp = bpk + cc_f * chunk_floats;
+            if (cc_f + 1 < n_chunks) {
+                ++cc_f;
+            } else {
+                const unsigned r2 = rest & (rest - 1);
+                if (r2) { rest = r2; cc_f = 0; set_offset(__ffs(r2) - 1); }
+            }
+        };
+        f32x4 ra[2][G8], rbv[G8][2];
+        next_stage();
+#pragma unroll
+        for (int g8 = 0; g8 < G8; ++g8) {
+            __builtin_amdgcn_sched_barrier(0);
+            ra[0][g8] = *reinterpret_cast<const f32x4 *>(ap[0] + 8 * g8);
+            __builtin_amdgcn_sched_barrier(0);
+            ra[1][g8] = *reinterpret_cast<const f32x4 *>(ap[1] + 8 * g8);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                __builtin_amdgcn_sched_barrier(0);
+                rbv[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < n_stages; ++s) {
+            next_stage();                                       // stage s + 1
+            __builtin_amdgcn_sched_barrier(SB);
+#pragma unroll
+            for (int g8 = 0; g8 < G8; ++g8) {
+                const f32x4 av0 = ra[0][g8], av1 = ra[1][g8];
+                const f32x4 b0 = rbv[g8][0], b1 = rbv[g8][1];
+#define FPCC_STEP(c)                                                                                     \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.c, b0.c, acc[0][0], 0, 0, 0);       \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.c, b1.c, acc[0][1], 0, 0, 0);       \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.c, b0.c, acc[1][0], 0, 0, 0);       \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.c, b1.c, acc[1][1], 0, 0, 0);
+                FPCC_STEP(x) FPCC_STEP(y) FPCC_STEP(z) FPCC_STEP(w)
+#undef FPCC_STEP
+                __builtin_amdgcn_sched_barrier(SB);
+                ra[0][g8] = *reinterpret_cast<const f32x4 *>(ap[0] + 8 * g8);
+                __builtin_amdgcn_sched_barrier(SB);
+                ra[1][g8] = *reinterpret_cast<const f32x4 *>(ap[1] + 8 * g8);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    __builtin_amdgcn_sched_barrier(SB);
+                    rbv[g8][nb] = *reinterpret_cast<const f32x4 *>(bp + ((int64_t)g8 * nbt + nb) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(SB);
+            }
+        }
+    }
+
+    const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t o = __shfl(my_row, 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+            if (o < 0) continue;
+            const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+            if (dst < 0) continue;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int col = 32 * ((int)cg * 2 + nb) + li;
+                const float b = a.bias ? a.bias[col] : 0.0f;
+                a.out[dst * a.ldo + col] = finish(acc[rb][nb][reg], b, a.act, slope, a.clip);
+            }
         }
     }
 }
@@ -568,58 +742,19 @@ int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
     return check_hip(hipGetLastError(), "k_conv_mfma");
 }
 
-// Offset-split evaluation for small maps ("order 2").  A level with a few hundred to a few thousand rows has too few
-// tiles to fill 256 CUs, and each tile walks a serial chain of n_offsets x chunks stages (~1 us each, latency bound).
-// Here every (tile, offset) pair is its own workgroup -- 27x the parallelism, chains 27x shorter -- writing raw
-// per-offset partial sums to a workspace; k_split_reduce adds them in ascending offset order, then bias / activation.
-__global__ __launch_bounds__(256) void k_split_reduce(const float *__restrict__ ws, int n_off, int64_t n_out, int c_out,
-                                                      const float *__restrict__ bias, int act,
-                                                      const float *__restrict__ slope, float clip,
-                                                      float *__restrict__ out, int ldo) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one float4 of one output row
-    const int c4 = c_out / 4;
-    if (e >= n_out * c4) return;
-    const int64_t o = e / c4;
-    const int q = (int)(e - o * c4);
-    const int64_t plane = n_out * (int64_t)c_out;
-    const float *src = ws + o * c_out + 4 * q;
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int k = 0; k < n_off; ++k) acc = acc + *reinterpret_cast<const f32x4 *>(src + k * plane);
-    const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
-    f32x4 r;
-    r.x = finish(acc.x, bias ? bias[4 * q] : 0.0f, act, sl, clip);
-    r.y = finish(acc.y, bias ? bias[4 * q + 1] : 0.0f, act, sl, clip);
-    r.z = finish(acc.z, bias ? bias[4 * q + 2] : 0.0f, act, sl, clip);
-    r.w = finish(acc.w, bias ? bias[4 * q + 3] : 0.0f, act, sl, clip);
-    float *dst = out + o * ldo + 4 * q;
-    dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; dst[3] = r.w;
-}
-
-template <int NBT, int CH>
-int launch_split(ConvArgs a, hipStream_t s) {
-    constexpr int TM = 32;
-    a.split = 1;
-    const unsigned tiles = (unsigned)((a.n_out + TM - 1) / TM);
-    hipLaunchKernelGGL((k_conv_mfma<NBT, CH, 1, NBT>), dim3(tiles, a.n_off), dim3(64 * NBT), 0, s, a);
-    if (int rc = check_hip(hipGetLastError(), "k_conv_mfma(split)")) return rc;
-    const int64_t items = a.n_out * (a.c_out / 4);
-    hipLaunchKernelGGL(k_split_reduce, dim3(blocks_for(items, 256)), dim3(256), 0, s, a.ws, a.n_off, a.n_out, a.c_out,
-                       a.bias, a.act, a.slope, a.clip, a.out, a.ldo);
-    return check_hip(hipGetLastError(), "k_split_reduce");
-}
-
 // Tuning knobs (fpcc_conv_set_tuning; initial values from the environment).  None of them changes a result EXCEPT
-// kKnobSplitRows, which selects summation order 2 vs 1 and is therefore part of the stream format: it has no environment
-// variable, and fpcc_conv_set_tuning refuses it unless the process runs with FPCC_EXPERIMENT=1.
-enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobSplitRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
-       kKnobCount = 7 };
-int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1};
+// kKnobGroupedOff (experiments only: 1 = multi-offset layers in order 1 on the plain wave kernel instead of grouped / order 3),
+// which is therefore refused unless the process runs with FPCC_EXPERIMENT=1 and has no environment variable.
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobReserved4 = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
+       kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobCount = 10 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
-        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_SPLIT_MAX_ROWS",
-                                                "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, FPCC_SPLIT_MAX_ROWS, 0, 32 * 1024};
-        const char *e = k == kKnobSplitRows ? nullptr : getenv(names[k]);
+        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "",
+                                                "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS", "", "FPCC_GROUPED_NBW",
+                                                "FPCC_WAVE22_MIN_ROWS"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 0, 0, 32 * 1024, 0, 0, 0};
+        const char *e = (k == kKnobReserved4 || k == kKnobGroupedOff) ? nullptr : getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
     return g_knob[k];
@@ -667,14 +802,44 @@ int launch_wave_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) 
     return check_hip(hipGetLastError(), "k_conv_wave");
 }
 
+// Grouped evaluation (summation order 3): one workgroup per (32-row block, column group), its four waves = the four offset groups.
+template <int NBW>
+int launch_grouped_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
+    const int64_t row_blocks = (a.n_out + 31) / 32;
+    const int64_t units = row_blocks * (nbt / NBW);
+    if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
+    hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    return check_hip(hipGetLastError(), "k_conv_wave(grouped)");
+}
+
+int launch_grouped(const ConvArgs &a, const float *wp, hipStream_t s) {
+    const int nbt = a.c_out / 32;
+    int nbw = knob(kKnobGroupedNbw);
+    if (nbw <= 0) nbw = a.n_out >= 40 * 1024 ? 2 : 1;        // measured: 64 columns per workgroup from ~40 K rows (profiles/r03/grouped_probe.md)
+    while (nbw > nbt || nbt % nbw) nbw >>= 1;
+    return nbw == 2 ? launch_grouped_cfg<2>(a, wp, nbt, s) : launch_grouped_cfg<1>(a, wp, nbt, s);
+}
+
 // Unit width (column blocks per wave) by map size, measured on MI355X (profiles/r02/wave_kernel_sweeps.md): two column blocks
 // from 32 Ki rows up, one below -- on a 18 K-row map one-block units are 20 % faster (4x the units for the same chip), on
 // 272 K rows two-block units gather every row half as often.  Four-block units (every row gathered once) are never the
 // fastest: the B stream is 256 bytes per MFMA at any width, and three waves per SIMD hide less than five.
 // Knob FPCC_WAVE_NBW = 1|2|4 forces.
+int launch_wave22(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
+    const int64_t units = ((a.n_out + 63) / 64) * (nbt / 2);
+    if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
+    const dim3 grid((unsigned)((units + 3) / 4), a.groups);
+    if (knob(kKnobWaveSb)) hipLaunchKernelGGL((k_conv_wave22<0x6>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else hipLaunchKernelGGL((k_conv_wave22<0>), grid, dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    return check_hip(hipGetLastError(), "k_conv_wave22");
+}
+
 int launch_wave(const ConvArgs &a, const float *wp, hipStream_t s) {
     const int nbt = a.c_out / 32;
     const int64_t work = a.n_out * a.groups;
+    // 64 x 64 wave tiles on multi-offset layers of maps with at least FPCC_WAVE22_MIN_ROWS rows (knob 9; 0 = never)
+    const int64_t rows22 = knob(kKnobWave22Rows);
+    if (rows22 > 0 && a.n_off > 1 && nbt % 2 == 0 && work >= rows22 && knob(kKnobWaveNbw) <= 0) return launch_wave22(a, wp, nbt, s);
     int nbw = knob(kKnobWaveNbw);
     if (nbw <= 0) nbw = work >= 32 * 1024 ? 2 : 1;
     while (nbw > nbt || nbt % nbw) nbw >>= 1;
@@ -887,24 +1052,24 @@ int launch_valu(const ConvArgs &a, hipStream_t s) {
 
 using namespace fpcc;
 
-// rows up to which multi-offset convolutions are evaluated offset-split (workspace: n_offsets * n_out * c_out floats).
-// NOT a tuning knob in production: it selects summation order 2 vs 1, i.e. the bits of the result (knob 4 exists for
-// experiments under FPCC_EXPERIMENT=1; encoder and decoder must agree on it).
-#define kSplitMaxRows ((int64_t)knob(kKnobSplitRows))
-
-static bool use_split(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
-    return mfma_chunk(c1, c2, c_out) == 32 && (c_out == 128 || c_out == 64 || c_out == 32) && n_offsets >= 8 &&
-           n_offsets <= kMaxOffsets && groups == 1 && n_out > 0 && n_out <= kSplitMaxRows;
+// Which multi-offset shapes are evaluated grouped (summation order 3): a property of the shape alone -- not of the row count, the
+// caller's arguments or a tuning knob (knob 7 exists for A/B experiments under FPCC_EXPERIMENT=1).
+static bool use_grouped(int c1, int c2, int c_out, int n_offsets, int groups) {
+    return mfma_chunk(c1, c2, c_out) == 32 && n_offsets >= 8 && n_offsets <= kMaxOffsets && groups == 1 && !knob(kKnobGroupedOff);
 }
 
 extern "C" int fpcc_conv_f32_order(int c1, int c2, int c_out) { return mfma_chunk(c1, c2, c_out) ? 1 : 0; }
 
 extern "C" int64_t fpcc_conv_f32_ws_bytes(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
-    return use_split(c1, c2, c_out, n_offsets, groups, n_out) ? (int64_t)n_offsets * n_out * c_out * 4 : 0;
+    // grouped shapes run on the wave kernel, which reads packed weights: without a packed copy from the caller they are packed
+    // into the workspace on every call
+    if (n_out > 0 && use_grouped(c1, c2, c_out, n_offsets, groups)) return (int64_t)n_offsets * (c1 + c2) * c_out * 4;
+    return 0;
 }
 
 extern "C" int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out) {
-    if (use_split(c1, c2, c_out, n_offsets, groups, n_out)) return 2;
+    (void)n_out;                                    // the order is a function of the shape alone (numerics version 2)
+    if (use_grouped(c1, c2, c_out, n_offsets, groups)) return 3;
     return mfma_chunk(c1, c2, c_out) ? 1 : 0;
 }
 
@@ -923,10 +1088,11 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
     if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");
-    if (which == kKnobSplitRows) {
+    if (which == kKnobReserved4) return fail_arg("conv_set_tuning: knob 4 (offset-split threshold) no longer exists");
+    if (which == kKnobGroupedOff) {
         const char *e = getenv("FPCC_EXPERIMENT");
         if (!e || atoi(e) != 1)
-            return fail_arg("conv_set_tuning: the offset-split threshold is part of the stream format (FPCC_EXPERIMENT=1 to override)");
+            return fail_arg("conv_set_tuning: the summation order is part of the stream format (FPCC_EXPERIMENT=1 to override)");
     }
     const int before = knob(which);
     g_knob[which] = value < 0 ? 0 : value;
@@ -975,21 +1141,26 @@ extern "C" int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x
     if (n_out == 0) return FPCC_OK;
 
     ConvArgs a{x1, c1, ld1, x2, c2, ld2, nbr, n_offsets, nbr_ks, nbr_os, w, bias, c_out, groups,
-               out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order, static_cast<float *>(ws), 0};
+               out_map, om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order};
     hipStream_t s = as_stream(stream);
     int ch = mfma_chunk(c1, c2, c_out);
     if (row_order && !ch) return fail_arg("conv_f32: row_order is a feature of the MFMA path (fpcc_conv_f32_order() != 0)");
     if (ch && n_offsets > kMaxOffsets) return fail_arg("conv_f32: the MFMA path supports at most 27 kernel offsets");
     if (ch && !(aligned16(x1) && ld1 % 4 == 0 && aligned16(w) && (c2 == 0 || (aligned16(x2) && ld2 % 4 == 0))))
         return fail_arg("conv_f32: the MFMA path needs 16-byte aligned inputs and row strides that are multiples of 4");
-    if (nbr && use_split(c1, c2, c_out, n_offsets, groups, n_out)) {
-        // the summation order is a property of the shape (fpcc_conv_f32_order_ex), never of what the caller passed
-        if (out_map) return fail_arg("conv_f32: offset-split shapes do not take an output map");
-        if (!ws || ws_bytes < fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out) || !aligned16(ws))
-            return fail_arg("conv_f32: this shape needs a 16-byte aligned workspace of fpcc_conv_f32_ws_bytes() bytes");
-        if (c_out == 128) return launch_split<4, 32>(a, s);
-        if (c_out == 64) return launch_split<2, 32>(a, s);
-        return launch_split<1, 32>(a, s);
+    if (nbr && use_grouped(c1, c2, c_out, n_offsets, groups)) {
+        // summation order 3, whatever the caller passed (the order is a property of the shape)
+        if (out_map) return fail_arg("conv_f32: grouped shapes do not take an output map");
+        const float *wp = w_packed;
+        if (!wp) {
+            if (!ws || ws_bytes < fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out) || !aligned16(ws))
+                return fail_arg("conv_f32: this shape needs packed weights or a 16-byte aligned workspace of fpcc_conv_f32_ws_bytes() bytes");
+            if (int rc = fpcc_conv_pack_weights_f32(w, n_offsets, c1 + c2, c_out, static_cast<float *>(ws), stream)) return rc;
+            wp = static_cast<const float *>(ws);
+        } else if (!aligned16(wp)) {
+            return fail_arg("conv_f32: packed weights must be 16-byte aligned");
+        }
+        return launch_grouped(a, wp, s);
     }
     // Narrow layers with 48 input channels (3 chunks of 16: 8 MFMAs between two barriers) on large maps are bound by the
     // gathers and the barriers: one stage per kernel offset (CH = 48) has a third as many.  Same per-element chain (the

@@ -87,6 +87,7 @@ _SIGS = {
     'fpcc_rans_binary_decode_dev': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     'fpcc_simple_dec_pop_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
+    'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
 
@@ -337,7 +338,8 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
     return out
 
 
-KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_SPLIT_ROWS, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 4, 5, 6
+KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 5, 6
+KNOB_GROUPED_OFF, KNOB_GROUPED_NBW, KNOB_WAVE22_ROWS = 7, 8, 9      # 7: experiments only (FPCC_EXPERIMENT=1), changes the summation order
 
 
 def numerics_version() -> int:
@@ -347,7 +349,9 @@ def numerics_version() -> int:
 
 def conv_set_tuning(which: int, value: int) -> int:
     """process-wide tuning knob of the wave kernel (fpcc_conv_set_tuning); returns the previous value"""
-    return _ok(lib().fpcc_conv_set_tuning(int(which), int(value)))
+    before = _ok(lib().fpcc_conv_set_tuning(int(which), int(value)))
+    conv_order.cache_clear()                    # knobs 4 / 7 (experiments only) move the summation-order thresholds
+    return before
 
 
 # When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
@@ -393,11 +397,11 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     if om_os == 0:
         om_os = groups
     ws, ws_bytes = None, 0
-    if nbr is not None:                                        # the library alone decides which shapes are evaluated offset-split
+    wp = packed_weights(w, c1, c2, c_out, n_offsets, groups, fresh=(pack == 'fresh')) if pack else None
+    if wp is None and nbr is not None and n_offsets >= 8:      # a grouped (order 3) shape without a packed copy: room to pack into
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
-    wp = packed_weights(w, c1, c2, c_out, n_offsets, groups, fresh=(pack == 'fresh')) if pack and not ws_bytes else None
     trace = CONV_TRACE
     if trace is not None:
         ev0 = _trace_event()
@@ -415,6 +419,81 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
                                  'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
                                  'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
+    return out
+
+
+class _MlpLayer(C.Structure):
+    _fields_ = [('w', _vp), ('w_packed', _vp), ('bias', _vp), ('slope', _vp), ('c_out', _i32), ('act', _i32), ('clip', _f32)]
+
+
+class _MlpChain(C.Structure):
+    _fields_ = [('x', _vp), ('cx', _i32), ('ldx', _i32), ('y', _vp), ('cy', _i32), ('ldy', _i32), ('cat_layer', _i32),
+                ('n_layers', _i32), ('layers', _MlpLayer * 4), ('out', _vp), ('ldo', _i32), ('n', _i64)]
+
+
+def mlp_chain_ok(cx: int, widths, cat_layer: int = -1, cy: int = 0) -> bool:
+    """shapes fpcc_mlp_chain_f32 takes: 1..4 layers of width 32 | 64 | 128, input of 1 or a multiple of 32 (<= 256) channels, an
+    optional concatenated operand of 32..128 channels entering a layer >= 1"""
+    if not 1 <= len(widths) <= 4 or any(c not in (32, 64, 128) for c in widths):
+        return False
+    if not (cx == 1 or (cx % 32 == 0 and 32 <= cx <= 256)):
+        return False
+    if cat_layer == -1:
+        return True
+    return 1 <= cat_layer < len(widths) and cy % 32 == 0 and 32 <= cy <= 128
+
+
+def mlp_chain(x: torch.Tensor, layers, y: Optional[torch.Tensor] = None, cat_layer: int = -1,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A stack of per-point layers as one launch (fpcc_mlp_chain_f32).  layers: sequence of (w [c_in, c_out] contiguous fp32,
+    bias | None, act, slope | None, clip); `y` is concatenated after the activations entering layer `cat_layer`."""
+    px, cx, ldx = _rows2d(x, 'x')
+    n = x.shape[0]
+    d = _MlpChain()
+    d.x, d.cx, d.ldx, d.n, d.n_layers, d.cat_layer = px, cx, ldx, n, len(layers), cat_layer
+    if y is not None:
+        d.y, d.cy, d.ldy = _rows2d(y, 'y')
+        if y.shape[0] != n:
+            raise ValueError('concatenated operand has a different number of rows')
+    keep = []
+    c_in = cx
+    flops = 0
+    for l, (w, bias, act, slope, clip) in enumerate(layers):
+        if l == cat_layer:
+            c_in += d.cy
+        if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or w.dim() != 2 or w.shape[0] != c_in:
+            raise ValueError(f'layer {l}: weights must be contiguous fp32 [{c_in}, c_out], got {tuple(w.shape)}')
+        c_out = w.shape[1]
+        L = d.layers[l]
+        L.w = w.data_ptr()
+        if c_in != 1:
+            wp = packed_weights(w, c_in, 0, c_out, 1, 1)
+            if wp is None:
+                raise ValueError(f'layer {l}: {c_in} -> {c_out} has no packed form')
+            keep.append(wp)
+            L.w_packed = wp.data_ptr()
+        L.bias = _dev(bias, torch.float32, 'bias', True)
+        L.slope = _dev(slope, torch.float32, 'slope', True)
+        L.c_out, L.act, L.clip = c_out, int(act), float(clip)
+        flops += 2 * n * c_in * c_out
+        c_in = c_out
+    if out is None:
+        out = torch.empty((n, c_in), dtype=torch.float32, device=x.device)
+    d.out, co, d.ldo = _rows2d(out, 'out')
+    if co != c_in or out.shape[0] != n:
+        raise ValueError('output shape mismatch')
+    trace = CONV_TRACE
+    if trace is not None:
+        ev0 = _trace_event()
+        ev0.record()
+    _ok(lib().fpcc_mlp_chain_f32(C.byref(d), _stream()))
+    if trace is not None:
+        ev1 = _trace_event()
+        ev1.record()
+        trace.append((ev0, ev1, {'mfma': True, 'chain': True, 'c_in': cx, 'c_out': c_in, 'n_out': n, 'groups': 1, 'n_offsets': 1,
+                                 'nbr': None, 'nbr_ks': 0, 'nbr_os': 1, 'flops': float(flops),
+                                 'bytes': 4.0 * n * (cx + (d.cy if y is not None else 0) + c_in) + 4.0 * sum(w.numel() for w, *_ in layers),
+                                 'layers': [tuple(w.shape) for w, *_ in layers]}))
     return out
 
 

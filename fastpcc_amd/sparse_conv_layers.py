@@ -61,6 +61,45 @@ class MEMLPBlock(nn.Module):
                f'bn={self.bn is not None}, act={self.act})'
 
 
+# Stacks of MEMLPBlocks (per-point layers) run as ONE launch of fpcc_mlp_chain_f32 in inference when their shapes allow it: the
+# activations between the layers stay in LDS.  Same bits as layer by layer (tests/test_gpu_mlp_chain.py); the switch exists
+# for that test and for A/B timing.
+FUSE_MLP_CHAINS = True
+CHAIN_CALLS = 0
+
+
+def mlp_chain_forward(blocks, x, y=None, cat_layer: int = -1, clip: float = 0.0):
+    """`blocks`: MEMLPBlocks applied in sequence to x (SparseTensor or [n, C] tensor); `y` (SparseTensor) is concatenated
+    after the activations entering block `cat_layer` (ME.cat(h, y)).  Returns the features [n, C_out] of the last block, or
+    None when the stack cannot run fused (training / autograd, batch norm, an activation that does not fuse, shapes outside
+    fpcc_mlp_chain_f32): the caller then evaluates block by block."""
+    global CHAIN_CALLS
+    from . import hipops as ops
+    if not FUSE_MLP_CHAINS or torch.is_grad_enabled():
+        return None
+    xf = x if isinstance(x, torch.Tensor) else (x.parts[0] if len(x.parts) == 1 else None)
+    yf = None
+    if y is not None:
+        if len(y.parts) != 1:
+            return None
+        yf = y.parts[0]
+    if xf is None or xf.dim() != 2 or xf.dtype != torch.float32 or xf.stride(1) != 1:
+        return None
+    if any(b.bn is not None or not _fusable(b.act) for b in blocks):
+        return None
+    widths = [b.mlp.linear.out_features for b in blocks]
+    if not ops.mlp_chain_ok(xf.shape[1], widths, cat_layer, 0 if yf is None else yf.shape[1]):
+        return None
+    layers = []
+    for i, b in enumerate(blocks):
+        act = ME._act_of(b.act)
+        bias = b.mlp.linear.bias
+        layers.append((b.mlp._weight_t(), None if bias is None else bias.detach(), act.kind, act.slope,
+                       clip if i == len(blocks) - 1 else 0.0))
+    CHAIN_CALLS += 1
+    return ops.mlp_chain(xf, layers, y=yf, cat_layer=cat_layer)
+
+
 class BaseConvBlock(nn.Module):
     def __init__(self, conv_class: Callable, in_channels, out_channels, kernel_size, stride, dilation=1, dimension=3,
                  region_type: str = 'HYPER_CUBE', bn: bool = False, bias: Optional[bool] = None,

@@ -110,17 +110,22 @@ enum { FPCC_ACT_NONE = 0, FPCC_ACT_PRELU = 1, FPCC_ACT_RELU = 2 };
 
 /* Numerics version.  A decoder must recompute the encoder's fp32 activations BIT FOR BIT (they pass through round() and
  * 16-bit probability quantisation before entropy coding), so the summation order of every layer is part of the stream
- * format.  The order of a layer is a function of its shape and row count only, through these constants -- none of them is a
- * tuning knob, changing one orphans every stream written before:
- *     offset-split evaluation (order 2)      multi-offset maps of at most FPCC_SPLIT_MAX_ROWS rows, C_out in {32,64,128}
- *     zero-padding to an MFMA shape (order 1) per-point / 3x3x3 layers on maps of at least FPCC_PAD_MIN_ROWS rows
- *     two-phase conv3 -> 1 channel (order 2)  every 3x3x3 layer with one output channel and C_in % 16 == 0
- *     MFMA channel order (order 1)            0,4,1,5,2,6,3,7 inside aligned groups of 8 channels
- * Tile shapes, row order, kernel choice (workgroup-tiled or wave kernel) and every fpcc_conv_set_tuning knob but knob 4 leave
- * all results unchanged (tests/test_gpu_fullsize.py).  The codecs' streams carry no version field (the reference's layout is
- * kept byte for byte); tests/golden/v2_stream.json holds a stream of this version that every later build must decode. */
-#define FPCC_NUMERICS_VERSION 1
-#define FPCC_SPLIT_MAX_ROWS 8192
+ * format.  Version 2: the order of a layer is a function of its SHAPE alone (channel counts, kernel offsets, groups) -- plus one
+ * row threshold for the zero-padded shapes -- never of tile shapes, row order, kernel choice or a tuning knob:
+ *     order 3 (grouped)                      multi-offset layers (8 <= K <= 27, one group) with C_in, c1 multiples of 32 and C_out
+ *                                            in {32,64,128}: the K offsets form four fixed contiguous groups
+ *                                            [ceil(g K / 4), ceil((g + 1) K / 4)); each group is an order-1 chain from zero over
+ *                                            the offsets present, the partial sums are added as ((g0 + g1) + g2) + g3, then bias
+ *     order 1 (MFMA chain)                   every other MFMA shape: one chain, offsets ascending, 0,4,1,5,2,6,3,7 inside
+ *                                            aligned groups of 8 channels
+ *     order 0 (natural chain)                shapes outside the MFMA path
+ *     zero-padding to an MFMA shape          per-point / 3x3x3 layers on maps of at least FPCC_PAD_MIN_ROWS rows
+ *     two-phase conv3 -> 1 channel (order 2) every 3x3x3 layer with one output channel and C_in % 16 == 0: per offset its own
+ *                                            chain, offsets' sums added in ascending order
+ * (Version 1 evaluated multi-offset maps of <= 8192 rows offset-split = order 2 and larger ones in order 1.)  The codecs' streams
+ * carry no version field by default (the reference's layout is kept byte for byte; `numerics_version_in_header` of the model
+ * configs prepends it); tests/golden/v2_stream.json holds a stream of this version that every later build must decode. */
+#define FPCC_NUMERICS_VERSION 2
 #define FPCC_PAD_MIN_ROWS 8192
 int fpcc_numerics_version(void);
 
@@ -142,9 +147,9 @@ int fpcc_numerics_version(void);
  * groups > 1 expresses a stride-2 transposed / generative convolution: group g = octant g of parent row o, with
  * out_map = child_row [m][8] ((om_os, om_gs) = (8, 1)) or NULL for the full generated set.
  *
- * Summation order (fixed, documented for bit-exact checking): one fp32 FMA chain per output element, offsets ascending,
- * channels ascending -- except that the MFMA path visits every aligned group of 8 channels as 0,4,1,5,2,6,3,7.
- * fpcc_conv_f32_order() reports which of the two a given shape uses (0 natural, 1 the MFMA order).
+ * Summation order (fixed, documented for bit-exact checking): see "Numerics version" above; fpcc_conv_f32_order_ex() reports
+ * the order of a shape (0 natural chain, 1 MFMA chain, 3 grouped).  A grouped shape runs on the wave kernel and needs packed
+ * weights: from the caller (fpcc_conv_f32_pk), or packed per call into a workspace of fpcc_conv_f32_ws_bytes() bytes.
  */
 int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2,
                   const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
@@ -154,9 +159,9 @@ int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, int c2, int
                   void *stream);
 /* The same operator with an additional PACKED copy of the weights (NULL: exactly fpcc_conv_f32).  Shapes for which
  * fpcc_conv_packed_floats() != 0 (C_in, c1 multiples of 32; C_out in {32, 64, 128}) then run on the wave-autonomous MFMA
- * kernel: every wave owns 32 output rows x 1, 2 or 4 column blocks and reads its B operands straight from the packed
- * weights (L2-resident) as coalesced 16-byte loads -- no LDS staging, no workgroup barrier.  Same results bit for bit (the
- * summation order is order 1 either way); shapes evaluated offset-split (order 2) ignore the packed copy.
+ * kernel: every wave owns 32 (or 64) output rows x 1, 2 or 4 column blocks and reads its B operands straight from the packed
+ * weights (L2-resident) as coalesced 16-byte loads -- no LDS staging; multi-offset shapes additionally split their offsets over
+ * the four waves of a workgroup (order 3).  Same results bit for bit with and without the packed copy.
  * fpcc_conv_pack_weights_f32: w [n_mats][c_in][c_out] (n_mats = groups * n_offsets) ->
  *     w_packed[m][cc][g8][nb][h][i][j] = w[m][32 cc + 8 g8 + 4 h + j][32 nb + i]      (same number of floats);
  * the caller caches it next to the weights (fastpcc_amd/hipops.py keeps one per weight tensor). */
@@ -170,7 +175,10 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *   5  row tile of the workgroup-tiled kernel: 0 = by map size, 1 | 2 | 3 = 128 | 64 | 32 rows
  *   6  rows from which per-point layers (one offset, identity map) run on the persistent kernel that keeps the weights in
  *      registers (FPCC_POINTWISE_MIN_ROWS, default 32768); 0 = never
- *   4  (NOT result-neutral) rows up to which multi-offset maps are evaluated offset-split = summation order 2; default 8192 */
+ *   8  column blocks per workgroup of the grouped evaluation: 0 = by map size, else 1 | 2 (FPCC_GROUPED_NBW)
+ *   9  rows from which order-1 multi-offset layers use 64 x 64 wave tiles (FPCC_WAVE22_MIN_ROWS; 0 = never, the default)
+ *   7  (NOT result-neutral, refused unless FPCC_EXPERIMENT=1) 1 = evaluate grouped shapes in order 1 instead: A/B experiments
+ *   4  removed (was the offset-split threshold of numerics version 1) */
 int fpcc_conv_set_tuning(int which, int value);
 /* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
  * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks
@@ -185,6 +193,38 @@ int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x2, int c2, 
                      const int32_t *out_map, int64_t om_os, int64_t om_gs, float *out, int ldo, int64_t n_out,
                      int act, const float *slope, float clip, const int32_t *row_order, void *ws, int64_t ws_bytes,
                      void *stream);
+/* A chain of per-point layers as ONE launch: MinkowskiLinear (+ bias + PReLU / ReLU + clamp) stacks with at most one channel
+ * concatenation in the middle -- SubDecoderGeoLossl / SubDecoderGeoLossl2 of the lossless coder
+ * (models/convolutional/lossy_coord_v2/layers.py:294-331: residual_decoder = MLP(1 -> C/2), MLP(C/2 -> C); decoder =
+ * MLP(cat(., y) -> C), MLP(C -> C)), which the reference evaluates as 4 x (linear, bias, activation) MinkowskiEngine calls.
+ *     h_0 = x [n, cx]                                  cx = 1, or a multiple of 32 (<= 256)
+ *     h_{l+1} = act_l(cat_l(h_l) @ W_l + bias_l)       cat_l(h) = [h, y] for l == cat_layer (>= 1; -1: none), else h
+ *     out = h_{n_layers} [n, c_out of the last layer]
+ * Layer widths c_out in {32, 64, 128}; y has cy in {32, 64, 96, 128} channels.  Weights: layer l's [c_in][c_out] matrix
+ * (MinkowskiLinear's weight transposed), plain in `w` (required for a one-channel first layer) and packed by
+ * fpcc_conv_pack_weights_f32(w, 1, c_in, c_out) in `w_packed` (required for every other layer).  Intermediate activations
+ * stay in LDS.  Every output element is the FMA chain of the corresponding fpcc_conv_f32 launches (summation order 1), so a
+ * fused chain and the layer-by-layer evaluation give the same bits. */
+#define FPCC_MLP_CHAIN_MAX_LAYERS 4
+typedef struct {
+    const float *w;          /* [c_in][c_out] */
+    const float *w_packed;   /* fpcc_conv_pack_weights_f32 layout, or NULL for a one-channel first layer */
+    const float *bias;       /* [c_out] or NULL */
+    const float *slope;      /* device float[1], PReLU only */
+    int c_out;
+    int act;                 /* FPCC_ACT_* */
+    float clip;              /* > 0: clamp to [-clip, clip] */
+} fpcc_mlp_layer;
+typedef struct {
+    const float *x; int cx; int ldx;
+    const float *y; int cy; int ldy;       /* concatenated after the activations entering layer `cat_layer` */
+    int cat_layer;                          /* -1: no concatenation */
+    int n_layers;
+    fpcc_mlp_layer layers[FPCC_MLP_CHAIN_MAX_LAYERS];
+    float *out; int ldo;
+    int64_t n;
+} fpcc_mlp_chain;
+int fpcc_mlp_chain_f32(const fpcc_mlp_chain *chain, void *stream);
 /* row_order (MFMA path only, NULL = natural): a permutation of [0, n_out); tile position p computes output row
  * row_order[p].  It changes which rows share a 32-row MFMA block -- and with it how many (block, offset) products are
  * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows

@@ -24,6 +24,10 @@
  *      order 2: per kernel offset its own chain (channels as in order 1) starting from zero; the offsets' partial
  *               sums are then added in ascending offset order -- the association of a per-offset
  *               gather-GEMM-scatter-add evaluation (and of MinkowskiEngine's own loop over kernel offsets)
+ *      order 3: the kernel offsets are cut into four fixed contiguous groups [ceil(g K / 4), ceil((g + 1) K / 4)); each group
+ *               is its own order-1 chain from zero over the offsets present, and the four partial sums are added as
+ *               ((g0 + g1) + g2) + g3 (a group without a present offset contributes its zero) -- the association of four
+ *               waves that share the offsets of one output block
  * so that a device kernel documenting the same order can be compared bit for bit.
  */
 #include <math.h>
@@ -34,7 +38,7 @@
 enum { ORC_ACT_NONE = 0, ORC_ACT_PRELU = 1, ORC_ACT_RELU = 2 };
 
 static inline int64_t chan_at(int64_t pos, int order) {
-    if (order == 0) return pos;   /* orders 1 and 2 share the channel permutation */
+    if (order == 0) return pos;   /* orders 1, 2 and 3 share the channel permutation */
     static const int p8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
     return (pos & ~(int64_t)7) + p8[pos & 7];
 }
@@ -56,17 +60,20 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
 #pragma omp parallel
     {
         float *acc = (float *)malloc(sizeof(float) * (size_t)c_out);
-        float *part = (float *)malloc(sizeof(float) * (size_t)c_out);
+        float *part = (float *)malloc(sizeof(float) * (size_t)c_out * 4);
 #pragma omp for schedule(dynamic, 64)
         for (int64_t o = 0; o < n_out; ++o) {
             int64_t dst = out_map ? out_map[o] : o;
             if (dst < 0) continue;
             for (int64_t j = 0; j < c_out; ++j) acc[j] = 0.0f;
+            if (order == 3) for (int64_t j = 0; j < 4 * c_out; ++j) part[j] = 0.0f;
             for (int64_t k = 0; k < K; ++k) {
                 int64_t r = nbr ? nbr[k * n_out + o] : o;
                 if (r < 0) continue;
                 const float *wk = w + k * c_in * c_out;
-                float *tgt = order == 2 ? part : acc;
+                int grp = 0;
+                if (order == 3) while (grp < 3 && ((grp + 1) * K + 3) / 4 <= k) ++grp;     /* group whose range holds offset k */
+                float *tgt = order == 2 ? part : order == 3 ? part + grp * c_out : acc;
                 if (order == 2) for (int64_t j = 0; j < c_out; ++j) part[j] = 0.0f;
                 /* orders 1 and 2 walk whole groups of 8: channels past c_in (zero padding on the device) are skipped */
                 const int64_t span = order == 0 ? c_in : ((c_in + 7) & ~(int64_t)7);
@@ -79,6 +86,9 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
                 }
                 if (order == 2) for (int64_t j = 0; j < c_out; ++j) acc[j] = acc[j] + part[j];
             }
+            if (order == 3)
+                for (int64_t j = 0; j < c_out; ++j)
+                    acc[j] = ((part[j] + part[c_out + j]) + part[2 * c_out + j]) + part[3 * c_out + j];
             float *orow = out + dst * ldo;
             for (int64_t j = 0; j < c_out; ++j) {
                 float v = acc[j];

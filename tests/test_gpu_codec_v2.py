@@ -352,3 +352,26 @@ def test_against_the_reference_run(run):
         assert len(rec) == len(ref)
     same = len({tuple(r) for r in rec.tolist()} & {tuple(r) for r in ref.tolist()})
     assert same >= 0.97 * len(ref)
+
+
+def test_numerics_version_byte_is_opt_in_and_checked():
+    """numerics_version_in_header: one leading byte; default off = the reference's layout; a stream of another version is refused"""
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    frame = torch.from_numpy(batched(surface_cloud(9, 64, 6000))).to(torch.int32).cuda()
+    streams = []
+    for flag in (False, True):
+        cfg = baseline_r1()
+        cfg.numerics_version_in_header = flag
+        torch.manual_seed(0)
+        model = Model(cfg)
+        enliven(model, 0)
+        model = model.cuda().eval()
+        data = model.compress(frame)
+        assert model.decompress(data).shape[0] == frame.shape[0]
+        streams.append(data)
+    assert streams[1] == bytes([hipops.numerics_version()]) + streams[0]
+    with pytest.raises(ValueError, match='numerics version'):
+        model.decompress(bytes([hipops.numerics_version() + 1]) + streams[0])

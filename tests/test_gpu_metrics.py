@@ -124,9 +124,8 @@ def test_knn3d_takes_integer_and_strided_inputs():
     a = torch.randint(0, 200, (2000, 3), generator=g, dtype=torch.int32).cuda()
     b = torch.randint(0, 200, (2000, 3), generator=g, dtype=torch.int32).cuda()
     idx, d2 = ops.knn3d(a, b, 4)
-    ref = (torch.cdist(a.double(), b.double()) ** 2).topk(4, dim=1, largest=False).values
-    assert torch.equal(d2.double(), ref)                                    # integer coordinates: exact
+    exact = lambda p, q, k: ((p[:, None, :].long() - q[None, :, :].long()) ** 2).sum(-1).topk(k, dim=1, largest=False).values
+    assert torch.equal(d2.long(), exact(a, b, 4))                           # integer coordinates: exact
     wide = torch.randint(0, 200, (2000, 6), generator=g, dtype=torch.int32).cuda()
     idx2, d3 = ops.knn3d(wide[:, ::2], wide[:, 1::2], 2)
-    ref2 = (torch.cdist(wide[:, ::2].double(), wide[:, 1::2].double()) ** 2).topk(2, dim=1, largest=False).values
-    assert torch.equal(d3.double(), ref2)
+    assert torch.equal(d3.long(), exact(wide[:, ::2], wide[:, 1::2], 2))

@@ -49,9 +49,22 @@ if os.environ.get('NBWS'):
 DEPTHS = [int(v) for v in os.environ.get('DEPTHS', '0').split(',')]
 if os.environ.get('LPT'):
     cases.append(('pattern+lpt', lpt(order, int(os.environ['LPT']))))
+if os.environ.get('W22'):        # W22=1: the default unit against 64 x 64 wave tiles
+    variants = [(-1, 1), (-2, 1)]
+if os.environ.get('GROUPED'):    # GROUPED=1 (needs FPCC_EXPERIMENT=1): order 1 default unit against the grouped (order 3) evaluation
+    variants = [(-1, 1), (-3, 1), (-4, 1)]
 for dbg, (nbw, sb) in [(a, c) for a in DBG for c in variants]:
   ops.conv_set_tuning(3, dbg)
   tag = ''
+  if nbw is not None and nbw < 0:
+      ops.conv_set_tuning(ops.KNOB_WAVE_ON, 1); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, 0); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
+      ops.conv_set_tuning(ops.KNOB_WAVE22_ROWS, 1 if nbw == -2 else 0)
+      tag = ' [wave 64x64]' if nbw == -2 else ' [wave default unit]'
+      if os.environ.get('GROUPED'):
+          ops.conv_set_tuning(ops.KNOB_GROUPED_OFF, 0 if nbw in (-3, -4) else 1)
+          ops.conv_set_tuning(ops.KNOB_GROUPED_NBW, 1 if nbw == -3 else 2)
+          tag = {-1: ' [order 1, default unit]', -3: ' [grouped, 32 columns per workgroup]', -4: ' [grouped, 64 columns per workgroup]'}[nbw]
+      nbw = None
   if nbw is not None:
       ops.conv_set_tuning(ops.KNOB_WAVE_ON, int(nbw > 0)); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
       tag = f' [tiled kernel dbg={dbg}]' if nbw == 0 else f' [wave nbw={nbw} sb={sb} dbg={dbg}]'
