@@ -42,6 +42,8 @@ def parse():
 def conv_flops(info, counts_cache):
     """algorithmic flop of one conv launch: 2 * L * C_in * C_out with L = rulebook pairs actually present"""
     import torch
+    if 'flops' in info:                     # a fused launch that carries its own count (fpcc_mlp_chain_f32: sum over its layers)
+        return info['flops']
     if info['nbr'] is None:
         pairs = info['n_out'] * info['groups']
     else:
@@ -64,7 +66,7 @@ def pmc_traffic():
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    mfma = [v for k, v in data.items() if k.startswith(('k_conv_mfma', 'k_conv_wave', 'k_pointwise_wave'))]
+    mfma = [v for k, v in data.items() if k.startswith(('k_conv_mfma', 'k_conv_wave', 'k_pointwise_wave', 'k_mlp_chain'))]
     launches = sum(v['launches'] for v in mfma)
     total = sum(v['fetch_bytes'] + v['write_bytes'] for v in mfma)
     if not launches:
@@ -387,10 +389,13 @@ def main():
                 fl = conv_flops(info, cache)
                 flops += fl
                 # B_fused of SURVEY.md 8(d): inputs and outputs once, 8 B per rulebook pair, weights once
-                pairs = fl / (2.0 * info['c_in'] * info['c_out'])
-                rows_in = info['n_out'] if info['nbr'] is None or info['n_offsets'] == 27 else pairs
-                bytes_fused += 4.0 * (rows_in * info['c_in'] + info['n_out'] * info['groups'] * info['c_out']) + \
-                    8.0 * pairs + 4.0 * info['groups'] * info['n_offsets'] * info['c_in'] * info['c_out']
+                if 'bytes' in info:
+                    bytes_fused += info['bytes']
+                else:
+                    pairs = fl / (2.0 * info['c_in'] * info['c_out'])
+                    rows_in = info['n_out'] if info['nbr'] is None or info['n_offsets'] == 27 else pairs
+                    bytes_fused += 4.0 * (rows_in * info['c_in'] + info['n_out'] * info['groups'] * info['c_out']) + \
+                        8.0 * pairs + 4.0 * info['groups'] * info['n_offsets'] * info['c_in'] * info['c_out']
                 ms += dt
                 n_launch += 1
             else:
@@ -429,8 +434,9 @@ def main():
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE)',
                          'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': round(bytes_fused / max(n_launch, 1)),
-                         'kernel': 'k_conv_wave / k_pointwise_wave / k_conv_mfma (fp32 gather->MFMA sparse convolution: wave-autonomous kernel, '
-                                   'persistent per-point kernel, workgroup-tiled kernel for the offset-split small maps and the narrow shapes)',
+                         'kernel': 'k_conv_wave / k_pointwise_wave / k_mlp_chain / k_conv_mfma (fp32 gather->MFMA sparse convolution: wave-autonomous '
+                                   'kernel -- grouped over four offset groups for multi-offset layers --, persistent per-point kernel, fused per-point '
+                                   'chains, workgroup-tiled kernel for the narrow shapes)',
                          'launches_per_step': n_launch // trace_steps,
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),

@@ -49,25 +49,82 @@ class SparseSequential(nn.Sequential):
         return x
 
 
-def _pairs_of(mask: torch.Tensor, count: Optional[int] = None) -> torch.Tensor:
-    """(row, octant) of the set bits of an [n, 8] mask, row-major.  With the number of set bits known on the host (the next level's row
-    count in the encoder, the popcount of the decoded symbols in the decoder) the device is not synchronised."""
-    if count is None:
-        count = getattr(mask, '_fpcc_count', None)
-    return mask.nonzero() if count is None else torch.nonzero_static(mask, size=int(count))
+class Occupancy:
+    """The 8-bit child occupancy of the n voxels of a level (symbols int16 [n]: symbol + 1 = the bits, or a [n, 8] 0/1 matrix) and
+    everything the traversal derives from it -- the occupied (row, octant) pairs in row-major order, the gather table of an
+    "occupied outputs only" linear layer, the bits as features, the children's coordinates -- produced by ONE kernel behind a
+    scan (fpcc_octree_children) instead of the reference's nonzero / index_select / shift / add / cat / scatter operators
+    (model.py:60-74,169-175,430-470).  `count` = occupied children in all; known on the host in both directions (encoder: the
+    next level's row count, decoder: the popcount of the symbols the host just decoded), so the device is never synchronised."""
+
+    def __init__(self, symbols: Optional[torch.Tensor] = None, bits: Optional[torch.Tensor] = None, count: Optional[int] = None):
+        src = symbols if symbols is not None else bits
+        self.n = src.shape[0]
+        self.symbols = symbols
+        self._bits_in = None if bits is None else (bits if bits.dtype == torch.uint8 else (bits != 0).to(torch.uint8)).contiguous()
+        if count is None:
+            count = getattr(src, '_fpcc_children', None)
+        if count is None:                                      # no host-side knowledge: one read-back
+            count = int((self._bits_in != 0).sum().item()) if symbols is None else \
+                int(((((symbols.to(torch.int32) + 1) & 255)[:, None] >> torch.arange(8, device=src.device)) & 1).sum().item())
+        self.count = int(count)
+        self._d = None
+        self._children = {}
+
+    def _derive(self, coords: Optional[torch.Tensor] = None):
+        d = ops.octree_children(self.n, self.count, symbols=self.symbols, bits=self._bits_in,
+                                coords=None if coords is None else coords.contiguous(), fxp_one=1 << SharedFxpShift,
+                                want_table=self._d is None, want_bits=self._d is None)
+        if self._d is None:
+            self._d = d
+        return d
+
+    def _get(self, key: str) -> torch.Tensor:
+        if self._d is None:
+            self._derive()
+        return self._d[key]
+
+    bits = property(lambda self: self._get('bits'))              # uint8 [n, 8]
+    fxp = property(lambda self: self._get('fxp'))                # int32 [n, 8]: the bits as Q8.23 features
+    parent_row = property(lambda self: self._get('parent_row'))  # int32 [count]
+    octant = property(lambda self: self._get('octant'))          # int32 [count]
+    table = property(lambda self: self._get('table'))            # int32 [ceil128(count), 8]
+
+    def bool(self) -> torch.Tensor:
+        return self.bits.bool()
+
+    def children(self, coords: torch.Tensor) -> torch.Tensor:
+        """[n, 4] coordinates of the level -> [count, 4] coordinates of the occupied children (one level finer)"""
+        key = (coords.data_ptr(), coords.shape[0])
+        if key not in self._children:
+            self._children[key] = self._derive(coords)['child_coords']
+        return self._children[key]
 
 
-def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tensor, count: Optional[int] = None) -> torch.Tensor:
+def _as_occ(mask, count: Optional[int] = None) -> Occupancy:
+    if isinstance(mask, Occupancy):
+        return mask
+    occ = getattr(mask, '_fpcc_occ', None)                      # a bits matrix seen before (the encoder's levels)
+    if occ is None:
+        occ = Occupancy(bits=mask, count=count)
+        try:
+            mask._fpcc_occ = occ
+        except AttributeError:
+            pass
+    return occ
+
+
+def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask, count: Optional[int] = None) -> torch.Tensor:
     """seq(x).F.reshape(n, 8, C)[mask] for a sequence that ends in a linear layer C_in -> 8*C (model.py:66-74,169-175): the
     reference evaluates all 8*C columns of every row and keeps the occupied octants; here the last layer is evaluated for the
     occupied (row, octant) pairs only -- an 8-"offset" gather convolution whose table has one entry per output row, followed by
     the layer's epilogue with the octant's bias / multiplier columns.  Same integers, ~1/6 of the arithmetic and of the
     int32 traffic on a LiDAR sweep."""
+    occ = _as_occ(mask, count)
     last = seq[len(seq) - 1] if len(seq) else None
     if not isinstance(last, LinearIn8W8Out32) or last.out_ch % 8:
         f = seq(x).F
-        pairs = _pairs_of(mask, count)
-        return f.reshape(f.shape[0], 8, f.shape[1] // 8)[pairs[:, 0], pairs[:, 1]]
+        return f.reshape(f.shape[0], 8, f.shape[1] // 8)[occ.parent_row.long(), occ.octant.long()]
     y = SparseTensor(x.F, x.C, x.stride, x.spatial_range)
     y._caches = x._caches
     for module in list(seq)[:-1]:
@@ -75,25 +132,18 @@ def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask: torch.Tens
             y.F = module(y.F)
         else:
             y = module(y)
-    pairs = _pairs_of(mask, count)                                     # (row, octant) of every occupied child, row-major
-    n_child, ch = pairs.shape[0], last.out_ch // 8
-    octant = pairs[:, 1].to(torch.int32)
-    table = torch.zeros(((n_child + 127) // 128 * 128, 8), dtype=torch.int32, device=mask.device)
-    table[:n_child].scatter_(1, pairs[:, 1:2], (pairs[:, 0:1] + 1).to(torch.int32))
+    n_child, ch = occ.count, last.out_ch // 8
     w = last._padded_weight()                                           # [1, 8*C, ldw] -> [8, C, ldw]
-    raw = ops.conv_i8(y.F, w.view(8, ch, w.shape[-1]), last.in_ch, ch, n_child, nbr=table, n_offsets=8, nbr_ks=1, nbr_os=8,
+    raw = ops.conv_i8(y.F, w.view(8, ch, w.shape[-1]), last.in_ch, ch, n_child, nbr=occ.table, n_offsets=8, nbr_ks=1, nbr_os=8,
                       nbr_bias=1)
     ep = last._epilogue()
     return ops.epilogue_i32(raw, ep['requant_mul'], ep['zero_point'], ep['shift'], ep['out_bits'], bias=ep['bias'],
-                            row_group=octant)
+                            row_group=occ.octant)
 
 
-def _children_of(coords: torch.Tensor, unfold_kernel: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-    """[N, 4] level-l coordinates + [N, 8] bool occupancy -> coordinates of the occupied children at level l-1"""
-    pairs = _pairs_of(mask)
-    c = coords[pairs[:, 0]]
-    c[:, 1:] <<= 1
-    return c + unfold_kernel[0][pairs[:, 1]]
+def _children_of(coords: torch.Tensor, unfold_kernel: torch.Tensor, mask) -> torch.Tensor:
+    """[N, 4] level-l coordinates + the level's occupancy -> coordinates of the occupied children at level l-1"""
+    return _as_occ(mask).children(coords)
 
 
 _POPCOUNT8 = np.array([bin(v).count('1') for v in range(256)], dtype=np.int64)
@@ -109,10 +159,8 @@ def _symbols_of(bits: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
     return (bits.to(torch.int32) << bin2oct).sum(1, dtype=torch.int32).add_(-1).to(torch.int16)
 
 
-def _bits_of(symbols: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
-    mask = ((symbols[:, None].to(torch.int32) + 1) >> bin2oct).bitwise_and_(1).bool()
-    mask._fpcc_count = getattr(symbols, '_fpcc_children', None)          # set where the symbols came from the host decoder
-    return mask
+def _bits_of(symbols: torch.Tensor, bin2oct: torch.Tensor) -> Occupancy:
+    return Occupancy(symbols=symbols)          # count: `_fpcc_children`, set where the symbols came from the host decoder
 
 
 class OneScalePredictor(nn.Module):
@@ -140,16 +188,23 @@ class OneScalePredictor(nn.Module):
         cur_rec = self.dec(cur_rec)
         return cur_rec, self.pred(cur_rec).F
 
-    def _expand(self, cur_rec: SparseTensor, bits: torch.Tensor, child_coords: torch.Tensor) -> SparseTensor:
-        cur_rec.F = torch.cat((cur_rec.F, self._feat(bits)), 1)
-        feats = _occupied_outputs(self.upsample, cur_rec, bits.bool(), child_coords.shape[0])
+    def _feat_of(self, occ) -> torch.Tensor:
+        """occupancy as input features: straight from the octree kernel in the shared fixed-point format, through `_feat` where a
+        subclass encodes them differently (the float twin)"""
+        occ = _as_occ(occ)
+        return occ.fxp if self._feat is OneScalePredictor._feat else self._feat(occ.bits)
+
+    def _expand(self, cur_rec: SparseTensor, bits, child_coords: torch.Tensor) -> SparseTensor:
+        occ = _as_occ(bits, child_coords.shape[0])
+        cur_rec.F = torch.cat((cur_rec.F, self._feat_of(occ)), 1)
+        feats = _occupied_outputs(self.upsample, cur_rec, occ)
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in cur_rec.stride))
 
     def compress(self, cur_rec, up_ref: SparseTensor, cur_bin, bin2oct_kernel, if_upsample):
         cur_rec, cur_pred = self._trunk(cur_rec)
         cur_oct = _symbols_of(cur_bin, bin2oct_kernel)
         if if_upsample:
-            cur_rec = self._expand(cur_rec, cur_bin, up_ref.C)
+            cur_rec = self._expand(cur_rec, Occupancy(symbols=cur_oct, count=up_ref.C.shape[0]), up_ref.C)
             cur_rec._caches = up_ref._caches
         return cur_rec, cur_pred, cur_oct
 
@@ -206,6 +261,7 @@ class OneScaleMultiStepPredictor(nn.Module):
         self.register_buffer('_shared_fxp_shift', torch.tensor(SharedFxpShift, dtype=torch.int32), persistent=False)
 
     _feat = staticmethod(OneScalePredictor._feat)
+    _feat_of = OneScalePredictor._feat_of
 
     def _refresh(self, cur_rec: SparseTensor, embed_in: SparseTensor) -> SparseTensor:
         embed_in._caches = cur_rec._caches
@@ -218,19 +274,21 @@ class OneScaleMultiStepPredictor(nn.Module):
         step i, bits_below[i] (absent for the last step) are the occupancy bits appended as extra channels."""
         cur, last = cur_rec, len(self.pred) - 1
         for i in range(1, last + 1):
-            f = _occupied_outputs(self.pred[i - 1], cur, masks[i - 1].bool(), coords[i - 1].shape[0])
+            f = _occupied_outputs(self.pred[i - 1], cur, masks[i - 1], coords[i - 1].shape[0])
             if i != last:
-                f = torch.cat([f, self._feat(bits_below[i - 1])], 1)
+                f = torch.cat([f, self._feat_of(bits_below[i - 1])], 1)
             cur = SparseTensor(f, coords[i - 1], strides[i - 1])
             cur._caches = cur_rec._caches
         return self.pred[last](cur).F
 
     def compress(self, cur_rec: SparseTensor, cur_bins: List[SparseTensor], bin2oct_kernel):
-        embed_in = SparseTensor(self._feat(cur_bins[1].F), cur_bins[1].C, stride=cur_bins[1].stride)
+        # occupancy of cur_bins[j] (j >= 1): its children are the voxels of cur_bins[j - 1]
+        occs = [None] + [_as_occ(cur_bins[j].F, cur_bins[j - 1].C.shape[0]) for j in range(1, len(cur_bins))]
+        embed_in = SparseTensor(self._feat_of(occs[1]), cur_bins[1].C, stride=cur_bins[1].stride)
         cur_rec = self._refresh(cur_rec, embed_in)
         n = len(self.pred)
-        masks = [cur_bins[-i].F.bool() for i in range(1, n)]
-        below = [cur_bins[-i - 1].F for i in range(1, n)]
+        masks = [occs[len(cur_bins) - i] for i in range(1, n)]
+        below = [occs[len(cur_bins) - i - 1] if len(cur_bins) - i - 1 >= 1 else None for i in range(1, n)]
         coords = [cur_bins[-i - 1].C for i in range(1, n)]
         strides = [cur_bins[-i - 1].stride for i in range(1, n)]
         logits = self._descend(cur_rec, masks, below, coords, strides)
@@ -244,7 +302,7 @@ class OneScaleMultiStepPredictor(nn.Module):
         top_stride //= 2
         caches = cur_rec._caches
         caches.cmaps[(top_stride,) * 3] = (top_rec, None)
-        embed_in = SparseTensor(self._feat(cur_bins[-1]), caches.cmaps[(top_stride * 2,) * 3][0],
+        embed_in = SparseTensor(self._feat_of(cur_bins[-1]), caches.cmaps[(top_stride * 2,) * 3][0],
                                 stride=(top_stride * 2,) * 3)
         cur_rec = self._refresh(cur_rec, embed_in)
         n = len(self.pred)

@@ -29,7 +29,7 @@ from ...int_sparse_conv import Conv3d, SparseTensor
 from ...rans_coder import RansDecoder, RansEncoder
 from ..lossl_coord.model import Block, SparseSequential
 from ..lossl_coord_int import model as int_model
-from ..lossl_coord_int.model import _bits_of, _children_of, _pairs_of, _symbols_of
+from ..lossl_coord_int.model import _as_occ, _bits_of, _children_of, _symbols_of
 from .model_config import Config
 
 log2_e = math.log2(math.e)
@@ -123,10 +123,10 @@ class OneScalePredictor(nn.Module):
 
     def _expand(self, cur_rec: SparseTensor, bits: torch.Tensor, child_coords: torch.Tensor) -> SparseTensor:
         """features of the children selected by `bits` ([n, 8] bool): cat(features, bits) -> upsample -> [n, 8, C] -> rows"""
-        cur_rec.F = torch.cat((cur_rec.F, bits.to(torch.float32)), 1)
+        occ = _as_occ(bits, child_coords.shape[0])              # bits, (row, octant) pairs: one kernel (fpcc_octree_children)
+        cur_rec.F = torch.cat((cur_rec.F, occ.bits.to(torch.float32)), 1)
         f = self.upsample(cur_rec).F
-        pairs = _pairs_of(bits, child_coords.shape[0])
-        feats = f.reshape(f.shape[0], 8, f.shape[1] // 8)[pairs[:, 0], pairs[:, 1]]
+        feats = f.reshape(f.shape[0], 8, f.shape[1] // 8)[occ.parent_row.long(), occ.octant.long()]
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in cur_rec.stride))
 
     # -- training path (:90-169) -----------------------------------------------------------------------------------

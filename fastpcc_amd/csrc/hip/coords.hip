@@ -13,6 +13,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
@@ -270,6 +271,67 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
     if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// One octree step of the integer codec: everything its traversal derives from a level's 8-bit child occupancy, in one scatter
+// pass behind a scan (the reference -- and round 2 of this build -- does it with nonzero / index_select / shifts / adds / cat /
+// scatter tensor operators: ~20 launches per level).
+struct OccCount {
+    const int16_t *symbols;     // symbol + 1 = the 8 occupancy bits, bit (7 - k) = child k  (or NULL)
+    const uint8_t *bits;        // [n][8], non-zero = child k occupied                        (or NULL)
+    __host__ __device__ __forceinline__ int operator()(int64_t i) const {
+        if (symbols) return __builtin_popcount(((unsigned)symbols[i] + 1u) & 0xffu);
+        int c = 0;
+        for (int k = 0; k < 8; ++k) c += bits[8 * i + k] != 0;
+        return c;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_octree_children(OccCount occ, const int32_t *__restrict__ pos_incl, const int32_t *__restrict__ coords,
+                                                         int64_t n, int64_t m, int32_t fxp_one, int32_t *__restrict__ child_coords,
+                                                         int32_t *__restrict__ parent_row, int32_t *__restrict__ octant,
+                                                         int32_t *__restrict__ table, int64_t table_rows, uint8_t *__restrict__ bits_out,
+                                                         int32_t *__restrict__ bits_fxp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) {
+        // zero the padding rows of the table (rows [m, table_rows)): one thread each, past the parents
+        const int64_t r = m + (i - n);
+        if (table && r < table_rows) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) table[8 * r + k] = 0;
+        }
+        return;
+    }
+    unsigned mask = 0;
+    if (occ.symbols) {
+        mask = ((unsigned)occ.symbols[i] + 1u) & 0xffu;                   // bit (7 - k) = child k
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mask |= (occ.bits[8 * i + k] != 0 ? 1u : 0u) << (7 - k);
+    }
+    int64_t j = pos_incl[i] - __builtin_popcount(mask);
+    int32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (coords) { c0 = coords[4 * i]; c1 = coords[4 * i + 1] << 1; c2 = coords[4 * i + 2] << 1; c3 = coords[4 * i + 3] << 1; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool on = (mask >> (7 - k)) & 1u;
+        if (bits_out) bits_out[8 * i + k] = on ? 1 : 0;
+        if (bits_fxp) bits_fxp[8 * i + k] = on ? fxp_one : 0;
+        if (!on || j >= m) continue;
+        if (child_coords) {
+            child_coords[4 * j] = c0; child_coords[4 * j + 1] = c1 + (k >> 2); child_coords[4 * j + 2] = c2 + ((k >> 1) & 1);
+            child_coords[4 * j + 3] = c3 + (k & 1);
+        }
+        if (parent_row) parent_row[j] = (int32_t)i;
+        if (octant) octant[j] = k;
+        if (table) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) table[8 * j + q] = q == k ? (int32_t)i + 1 : 0;
+        }
+        ++j;
+    }
+}
+
 template <typename InIt>
 int64_t scan_bytes(InIt in, int64_t n) {
     size_t bytes = 0;
@@ -482,6 +544,32 @@ extern "C" int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *m
     hipLaunchKernelGGL(k_refine_scatter, dim3(blocks_for(n_cand, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
                        n_cand, mask, (const int32_t *)pos, keys_out, parent_of, child_row, count_out);
     FPCC_LAUNCHED(k_refine_scatter);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_octree_children(const int16_t *symbols, const uint8_t *bits, const int32_t *coords, int64_t n, int64_t m,
+                                        int32_t fxp_one, int32_t *child_coords, int32_t *parent_row, int32_t *octant, int32_t *table,
+                                        int64_t table_rows, uint8_t *bits_out, int32_t *bits_fxp, void *ws, int64_t ws_bytes,
+                                        void *stream) {
+    if (n < 0 || m < 0 || table_rows < 0 || (table && table_rows < m)) return fail_arg("octree_children: bad sizes");
+    if ((symbols != nullptr) == (bits != nullptr) && ws) return fail_arg("octree_children: give symbols or bits (one of them)");
+    OccCount occ{symbols, bits};
+    const int64_t nn = n > 0 ? n : 1;
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), occ);
+    const int64_t arr = align_up(4 * nn, 256);
+    const int64_t tmp_bytes = align_up(scan_bytes(in, nn), 256);
+    const int64_t need = arr + tmp_bytes;
+    if (!ws) return need;
+    if (ws_bytes < need) { set_error("octree_children: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
+    if (n == 0) return FPCC_OK;
+    int32_t *pos = static_cast<int32_t *>(ws);
+    void *tmp = static_cast<char *>(ws) + arr;
+    size_t tb = (size_t)tmp_bytes;
+    FPCC_HIP(rocprim::inclusive_scan(tmp, tb, in, pos, (size_t)n, rocprim::plus<int32_t>(), as_stream(stream)));
+    const int64_t pad = table && table_rows > m ? table_rows - m : 0;
+    hipLaunchKernelGGL(k_octree_children, dim3(blocks_for(n + pad, 256)), dim3(256), 0, as_stream(stream), occ, (const int32_t *)pos,
+                       coords, n, m, fxp_one, child_coords, parent_row, octant, table, table_rows, bits_out, bits_fxp);
+    FPCC_LAUNCHED(k_octree_children);
     return FPCC_OK;
 }
 

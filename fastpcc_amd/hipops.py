@@ -88,6 +88,7 @@ _SIGS = {
     'fpcc_simple_dec_pop_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
     'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
+    'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
 
@@ -878,6 +879,34 @@ def epilogue_i32(x: torch.Tensor, requant_mul: torch.Tensor, zero_point: Optiona
                                 _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
                                 per_channel, _dev(zero_point, torch.int64, 'zero_point', True), int(shift), out_bits,
                                 out.data_ptr(), ch, 0, n, ch, _dev(row_group, torch.int32, 'row_group', True), _stream()))
+    return out
+
+
+def octree_children(n: int, m: int, *, symbols: Optional[torch.Tensor] = None, bits: Optional[torch.Tensor] = None,
+                    coords: Optional[torch.Tensor] = None, fxp_one: int = 1 << 23, want_table: bool = True, want_bits: bool = True):
+    """One octree step of the integer codec (fpcc_octree_children): from the child occupancy of n parents (symbols int16 [n] or
+    bits uint8 [n, 8]) with m occupied children in all -> dict(bits uint8 [n, 8], fxp int32 [n, 8], parent_row int32 [m],
+    octant int32 [m], table int32 [ceil128(m), 8], child_coords int32 [m, 4] when the parents' coords are given)."""
+    src = symbols if symbols is not None else bits
+    dev = src.device
+    out = {'parent_row': torch.empty(m, dtype=torch.int32, device=dev), 'octant': torch.empty(m, dtype=torch.int32, device=dev)}
+    table_rows = (m + 127) // 128 * 128
+    if want_table:
+        out['table'] = torch.empty((table_rows, 8), dtype=torch.int32, device=dev)
+    if want_bits:
+        out['bits'] = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+        out['fxp'] = torch.empty((n, 8), dtype=torch.int32, device=dev)
+    if coords is not None:
+        if coords.shape != (n, 4):
+            raise ValueError('coords must be int32 [n, 4]')
+        out['child_coords'] = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_octree_children(None, None, None, n, m, 0, None, None, None, None, 0, None, None, None, 0, None), dev)
+    ptr = lambda k: out[k].data_ptr() if k in out else None
+    _ok(L.fpcc_octree_children(_dev(symbols, torch.int16, 'symbols', True), _dev(bits, torch.uint8, 'bits', True),
+                               _dev(coords, torch.int32, 'coords', True), n, m, int(fxp_one), ptr('child_coords'), ptr('parent_row'),
+                               ptr('octant'), ptr('table'), table_rows if want_table else 0, ptr('bits'), ptr('fxp'),
+                               ws.data_ptr(), need, _stream()))
     return out
 
 

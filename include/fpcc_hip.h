@@ -475,6 +475,17 @@ int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift
  * lanes fetch probabilities 64 at a time and hold the byte window. */
 int fpcc_rans_binary_decode_dev(const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
                                 uint8_t *bits_out, int32_t *ones_out, int32_t *status, void *hip_stream);
+/* One octree step of the integer codec's traversal: from a level's child occupancy -- symbols int16 [n] (symbol + 1 = the 8 bits,
+ * bit (7 - k) = child k = 4 dx + 2 dy + dz, model.py:60) or bits uint8 [n][8] -- and the parents' coordinates int32 [n][4]
+ * (b, x, y, z), everything the reference derives with nonzero / index_select / shift / add / cat / scatter tensor operators
+ * (models/convolutional/lossl_coord_int/model.py:60-74,169-175,262-295,430-470): per occupied child j (row-major over parents
+ * and octants, m of them = the popcount the caller knows on the host) child_coords[j] = (b, 2x+dx, 2y+dy, 2z+dz),
+ * parent_row[j], octant[j], table[j][8] (parent_row + 1 in column octant, else 0: the one-entry-per-row gather table of an
+ * "occupied outputs only" linear layer; rows [m, table_rows) are zeroed); per parent bits_out [n][8] (0 | 1) and bits_fxp
+ * [n][8] (0 | fxp_one: the occupancy bits as Q8.23 features).  Any output may be NULL.  ws == NULL returns the workspace size. */
+int64_t fpcc_octree_children(const int16_t *symbols, const uint8_t *bits, const int32_t *coords, int64_t n, int64_t m,
+                             int32_t fxp_one, int32_t *child_coords, int32_t *parent_row, int32_t *octant, int32_t *table,
+                             int64_t table_rows, uint8_t *bits_out, int32_t *bits_fxp, void *ws, int64_t ws_bytes, void *stream);
 /* RansDecoder.decode of simple_rans_ext_cpp (models/convolutional/lossy_coord_v3/rans_coder/simple_rans_wrapper.cpp:206-239)
  * on the device: rows uint16 [n | 1][width <= 256] as fpcc_logits_to_cdf16 writes them, state int32[4] = {x, position low,
  * position high, status} carried from launch to launch (initialise from fpcc_simple_dec_tell of libfpcc_host or from the

@@ -26,7 +26,7 @@ def main(path):
     model = Model(baseline_r1())
     enliven(model, 0)
     model = model.cuda().eval()
-    xyz = surface_cloud(11, 128, 90000)              # stride-2 map > 8192 rows (MFMA chains), deeper levels below (offset-split)
+    xyz = surface_cloud(11, 128, 90000)              # levels from ~23 K rows down to a few dozen: grouped (order 3), padded and two-phase shapes
     data = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda())
     rec = model.decompress(data).cpu().numpy()
     out = {'numerics_version': hipops.numerics_version(), 'cloud': {'generator': 'surface_cloud(11, 128, 90000)', 'voxels': int(len(xyz))},
