@@ -1294,6 +1294,32 @@ def make_codec_v2():
         print('codec_v2', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
     out['runs'] = runs
 
+    # the headline configuration at its REAL widths (16/64 encoder, 64 + 11 x 128 lossless levels), read from the reference's
+    # own YAML through the reference's own config loader (lib/config.py:104-117 Config.merge_with_yaml ->
+    # config/convolutional/lossy_coord_v2/baseline_r1.yaml); the pyramid of 1 + 6 stride halvings needs a 256^3 cloud to have more than one bottom voxel
+    from lib.config import Config as RefConfig
+    ref_cfg = RefConfig()
+    ref_cfg.merge_with_yaml(os.path.join(REF, 'config/convolutional/lossy_coord_v2/baseline_r1.yaml'))
+    ref_cfg.check()
+    mc = ref_cfg.model
+    torch.manual_seed(0)
+    model = PCC(mc)
+    enliven(model, 6)
+    model.eval()
+    xyz = surface_cloud(46, 256, 4000) + np.array([1, 4, 2], dtype=np.int32)
+    perm = np.random.default_rng(6).permutation(len(xyz))
+    with torch.no_grad():
+        data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
+        rec = model.decompress(data)
+    out['baseline_r1_yaml'] = {
+        'label': 'baseline_r1_yaml', 'yaml': 'config/convolutional/lossy_coord_v2/baseline_r1.yaml', 'seed': 6,
+        'config': {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in vars(mc).items() if not k.startswith('_')},
+        'xyz': xyz[perm].tolist(),
+        'param_abs_sum': float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)),
+        'state_dict_shapes': [[k, list(v.shape)] for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)],
+        'stream_hex': data.hex(), 'recon': rec.tolist()}
+    print('codec_v2 baseline_r1.yaml', len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
+
     # training objective (PCC.train_forward, model.py:144-183: rate of the lossless levels under the noisy deep-factorised
     # bottleneck, occupancy cross-entropies, reconstruction losses of the lossy part, warm-up factors) on batches of clouds,
     # with the bottleneck's uniform noise replaced by zeros on both sides (CPU generator there, device generator here)

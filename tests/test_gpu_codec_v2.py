@@ -323,9 +323,15 @@ def test_deeper_lossy_part_keeps_local_maxima_of_the_decoder_input_cells(enc, de
 
 
 def _golden_runs():
+    """the reference runs of codec_v2.json: five stand-in widths + the run at baseline_r1.yaml's real widths (16/64 encoder,
+    64 + 11 x 128 lossless levels), whose config the reference's own loader read from its own YAML"""
     import json, os
     with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2.json')) as f:
-        return json.load(f)['runs']
+        g = json.load(f)
+    keys = {f.name for f in __import__('dataclasses').fields(__import__('fastpcc_amd.codecs.lossy_coord_v2.model_config', fromlist=['ModelConfig']).ModelConfig)}
+    real = dict(g['baseline_r1_yaml'])
+    real['config'] = {k: v for k, v in real['config'].items() if k in keys}
+    return g['runs'] + [real]
 
 
 @pytest.mark.parametrize('run', _golden_runs(), ids=[r['label'] for r in _golden_runs()])

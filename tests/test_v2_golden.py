@@ -38,7 +38,28 @@ def model_of(run):
     return cfg, model
 
 
-@pytest.mark.parametrize('run', G['runs'], ids=[r['label'] for r in G['runs']])
+def _runs():
+    """the five stand-in-width runs + the run at the real widths of config/convolutional/lossy_coord_v2/baseline_r1.yaml (read by
+    the reference's own config loader)"""
+    keys = {f.name for f in __import__('dataclasses').fields(ModelConfig)}
+    real = dict(G['baseline_r1_yaml'])
+    real['config'] = {k: v for k, v in real['config'].items() if k in keys}
+    return G['runs'] + [real]
+
+
+def test_real_width_run_is_the_headline_configuration():
+    """the YAML the reference's loader read gives exactly fastpcc_amd's baseline_r1() and the same state_dict (names, shapes)"""
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import baseline_r1
+    run = _runs()[-1]
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    assert cfg == baseline_r1()
+    torch.manual_seed(0)
+    model = Model(cfg)
+    ours = [[k, list(v.shape)] for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)]
+    assert ours == run['state_dict_shapes']
+
+
+@pytest.mark.parametrize('run', _runs(), ids=[r['label'] for r in _runs()])
 def test_reference_run(run):
     cfg, model = model_of(run)
     assert float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)) == \
