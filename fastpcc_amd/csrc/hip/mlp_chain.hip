@@ -22,6 +22,8 @@
 // Roofline: 2 * rows * sum(C_in * C_out) flop against the fp32 MFMA peak; HBM traffic is the chain's input + concatenated
 // operand + output only (the unfused form moves every intermediate twice).
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace fpcc {
 namespace {
@@ -60,6 +62,30 @@ __device__ __forceinline__ float finish(float v, float b, int act, float slope, 
     else if (act == FPCC_ACT_RELU) v = v < 0.0f ? 0.0f : v;
     if (clip > 0.0f) v = fminf(fmaxf(v, -clip), clip);
     return v;
+}
+
+// finish() with the activation and the clamp resolved once per layer (both are wave-uniform run-time values: left inside the
+// per-element code they become a chain of scalar branches around every one of the 16 accumulator registers)
+template <int ACT, bool CLIP>
+__device__ __forceinline__ float finish_t(float v, float b, float slope, float clip) {
+    v = v + b;
+    if (ACT == FPCC_ACT_PRELU) v = v < 0.0f ? v * slope : v;
+    else if (ACT == FPCC_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+    if (CLIP) v = fminf(fmaxf(v, -clip), clip);
+    return v;
+}
+
+template <typename F>
+__device__ __forceinline__ void with_epilogue(int act, float clip, F &&f) {
+    if (clip > 0.0f) {
+        if (act == FPCC_ACT_PRELU) f(std::integral_constant<int, FPCC_ACT_PRELU>(), std::true_type());
+        else if (act == FPCC_ACT_RELU) f(std::integral_constant<int, FPCC_ACT_RELU>(), std::true_type());
+        else f(std::integral_constant<int, FPCC_ACT_NONE>(), std::true_type());
+    } else {
+        if (act == FPCC_ACT_PRELU) f(std::integral_constant<int, FPCC_ACT_PRELU>(), std::false_type());
+        else if (act == FPCC_ACT_RELU) f(std::integral_constant<int, FPCC_ACT_RELU>(), std::false_type());
+        else f(std::integral_constant<int, FPCC_ACT_NONE>(), std::false_type());
+    }
 }
 
 // acc += A[32 rows x 32 n_chunks] @ B over the chunks of one operand part.  `arow` points at this lane's A row + 4 h floats (LDS
@@ -123,15 +149,18 @@ __device__ __forceinline__ void mfma_layer(const Layer &l, float *tile, const fl
     // every read of the tile has been consumed by an MFMA above: the tile may be overwritten with this layer's output
     const float slope = (l.act == FPCC_ACT_PRELU && l.slope) ? l.slope[0] : 0.0f;
     __builtin_amdgcn_wave_barrier();
+    const float clip = l.clip;
+    with_epilogue(l.act, clip, [&](auto act_c, auto clip_c) {
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-        const float b = l.bias ? l.bias[32 * nb + li] : 0.0f;
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float b = l.bias ? l.bias[32 * nb + li] : 0.0f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            tile[r * kPitch + 32 * nb + li] = finish(acc[nb][reg], b, l.act, slope, l.clip);
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                tile[r * kPitch + 32 * nb + li] = finish_t<decltype(act_c)::value, decltype(clip_c)::value>(acc[nb][reg], b, slope, clip);
+            }
         }
-    }
+    });
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -187,6 +216,206 @@ __global__ __launch_bounds__(256, 2) void k_mlp_chain(ChainArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup form for the chain shapes of the codecs (template instances below): a workgroup of four waves owns a tile of 64
+// rows; wave w owns column block w of every 128-wide layer (two waves per column block and one row block each for 64-wide
+// layers) and keeps ITS B operands of EVERY layer in registers for the whole launch (224 VGPRs for the four-layer decoder
+// block: one wave per SIMD) -- no weight traffic at all in steady state, where the wave form above re-streams 224 KB of packed
+// weights from L2 for every 32 rows.  Activations ping-pong between two LDS tiles (one barrier per layer), the concatenated
+// operand and the next tile's inputs are staged through registers while the current tile computes, the output leaves through
+// the tile as whole 128-byte lines.  A unit of work is 64 rows x one layer-set = 448 MFMAs per wave (wave form: 896 on 32 rows
+// x all columns), so maps of a few hundred to a few ten thousand rows spread over four times as many waves and the partial last
+// round of a launch is a quarter as long.  Same FMA chains: bit-identical to the wave form and to the separate launches.
+constexpr int kTileRows = 64;
+constexpr int kTileFloats = kTileRows * kPitch;
+
+struct WgArgs {
+    const float *x; int ldx;
+    const float *y; int ldy;
+    float *out; int ldo;
+    int64_t n;
+    unsigned n_tiles;
+    const float *wp[kMaxLayers];      // packed weights (NULL for a one-channel first layer)
+    const float *w1;                  // one-channel first layer: w[c_out]
+    const float *bias[kMaxLayers];
+    const float *slope[kMaxLayers];
+    int act[kMaxLayers];
+    float clip[kMaxLayers];
+};
+
+template <int G>
+__device__ __forceinline__ void load_b(f32x4 (&B)[G], const float *wp, int nbt, int cb, int lane) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) B[g] = *reinterpret_cast<const f32x4 *>(wp + ((int64_t)g * nbt + cb) * 256 + lane * 4);
+}
+
+// one MFMA layer on the workgroup's 64-row tile: A from `tin` (GT groups of 8 channels) and then from `ty` (GY groups), this
+// wave's column block `cb` of the output into `tout`.  NCB = column blocks of the layer (4: every wave does both row blocks;
+// 2: waves {w, w + 2} share a column block and take one row block each).
+template <int GT, int GY, int NCB>
+__device__ __forceinline__ void wg_layer(const float *tin, const float *ty, float *tout, const f32x4 (&B)[GT + GY], float bias, int act,
+                                         float slope, float clip, int wv, int li, int lh) {
+    constexpr int G = GT + GY, NRG = 4 / NCB;
+    const int cb = wv % NCB, rg = wv / NCB;
+    for (int rb = rg; rb < 2; rb += NRG) {
+        const float *arow = tin + (32 * rb + li) * kPitch + 4 * lh;
+        const float *yrow = GY ? ty + (32 * rb + li) * kPitch + 4 * lh : arow;
+        auto frag = [&](int g) -> f32x4 {
+            return g < GT ? *reinterpret_cast<const f32x4 *>(arow + 8 * g) : *reinterpret_cast<const f32x4 *>(yrow + 8 * (g - GT));
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // A fragments three groups (12 MFMAs) ahead of their use; sched_barrier keeps them there (hipcc otherwise sinks every LDS
+        // read to just before its first use and the wave -- alone on its SIMD -- waits out the LDS latency once per group)
+        f32x4 a0 = frag(0), a1 = frag(G > 1 ? 1 : 0), a2 = frag(G > 2 ? 2 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const f32x4 a3 = g + 3 < G ? frag(g + 3) : a0;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, B[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, B[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, B[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, B[g].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1; a1 = a2; a2 = a3;
+        }
+        with_epilogue(act, clip, [&](auto act_c, auto clip_c) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                tout[r * kPitch + 32 * cb + li] = finish_t<decltype(act_c)::value, decltype(clip_c)::value>(acc[reg], bias, slope, clip);
+            }
+        });
+    }
+}
+
+// rows [row0, row0 + 64) x C channels of a global matrix -> registers (C / 4 float4 per row over 256 threads), zeros past n
+template <int C>
+__device__ __forceinline__ void stage_load(f32x4 (&v)[C / 16], const float *src, int ld, int64_t row0, int64_t n, int t) {
+    constexpr int Q = C / 4;                       // float4 per row
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int idx = t + 256 * k, r = idx / Q, c4 = idx - r * Q;
+        v[k] = row0 + r < n ? *reinterpret_cast<const f32x4 *>(src + (row0 + r) * ld + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void stage_store(const f32x4 (&v)[C / 16], float *tile, int t) {
+    constexpr int Q = C / 4;
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int idx = t + 256 * k, r = idx / Q, c4 = idx - r * Q;
+        *reinterpret_cast<f32x4 *>(tile + r * kPitch + 4 * c4) = v[k];
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void tile_to_global(const float *tile, float *out, int ldo, int64_t row0, int64_t n, int t) {
+    constexpr int Q = C / 4;
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int idx = t + 256 * k, r = idx / Q, c4 = idx - r * Q;
+        if (row0 + r < n) *reinterpret_cast<f32x4 *>(out + (row0 + r) * ldo + 4 * c4) = *reinterpret_cast<const f32x4 *>(tile + r * kPitch + 4 * c4);
+    }
+}
+
+// SubDecoderGeoLossl: x [n, 1] -> W0 (outer product) -> W1 -> cat(., y [n, CY]) -> W2 -> W3
+template <int W0, int W1, int CY, int W2, int W3>
+__global__ __launch_bounds__(256, 1) void k_mlp_chain_a(WgArgs a) {
+    static_assert(W1 == 128 && W2 == 128 && W3 == 128 && W0 % 32 == 0 && CY % 32 == 0, "column blocks of the MFMA layers are split over four waves");
+    __shared__ __attribute__((aligned(16))) float s_p[kTileFloats], s_q[kTileFloats], s_y[kTileFloats];
+    __shared__ float s_x[kTileRows];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    f32x4 B1[W0 / 8], B2[(W1 + CY) / 8], B3[W2 / 8];
+    load_b(B1, a.wp[1], W1 / 32, wv, lane);
+    load_b(B2, a.wp[2], W2 / 32, wv, lane);
+    load_b(B3, a.wp[3], W3 / 32, wv, lane);
+    const int col0 = t % W0;
+    const float w0 = a.w1[col0], b0 = a.bias[0] ? a.bias[0][col0] : 0.0f;
+    float bia[4], slp[4];
+#pragma unroll
+    for (int l = 1; l < 4; ++l) bia[l] = a.bias[l] ? a.bias[l][32 * wv + li] : 0.0f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) slp[l] = (a.act[l] == FPCC_ACT_PRELU && a.slope[l]) ? a.slope[l][0] : 0.0f;
+
+    f32x4 yv[CY / 16];
+    float xv = 0.0f;
+    unsigned tile = blockIdx.x;
+    if (tile < a.n_tiles) {
+        const int64_t row0 = (int64_t)tile * kTileRows;
+        stage_load<CY>(yv, a.y, a.ldy, row0, a.n, t);
+        if (t < kTileRows) xv = row0 + t < a.n ? a.x[(row0 + t) * a.ldx] : 0.0f;
+    }
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t row0 = (int64_t)tile * kTileRows;
+        stage_store<CY>(yv, s_y, t);
+        if (t < kTileRows) s_x[t] = xv;
+        __syncthreads();
+        // the next tile's inputs travel while this one computes
+        const unsigned nxt = tile + gridDim.x;
+        if (nxt < a.n_tiles) {
+            const int64_t r1 = (int64_t)nxt * kTileRows;
+            stage_load<CY>(yv, a.y, a.ldy, r1, a.n, t);
+            if (t < kTileRows) xv = r1 + t < a.n ? a.x[(r1 + t) * a.ldx] : 0.0f;
+        }
+        // layer 0: one input channel, an outer product over all 256 threads (thread = column, rows strided)
+        with_epilogue(a.act[0], a.clip[0], [&](auto act_c, auto clip_c) {
+#pragma unroll
+            for (int r = t / W0; r < kTileRows; r += 256 / W0)
+                s_p[r * kPitch + col0] = finish_t<decltype(act_c)::value, decltype(clip_c)::value>(fmaf(s_x[r], w0, 0.0f), b0, slp[0], a.clip[0]);
+        });
+        __syncthreads();
+        wg_layer<W0 / 8, 0, 4>(s_p, s_p, s_q, B1, bia[1], a.act[1], slp[1], a.clip[1], wv, li, lh);
+        __syncthreads();
+        wg_layer<W1 / 8, CY / 8, 4>(s_q, s_y, s_p, B2, bia[2], a.act[2], slp[2], a.clip[2], wv, li, lh);
+        __syncthreads();
+        wg_layer<W2 / 8, 0, 4>(s_p, s_p, s_q, B3, bia[3], a.act[3], slp[3], a.clip[3], wv, li, lh);
+        __syncthreads();
+        tile_to_global<W3>(s_q, a.out, a.ldo, row0, a.n, t);
+        // s_q is read here and next written by layer 1 of the following tile, two barriers further on; s_y / s_x are rewritten at
+        // the top of the loop, after every wave has passed the barrier behind the layer that read them
+    }
+}
+
+// SubDecoderGeoLossl2: x [n, CX] -> W -> W (two square-ish MFMA layers of equal width)
+template <int CX, int W>
+__global__ __launch_bounds__(256, 1) void k_mlp_chain_b(WgArgs a) {
+    static_assert((W == 128 || W == 64) && CX % 32 == 0, "");
+    constexpr int NCB = W / 32;
+    __shared__ __attribute__((aligned(16))) float s_p[kTileFloats], s_q[kTileFloats];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int cb = wv % NCB;
+    f32x4 B0[CX / 8], B1[W / 8];
+    load_b(B0, a.wp[0], NCB, cb, lane);
+    load_b(B1, a.wp[1], NCB, cb, lane);
+    float bia[2], slp[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        bia[l] = a.bias[l] ? a.bias[l][32 * cb + li] : 0.0f;
+        slp[l] = (a.act[l] == FPCC_ACT_PRELU && a.slope[l]) ? a.slope[l][0] : 0.0f;
+    }
+    f32x4 xv[CX / 16];
+    unsigned tile = blockIdx.x;
+    if (tile < a.n_tiles) stage_load<CX>(xv, a.x, a.ldx, (int64_t)tile * kTileRows, a.n, t);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t row0 = (int64_t)tile * kTileRows;
+        stage_store<CX>(xv, s_p, t);
+        __syncthreads();
+        const unsigned nxt = tile + gridDim.x;
+        if (nxt < a.n_tiles) stage_load<CX>(xv, a.x, a.ldx, (int64_t)nxt * kTileRows, a.n, t);
+        wg_layer<CX / 8, 0, NCB>(s_p, s_p, s_q, B0, bia[0], a.act[0], slp[0], a.clip[0], wv, li, lh);
+        __syncthreads();
+        wg_layer<W / 8, 0, NCB>(s_q, s_q, s_p, B1, bia[1], a.act[1], slp[1], a.clip[1], wv, li, lh);
+        __syncthreads();
+        tile_to_global<W>(s_p, a.out, a.ldo, row0, a.n, t);
+        __syncthreads();                              // s_p is refilled with the next tile's input right away
+    }
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool width_ok(int c) { return c == 32 || c == 64 || c == 128; }
 
@@ -194,6 +423,15 @@ inline bool width_ok(int c) { return c == 32 || c == 64 || c == 128; }
 }  // namespace fpcc
 
 using namespace fpcc;
+
+// 1 (default; FPCC_MLP_CHAIN_WG): the codecs' chain shapes run in the workgroup form, 0: everything in the wave form.  Result-neutral.
+static int g_chain_form = [] { const char *e = getenv("FPCC_MLP_CHAIN_WG"); return e ? atoi(e) : 1; }();
+
+extern "C" int fpcc_mlp_chain_set_form(int form) {
+    const int before = g_chain_form;
+    if (form >= 0) g_chain_form = form;
+    return before;
+}
 
 extern "C" int fpcc_mlp_chain_f32(const fpcc_mlp_chain *d, void *stream) {
     if (!d) return fail_arg("mlp_chain: null descriptor");
@@ -236,6 +474,31 @@ extern "C" int fpcc_mlp_chain_f32(const fpcc_mlp_chain *d, void *stream) {
         prev = s.c_out;
     }
     if (d->ldo < prev) return fail_arg("mlp_chain: output row stride smaller than the row");
+    // the chain shapes of the codecs run in the workgroup form (weights in registers); FPCC_MLP_CHAIN_WG=0 keeps the wave form
+    if (g_chain_form != 0) {
+        WgArgs g{};
+        g.x = d->x; g.ldx = d->ldx; g.y = d->y; g.ldy = d->ldy; g.out = d->out; g.ldo = d->ldo; g.n = d->n;
+        g.n_tiles = (unsigned)((d->n + kTileRows - 1) / kTileRows);
+        for (int l = 0; l < d->n_layers; ++l) {
+            g.wp[l] = a.L[l].wp; g.bias[l] = a.L[l].bias; g.slope[l] = a.L[l].slope; g.act[l] = a.L[l].act; g.clip[l] = a.L[l].clip;
+        }
+        g.w1 = a.L[0].w1;
+        const unsigned grid = g.n_tiles < 256u ? g.n_tiles : 256u;
+        const fpcc_mlp_layer *L = d->layers;
+        const bool y_ok = d->cat_layer == 2 && d->cy == 128 && aligned16(d->y) && d->ldy % 4 == 0;
+        if (d->n_layers == 4 && d->cx == 1 && y_ok && L[0].c_out == 64 && L[1].c_out == 128 && L[2].c_out == 128 && L[3].c_out == 128) {
+            hipLaunchKernelGGL((k_mlp_chain_a<64, 128, 128, 128, 128>), dim3(grid), dim3(256), 0, as_stream(stream), g);
+            return check_hip(hipGetLastError(), "k_mlp_chain_a");
+        }
+        if (d->n_layers == 2 && d->cat_layer < 0 && d->cx == 128 && L[0].c_out == 128 && L[1].c_out == 128) {
+            hipLaunchKernelGGL((k_mlp_chain_b<128, 128>), dim3(grid), dim3(256), 0, as_stream(stream), g);
+            return check_hip(hipGetLastError(), "k_mlp_chain_b");
+        }
+        if (d->n_layers == 2 && d->cat_layer < 0 && d->cx == 64 && L[0].c_out == 64 && L[1].c_out == 64) {
+            hipLaunchKernelGGL((k_mlp_chain_b<64, 64>), dim3(grid), dim3(256), 0, as_stream(stream), g);
+            return check_hip(hipGetLastError(), "k_mlp_chain_b");
+        }
+    }
     a.n_row_blocks = (unsigned)((d->n + 31) / 32);
     unsigned waves = 256u * 4u * 2u;                         // two waves per SIMD on the whole chip
     if (waves > a.n_row_blocks) waves = a.n_row_blocks;

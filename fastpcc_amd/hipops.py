@@ -88,6 +88,7 @@ _SIGS = {
     'fpcc_simple_dec_pop_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
     'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
+    'fpcc_mlp_chain_set_form': (_i32, [_i32]),
     'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
@@ -430,6 +431,11 @@ class _MlpLayer(C.Structure):
 class _MlpChain(C.Structure):
     _fields_ = [('x', _vp), ('cx', _i32), ('ldx', _i32), ('y', _vp), ('cy', _i32), ('ldy', _i32), ('cat_layer', _i32),
                 ('n_layers', _i32), ('layers', _MlpLayer * 4), ('out', _vp), ('ldo', _i32), ('n', _i64)]
+
+
+def mlp_chain_set_form(form: int) -> int:
+    """1: workgroup form for the codecs' chain shapes (default), 0: wave form for all; returns the previous setting (result-neutral)"""
+    return lib().fpcc_mlp_chain_set_form(int(form))
 
 
 def mlp_chain_ok(cx: int, widths, cat_layer: int = -1, cy: int = 0) -> bool:

@@ -225,6 +225,10 @@ typedef struct {
     int64_t n;
 } fpcc_mlp_chain;
 int fpcc_mlp_chain_f32(const fpcc_mlp_chain *chain, void *stream);
+/* Tuning (result-neutral): 1 = the chain shapes of the codecs (1->64->128 ++128 ->128->128, 128->128->128, 64->64->64) run in the
+ * workgroup form that keeps the weights in registers (default), 0 = every chain in the wave form; negative = query.  Returns
+ * the previous setting. */
+int fpcc_mlp_chain_set_form(int form);
 /* row_order (MFMA path only, NULL = natural): a permutation of [0, n_out); tile position p computes output row
  * row_order[p].  It changes which rows share a 32-row MFMA block -- and with it how many (block, offset) products are
  * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows

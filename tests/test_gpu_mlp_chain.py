@@ -35,6 +35,7 @@ CHAINS = [  # cx, widths, cat_layer, cy
     (1, [64, 128, 128, 128], 2, 128),          # SubDecoderGeoLossl of baseline_r1
     (128, [128, 128], -1, 0),                  # SubDecoderGeoLossl2
     (128, [64, 64], -1, 0),
+    (64, [64, 64], -1, 0),                     # SubDecoderGeoLossl2 of the 64-channel top level
     (64, [32], -1, 0),
     (256, [128, 64, 32], -1, 0),
     (1, [32, 64], 1, 32),
@@ -43,7 +44,7 @@ CHAINS = [  # cx, widths, cat_layer, cy
 ]
 
 
-@pytest.mark.parametrize('n', [1, 31, 32, 33, 1000, 70001])
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 63, 64, 65, 1000, 70001])
 @pytest.mark.parametrize('cx,widths,cat_layer,cy', CHAINS)
 def test_fused_chain_equals_the_separate_launches(n, cx, widths, cat_layer, cy):
     from fastpcc_amd import hipops as ops
@@ -54,11 +55,17 @@ def test_fused_chain_equals_the_separate_launches(n, cx, widths, cat_layer, cy):
     spec = _layers(rng, cx, widths, cat_layer, cy, 1.7)
     dev = [(_cuda(w), None if b is None else _cuda(b), act, torch.tensor([s], device='cuda') if act == 1 else None, clip)
            for w, b, act, s, clip in spec]
-    got = ops.mlp_chain(x, dev, y=y, cat_layer=cat_layer)
     h = x
     for l, (w, b, act, slope, clip) in enumerate(dev):
         h = ops.conv_f32(h, w, w.shape[1], n, x2=y if l == cat_layer else None, bias=b, act=act, slope=slope, clip=clip, pack=True)
-    assert got.shape == h.shape and (_bits(got) == _bits(h)).all()
+    before = ops.mlp_chain_set_form(1)
+    try:
+        for form in (1, 0):                       # workgroup form (weights in registers; the codecs' shapes) and wave form
+            ops.mlp_chain_set_form(form)
+            got = ops.mlp_chain(x, dev, y=y, cat_layer=cat_layer)
+            assert got.shape == h.shape and (_bits(got) == _bits(h)).all(), form
+    finally:
+        ops.mlp_chain_set_form(before)
 
 
 @pytest.mark.parametrize('cx,widths,cat_layer,cy', CHAINS[:3] + CHAINS[5:7])

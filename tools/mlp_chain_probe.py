@@ -12,7 +12,7 @@ from fastpcc_amd import hipops as ops
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 CHAINS = {'decoder block 1->64->128 ++128 ->128->128': (1, [64, 128, 128, 128], 2, 128),
           'decoder block 128->128->128': (128, [128, 128], -1, 0),
-          'decoder block 128->64->64': (128, [64, 64], -1, 0)}
+          'decoder block 64->64->64': (64, [64, 64], -1, 0)}
 
 
 def timed(fn):
@@ -50,5 +50,10 @@ for name, (cx, widths, cat, cy) in CHAINS.items():
 
         fused = lambda: ops.mlp_chain(x, layers, y=y, cat_layer=cat)
         assert torch.equal(fused(), unfused())
-        tu, tf = timed(unfused), timed(fused)
-        print(f'{name:45s} rows {n:7d}: separate {tu:8.1f} us   fused {tf:8.1f} us ({flops / tf / 1e6:6.1f} TFLOP/s)   x{tu / tf:.2f}')
+        tu = timed(unfused)
+        ops.mlp_chain_set_form(0)
+        tw = timed(fused)
+        ops.mlp_chain_set_form(1)
+        tf = timed(fused)
+        print(f'{name:45s} rows {n:7d}: separate {tu:8.1f} us   wave form {tw:8.1f} us   workgroup form {tf:8.1f} us '
+              f'({flops / tf / 1e6:6.1f} TFLOP/s)   x{tu / tf:.2f}')
