@@ -38,15 +38,41 @@ PRE_SHIFT = SharedFxpShift - 16          # Q8.23 logits -> Q15.16 softmax input
 class SparseSequential(nn.Sequential):
     """modules of _DENSE act on the feature matrix, the others on the sparse tensor (model.py:524-534)"""
 
-    def forward(self, input: SparseTensor) -> SparseTensor:
+    def forward(self, input: SparseTensor, _also=None) -> SparseTensor:
+        """_also: requantisers that will consume the LAST module's output (handed to it when it can write their int8 copies)"""
         x = SparseTensor(input.F, input.C, input.stride, input.spatial_range)
         x._caches = input._caches
-        for module in self:
-            if isinstance(module, _DENSE):
-                x.F = module(x.F)
-            else:
-                x = module(x)
+        mods = list(self)
+        for i, module in enumerate(mods):
+            x = _apply(module, x, _consumers(mods, i + 1) or (_also if i == len(mods) - 1 else None))
         return x
+
+
+def _consumers(mods, at: int):
+    """the requantiser that reads the output of mods[at - 1], when the next module is one (or starts with one)"""
+    if at >= len(mods):
+        return None
+    nxt = mods[at]
+    if isinstance(nxt, RequantFxpToScaledInt8):
+        return [nxt]
+    if isinstance(nxt, SparseResBlockIn32W8Out32):
+        return [nxt.input_requant]
+    return None
+
+
+def _apply(module, x: SparseTensor, also) -> SparseTensor:
+    """one module of a SparseSequential; producers of Q8.23 activations are told their consumers' requantisers"""
+    if isinstance(module, _DENSE):
+        if also and isinstance(module, (LinearIn8W8Out32, LinearPReLUIn8W8Out32)):
+            x.F = module(x.F, _also=also)
+        else:
+            x.F = module(x.F)
+        return x
+    if also and isinstance(module, SparseResBlockIn32W8Out32):
+        return module(x, _also=also)
+    if also and isinstance(module, (SparseConvIn8W8Out32, SparseConvPReLUIn8W8Out32)):
+        return module.forward_with_sparse_tensor(x, _also=also)
+    return module(x)
 
 
 class Occupancy:
@@ -114,7 +140,7 @@ def _as_occ(mask, count: Optional[int] = None) -> Occupancy:
     return occ
 
 
-def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask, count: Optional[int] = None) -> torch.Tensor:
+def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask, count: Optional[int] = None, _also=None) -> torch.Tensor:
     """seq(x).F.reshape(n, 8, C)[mask] for a sequence that ends in a linear layer C_in -> 8*C (model.py:66-74,169-175): the
     reference evaluates all 8*C columns of every row and keeps the occupied octants; here the last layer is evaluated for the
     occupied (row, octant) pairs only -- an 8-"offset" gather convolution whose table has one entry per output row, followed by
@@ -127,16 +153,20 @@ def _occupied_outputs(seq: 'SparseSequential', x: SparseTensor, mask, count: Opt
         return f.reshape(f.shape[0], 8, f.shape[1] // 8)[occ.parent_row.long(), occ.octant.long()]
     y = SparseTensor(x.F, x.C, x.stride, x.spatial_range)
     y._caches = x._caches
-    for module in list(seq)[:-1]:
-        if isinstance(module, _DENSE):
-            y.F = module(y.F)
-        else:
-            y = module(y)
+    mods = list(seq)
+    for i, module in enumerate(mods[:-1]):
+        y = _apply(module, y, _consumers(mods, i + 1))
     n_child, ch = occ.count, last.out_ch // 8
     w = last._padded_weight()                                           # [1, 8*C, ldw] -> [8, C, ldw]
     raw = ops.conv_i8(y.F, w.view(8, ch, w.shape[-1]), last.in_ch, ch, n_child, nbr=occ.table, n_offsets=8, nbr_ks=1, nbr_os=8,
                       nbr_bias=1)
     ep = last._epilogue()
+    if _also:                                                        # the next level's first requantiser: written right here
+        hints = list(_also)
+        out, extra = ops.epilogue_i32(raw, ep['requant_mul'], ep['zero_point'], ep['shift'], ep['out_bits'], bias=ep['bias'],
+                                      row_group=occ.octant, also=[h.hint(ch) for h in hints])
+        out._fpcc_q8 = {id(h): b for h, b in zip(hints, extra)}
+        return out
     return ops.epilogue_i32(raw, ep['requant_mul'], ep['zero_point'], ep['shift'], ep['out_bits'], bias=ep['bias'],
                             row_group=occ.octant)
 
@@ -185,7 +215,14 @@ class OneScalePredictor(nn.Module):
     def _trunk(self, cur_rec: SparseTensor):
         if cur_rec.F.shape[1] == 1:
             cur_rec = self.dec_init(cur_rec)
-        cur_rec = self.dec(cur_rec)
+        # the block's output R is requantised twice: for `pred` and -- with the occupancy bits appended -- for `upsample`; both
+        # int8 copies come out of the block's last epilogue (the second with room for the 8 bit columns, filled in `_expand`)
+        also = None
+        if isinstance(self.dec, SparseResBlockIn32W8Out32) and len(self.pred) and isinstance(self.pred[0], RequantFxpToScaledInt8):
+            also = [self.pred[0]]
+            if self.upsample is not None and len(self.upsample) and isinstance(self.upsample[0], RequantFxpToScaledInt8):
+                also.append((self.upsample[0], (self.dec.ch + 8 + 15) // 16 * 16))
+        cur_rec = self.dec(cur_rec, _also=also) if also else self.dec(cur_rec)
         return cur_rec, self.pred(cur_rec).F
 
     def _feat_of(self, occ) -> torch.Tensor:
@@ -194,25 +231,45 @@ class OneScalePredictor(nn.Module):
         occ = _as_occ(occ)
         return occ.fxp if self._feat is OneScalePredictor._feat else self._feat(occ.bits)
 
-    def _expand(self, cur_rec: SparseTensor, bits, child_coords: torch.Tensor) -> SparseTensor:
+    def _expand(self, cur_rec: SparseTensor, bits, child_coords: torch.Tensor, _also=None) -> SparseTensor:
         occ = _as_occ(bits, child_coords.shape[0])
-        cur_rec.F = torch.cat((cur_rec.F, self._feat_of(occ)), 1)
-        feats = _occupied_outputs(self.upsample, cur_rec, occ)
+        ready = getattr(cur_rec.F, '_fpcc_q8', None)
+        first = self.upsample[0] if len(self.upsample) else None
+        if ready is not None and id(first) in ready and self._feat is OneScalePredictor._feat:
+            # requant(cat(R, bits << 23)) = [requant(R) | requant(bits << 23)]: the left part was written by the trunk's last
+            # epilogue, the eight bit columns are filled here; the int32 concatenation is never built
+            q = ready[id(first)]
+            mul, zp, shift, _ = first.hint(q.shape[1])
+            ops.fill_bits_i8(occ.bits, q, cur_rec.F.shape[1], mul, zp, shift, 1 << SharedFxpShift)
+        else:
+            cur_rec.F = torch.cat((cur_rec.F, self._feat_of(occ)), 1)
+        feats = _occupied_outputs(self.upsample, cur_rec, occ, _also=_also)
         return SparseTensor(feats, child_coords, tuple(s // 2 for s in cur_rec.stride))
 
-    def compress(self, cur_rec, up_ref: SparseTensor, cur_bin, bin2oct_kernel, if_upsample):
+    @staticmethod
+    def _first_requant_of(block):
+        """the requantiser that will read this level's output features in `block` (the next finer level's predictor), if it reads
+        them as they are (a one-scale predictor's residual block); None otherwise"""
+        dec = getattr(block, 'dec', None)
+        if isinstance(block, OneScalePredictor) and isinstance(dec, SparseResBlockIn32W8Out32):
+            return [dec.input_requant]
+        return None
+
+    def compress(self, cur_rec, up_ref: SparseTensor, cur_bin, bin2oct_kernel, if_upsample, next_block=None):
         cur_rec, cur_pred = self._trunk(cur_rec)
         cur_oct = _symbols_of(cur_bin, bin2oct_kernel)
         if if_upsample:
-            cur_rec = self._expand(cur_rec, Occupancy(symbols=cur_oct, count=up_ref.C.shape[0]), up_ref.C)
+            cur_rec = self._expand(cur_rec, Occupancy(symbols=cur_oct, count=up_ref.C.shape[0]), up_ref.C,
+                                   _also=self._first_requant_of(next_block))
             cur_rec._caches = up_ref._caches
         return cur_rec, cur_pred, cur_oct
 
-    def decompress(self, cur_rec, bin2oct_kernel, unfold_kernel, rans_decode_oct, if_upsample):
+    def decompress(self, cur_rec, bin2oct_kernel, unfold_kernel, rans_decode_oct, if_upsample, next_block=None):
         cur_rec, cur_pred = self._trunk(cur_rec)
         cur_bin = _bits_of(rans_decode_oct(cur_pred), bin2oct_kernel)
         if if_upsample:
-            cur_rec = self._expand(cur_rec, cur_bin, _children_of(cur_rec.C, unfold_kernel, cur_bin))
+            cur_rec = self._expand(cur_rec, cur_bin, _children_of(cur_rec.C, unfold_kernel, cur_bin),
+                                   _also=self._first_requant_of(next_block))
         return cur_rec, cur_bin
 
 
@@ -266,6 +323,9 @@ class OneScaleMultiStepPredictor(nn.Module):
     def _refresh(self, cur_rec: SparseTensor, embed_in: SparseTensor) -> SparseTensor:
         embed_in._caches = cur_rec._caches
         cur_rec.F = torch.cat([cur_rec.F, self.embed(embed_in).F], 1)
+        first = self.pred[0][0] if len(self.pred) and len(self.pred[0]) else None
+        if isinstance(first, RequantFxpToScaledInt8) and isinstance(self.dec, (SparseSequential, SparseResBlockIn32W8Out32)):
+            return self.dec(cur_rec, _also=[first])                  # pred[0]'s requantiser: written by the block's last epilogue
         return self.dec(cur_rec)
 
     def _descend(self, cur_rec: SparseTensor, masks: List[torch.Tensor], bits_below: List[torch.Tensor],
@@ -481,7 +541,8 @@ class Model(nn.Module):
             block = self._block(idx, blocks)
             if isinstance(block, OneScalePredictor):
                 cur_rec, logits, symbols = block.compress(cur_rec, strided[idx - 1], strided[idx].F, self.bin2oct_kernel,
-                                                          if_upsample=idx != 1 and block.if_upsample)
+                                                          if_upsample=idx != 1 and block.if_upsample,
+                                                          next_block=self._block(idx - 1, blocks) if idx > 1 else None)
             else:
                 cur_rec, logits, symbols = block.compress(cur_rec, strided[idx: idx + block.pred_steps], self.bin2oct_kernel)
             pending.append(ops.logits_to_ranges(logits.contiguous(), PRE_SHIFT, symbols.contiguous()))
@@ -540,7 +601,8 @@ class Model(nn.Module):
             block = self._block(idx, blocks)
             if isinstance(block, OneScalePredictor):
                 cur_rec, cur_bin = block.decompress(cur_rec, self.bin2oct_kernel, self.unfold_kernel, self.rans_decode_oct,
-                                                    if_upsample=idx != 1 and block.if_upsample)
+                                                    if_upsample=idx != 1 and block.if_upsample,
+                                                    next_block=self._block(idx - 1, blocks) if idx > 1 else None)
             else:
                 cur_bins.append(cur_bin)
                 cur_rec, cur_bin, top_rec, top_stride = block.decompress(

@@ -11,6 +11,7 @@
 // dependency-bound, not math-bound, so the kernel favours few launches (bias/PReLU/requant fused, raw conv optional)
 // over peak MFMA rate.
 #include "common.h"
+#include <cstddef>
 #include <cstdlib>
 
 namespace fpcc {
@@ -122,6 +123,15 @@ __device__ __forceinline__ int32_t requant(int64_t v, uint32_t mul, int64_t zp, 
     return (int32_t)(r < lo ? lo : (r > hi ? hi : r));
 }
 
+// Additional int8 copies of an int32 (Q8.23) result, each requantised with the parameters of ONE consumer's RequantFxpToScaledInt8
+// (cuda_ops.py:473-509: per-tensor multiplier, zero point, shift): written by the producer's epilogue, so the consumers'
+// stand-alone requantisation launches -- one read of the [n, C] int32 matrix and one int8 write each -- disappear.
+struct Also8 {                                           // scalar fields on purpose: arrays indexed in a loop end up in scratch
+    int8_t *out0; int ld0; int pad0; const uint32_t *mul0; const int64_t *zp0; int shift0;     // columns [c_out, pad) are zeroed
+    int8_t *out1; int ld1; int pad1; const uint32_t *mul1; const int64_t *zp1; int shift1;
+    int n;
+};
+
 struct ConvI8Args {
     const int8_t *a; int lda;               // [n_in][lda] int8, lda % 16 == 0, columns >= c_in zero
     const int32_t *nbr; int n_off; int64_t nbr_ks; int64_t nbr_os; int nbr_bias;   // input row = nbr[...] - nbr_bias, < 0 absent
@@ -132,7 +142,74 @@ struct ConvI8Args {
     void *out; int ldo; int c_out; int64_t n_out; int out_pad;   // columns [c_out, out_pad) of an int8 output are zeroed
     const int32_t *row_order;               // tile position -> output row (NULL: identity)
     const int32_t *res; int ld_res; const int32_t *slope2;   // int32 outputs only: out = clamp_i32(prelu(res + out (wrapping), slope2))
+    Also8 also;                                              // int32 outputs only
 };
+
+// The descriptor is read from the kernel-argument segment where the epilogue needs it: referenced as `p.also` the compiler loads
+// its 13 fields into SGPRs at kernel entry and keeps them live through the main loop (22 SGPR spills, 320 bytes of scratch per
+// lane and a 5x slower k_conv_i8_tiled, measured).  Valid because ConvI8Args is the kernels' first (by-value) parameter.
+__device__ __forceinline__ Also8 load_also8() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const char __attribute__((address_space(4))) *CP;
+    typedef const int32_t __attribute__((address_space(4))) *IP;
+    const CP base = (CP)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvI8Args, also);
+    Also8 e;
+    int32_t *dst = reinterpret_cast<int32_t *>(&e);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Also8) / 4; ++i) dst[i] = ((IP)base)[i];
+    return e;
+#else
+    return Also8{};
+#endif
+}
+
+__device__ __forceinline__ int32_t pack4_i8(int32_t a, int32_t b, int32_t c, int32_t d) {
+    return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | (int32_t)((uint32_t)(d & 0xff) << 24);
+}
+
+// The wave's finished 32 x (32 NB) tile of int32 results, read back (its own stores, L2-resident) four columns per lane and
+// written as the consumers' int8 copies.  A compact loop behind the unrolled epilogue on purpose: requantising inside the
+// epilogue triples its 64-element body, and the accumulators end up in scratch.
+template <int NB>
+__device__ __forceinline__ void also8_tail(const ConvI8Args &p, const int32_t *my_rows, int col0, int lane) {
+    if (p.out_bits != 32) return;
+    const Also8 e = load_also8();
+    if (e.n == 0) return;
+    __builtin_amdgcn_s_waitcnt(0);                           // this wave's stores of the tile have left
+    __builtin_amdgcn_wave_barrier();
+    constexpr int Q = 8 * NB;                                // groups of four columns per row
+    const int32_t *out = static_cast<const int32_t *>(p.out);
+    for (int idx = lane; idx < 32 * Q; idx += 64) {
+        const int r = idx / Q, col = col0 + 4 * (idx - r * Q);
+        const int64_t o = my_rows[r];
+        if (o < 0 || col >= p.ldo) continue;
+        i32x4 v = {0, 0, 0, 0};
+        if (col < p.c_out) v = *reinterpret_cast<const i32x4 *>(out + o * p.ldo + col);     // c_out, ldo multiples of 4 (checked on the host)
+        for (int i = 0; i < e.n; ++i) {
+            int8_t *dst = i == 0 ? e.out0 : e.out1;
+            const int ld = i == 0 ? e.ld0 : e.ld1, pad = i == 0 ? e.pad0 : e.pad1, sh = i == 0 ? e.shift0 : e.shift1;
+            const uint32_t mul = (i == 0 ? e.mul0 : e.mul1)[0];
+            const int64_t zp = (i == 0 ? e.zp0 : e.zp1)[0];
+            if (col < p.c_out)
+                *reinterpret_cast<int32_t *>(dst + o * ld + col) = pack4_i8(requant(v.x, mul, zp, sh, 8), requant(v.y, mul, zp, sh, 8),
+                                                                            requant(v.z, mul, zp, sh, 8), requant(v.w, mul, zp, sh, 8));
+            else if (col < pad)
+                *reinterpret_cast<int32_t *>(dst + o * ld + col) = 0;
+        }
+    }
+}
+
+// single element form for the stand-alone epilogue kernel
+__device__ __forceinline__ void store_also8(const Also8 &e, int64_t o, int col, int c_out, int32_t v) {
+    if (e.n > 0) {
+        if (col < c_out) e.out0[o * e.ld0 + col] = (int8_t)requant((int64_t)v, e.mul0[0], e.zp0[0], e.shift0, 8);
+        else if (col < e.pad0) e.out0[o * e.ld0 + col] = 0;
+    }
+    if (e.n > 1) {
+        if (col < c_out) e.out1[o * e.ld1 + col] = (int8_t)requant((int64_t)v, e.mul1[0], e.zp1[0], e.shift1, 8);
+        else if (col < e.pad1) e.out1[o * e.ld1 + col] = 0;
+    }
+}
 
 // tail of SparseResBlockIn32W8Out32.forward fused behind the convolution's own epilogue (cuda_ops.py:82-92): the int32 tensor
 // add of the reference wraps, the PReLU is `prelu` of src/element_wise/prelu.cu
@@ -286,6 +363,7 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p, int32_t *acc_out,
             else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
         }
     }
+    also8_tail<NB>(p, my_rows, col0, lane);
 }
 
 // Workgroup-tiled variant for maps that fill the chip with row tiles: 4 waves = 128 output rows x 32*NB output columns.
@@ -442,15 +520,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
             else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
         }
     }
+    also8_tail<NB>(p, my_rows, col0, lane);
 }
 
 // stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
 __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const int32_t *bias, const int32_t *slope,
                                const uint32_t *mul, int mul_stride, const int64_t *zp, int shift, int out_bits,
                                void *out, int ldo, int64_t n, int ch, int out_pad, const int32_t *row_group,
-                               const int32_t *res = nullptr, int ld_res = 0, const int32_t *slope2 = nullptr) {
+                               const int32_t *res = nullptr, int ld_res = 0, const int32_t *slope2 = nullptr, Also8 also = Also8{}) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int width = out_pad > ch ? out_pad : ch;
+    int width = out_pad > ch ? out_pad : ch;
+    if (also.n > 0 && also.pad0 > width) width = also.pad0;
+    if (also.n > 1 && also.pad1 > width) width = also.pad1;
     if (e >= n * width) return;
     const int64_t r = e / width;
     const int c = (int)(e - r * width);
@@ -461,8 +542,13 @@ __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const in
         if (slope) t = prelu_q625(t, slope[0]);
         v = requant(t, mul[pc * mul_stride], zp ? zp[0] : 0, shift, out_bits);
     }
-    if (out_bits == 8) static_cast<int8_t *>(out)[r * ldo + c] = (int8_t)v;
-    else if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = res ? residual_prelu(v, res[r * ld_res + c], slope2[0]) : v;
+    if (out_bits == 8) {
+        if (c < (out_pad > ch ? out_pad : ch)) static_cast<int8_t *>(out)[r * ldo + c] = (int8_t)v;
+    } else {
+        const int32_t vf = (c < ch && res) ? residual_prelu(v, res[r * ld_res + c], slope2[0]) : v;
+        if (c < ch) static_cast<int32_t *>(out)[r * ldo + c] = vf;
+        if (also.n) store_also8(also, r, c, ch, vf);
+    }
 }
 
 // out = clamp_i32(prelu_q625(a (+ b)))
@@ -707,12 +793,43 @@ extern "C" int fpcc_conv_i8(const int8_t *a, int c_in, int lda, const int32_t *n
                             ws_bytes, stream);
 }
 
+static int make_also(const fpcc_requant8 *also, int n_also, int out_bits, bool has_requant, int c_out, int covered_cols, Also8 &e) {
+    e = Also8{};
+    if (n_also < 0 || n_also > 2) return fail_arg("at most two additional int8 outputs");
+    if (n_also == 0) return FPCC_OK;
+    if (!also || out_bits != 32 || !has_requant) return fail_arg("additional int8 outputs need a requantised int32 primary output");
+    if (c_out % 4) return fail_arg("additional int8 outputs need a channel count that is a multiple of 4");
+    for (int i = 0; i < n_also; ++i) {
+        const fpcc_requant8 &q = also[i];
+        if (!q.out || !q.requant_mul || !q.zero_point || q.shift < 0 || q.ld < c_out || q.pad > q.ld || q.pad > covered_cols || q.ld % 4 ||
+            q.pad % 4 || (reinterpret_cast<uintptr_t>(q.out) & 3))
+            return fail_arg("additional int8 output: null / unaligned pointer, negative shift or row stride / padding out of range");
+        const int pad = q.pad > c_out ? q.pad : c_out;
+        if (i == 0) { e.out0 = q.out; e.ld0 = q.ld; e.pad0 = pad; e.mul0 = q.requant_mul; e.zp0 = q.zero_point; e.shift0 = q.shift; }
+        else { e.out1 = q.out; e.ld1 = q.ld; e.pad1 = pad; e.mul1 = q.requant_mul; e.zp1 = q.zero_point; e.shift1 = q.shift; }
+    }
+    e.n = n_also;
+    return FPCC_OK;
+}
+
 extern "C" int fpcc_conv_i8_res(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
                                 int64_t nbr_os, int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp,
                                 const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
                                 const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad, int c_out,
                                 int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
                                 const int32_t *slope2, void *ws, int64_t ws_bytes, void *stream) {
+    return fpcc_conv_i8_also(a, c_in, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, zp_comp, bias, slope, requant_mul, zero_point,
+                             shift, out_bits, out, ldo, out_pad, c_out, n_out, row_order, residual, ld_res, slope2, nullptr, 0, ws, ws_bytes,
+                             stream);
+}
+
+extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks,
+                                 int64_t nbr_os, int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp,
+                                 const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
+                                 const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad, int c_out,
+                                 int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
+                                 const int32_t *slope2, const fpcc_requant8 *also, int n_also, void *ws, int64_t ws_bytes,
+                                 void *stream) {
     if (residual && (!slope2 || out_bits != 32 || !requant_mul || ld_res < c_out))
         return fail_arg("conv_i8: a fused residual needs its PReLU slope, a requantised int32 output and ld_res >= c_out");
     if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1 || n_offsets > kI8MaxOffsets)
@@ -728,8 +845,9 @@ extern "C" int fpcc_conv_i8_res(const int8_t *a, int c_in, int lda, const int32_
     if (ldo < c_out || out_pad > ldo) return fail_arg("conv_i8: output row stride too small");
     ConvI8Args p{a, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, (c_in + 31) / 32, zp_comp,
                  bias, slope, requant_mul, zero_point, shift, out_bits, out, ldo, c_out, n_out, out_pad, row_order,
-                 residual, ld_res, slope2};
+                 residual, ld_res, slope2, Also8{}};
     const int width = out_pad > c_out ? out_pad : c_out;
+    if (int rc = make_also(also, n_also, out_bits, requant_mul != nullptr, c_out, width, p.also)) return rc;
     const unsigned gx = (unsigned)((n_out + 127) / 128);
     hipStream_t s = as_stream(stream);
     if (i8_split(nbr, n_offsets, n_out)) {
@@ -750,7 +868,7 @@ extern "C" int fpcc_conv_i8_res(const int8_t *a, int c_in, int lda, const int32_
         if (requant_mul) {
             hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
                                slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0, nullptr,
-                               residual, ld_res, slope2);
+                               residual, ld_res, slope2, p.also);
             FPCC_LAUNCHED(k_epilogue_i32);
         }
         return FPCC_OK;
@@ -773,17 +891,59 @@ extern "C" int fpcc_epilogue_i32(const int32_t *in, int ldi, const int32_t *bias
                                  const uint32_t *requant_mul, int mul_per_channel, const int64_t *zero_point, int shift,
                                  int out_bits, void *out, int ldo, int out_pad, int64_t n, int ch, const int32_t *row_group,
                                  void *stream) {
+    return fpcc_epilogue_i32_also(in, ldi, bias, slope, requant_mul, mul_per_channel, zero_point, shift, out_bits, out, ldo, out_pad, n, ch,
+                                  row_group, nullptr, 0, stream);
+}
+
+extern "C" int fpcc_epilogue_i32_also(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope,
+                                      const uint32_t *requant_mul, int mul_per_channel, const int64_t *zero_point, int shift,
+                                      int out_bits, void *out, int ldo, int out_pad, int64_t n, int ch, const int32_t *row_group,
+                                      const fpcc_requant8 *also, int n_also, void *stream) {
     if (n < 0 || ch < 1 || shift < 0) return fail_arg("epilogue_i32: bad sizes or negative shift");
     if (n == 0) return FPCC_OK;
     if (!in || !requant_mul || !out) return fail_arg("epilogue_i32: null pointer");
     if (out_bits != 8 && out_bits != 16 && out_bits != 32) return fail_arg("epilogue_i32: out_bits must be 8, 16 or 32");
     if (out_bits == 16) return fail_arg("epilogue_i32: int16 outputs are not used by any in-scope model");
-    const int width = out_pad > ch ? out_pad : ch;
+    int width = out_pad > ch ? out_pad : ch;
     if (ldo < width || ldi < ch) return fail_arg("epilogue_i32: row stride too small");
+    Also8 e;
+    if (int rc = make_also(also, n_also, out_bits, true, ch, 1 << 30, e)) return rc;
+    if (e.n > 0 && e.pad0 > width) width = e.pad0;
+    if (e.n > 1 && e.pad1 > width) width = e.pad1;
     hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n * width, kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
                        bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch,
-                       out_bits == 8 ? out_pad : 0, row_group);
+                       out_bits == 8 ? out_pad : 0, row_group, nullptr, 0, nullptr, e);
     FPCC_LAUNCHED(k_epilogue_i32);
+    return FPCC_OK;
+}
+
+namespace fpcc {
+namespace {
+// occupancy bits as requantised int8 features behind the columns of an int8 activation matrix: out[r][col0 + k] = q(bit ? one : 0)
+// with the consumer's RequantFxpToScaledInt8 parameters, columns [col0 + 8, pad) zeroed -- the int8 image of
+// requant(cat(R, bits << shift)) without building the int32 concatenation
+__global__ void k_fill_bits_i8(const uint8_t *__restrict__ bits, int64_t n, int32_t fxp_one, const uint32_t *mul, const int64_t *zp, int shift,
+                               int8_t *__restrict__ out, int ld, int col0, int pad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = pad - col0;
+    if (e >= n * w) return;
+    const int64_t r = e / w;
+    const int k = (int)(e - r * w);
+    int8_t v = 0;
+    if (k < 8) v = (int8_t)requant(bits[8 * r + k] ? (int64_t)fxp_one : 0, mul[0], zp[0], shift, 8);
+    out[r * ld + col0 + k] = v;
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int fpcc_fill_bits_i8(const uint8_t *bits, int64_t n, int32_t fxp_one, const uint32_t *requant_mul, const int64_t *zero_point,
+                                 int shift, int8_t *out, int ld, int col0, int pad, void *stream) {
+    if (n < 0 || shift < 0 || col0 < 0 || pad < col0 + 8 || pad > ld) return fail_arg("fill_bits_i8: bad sizes");
+    if (n == 0) return FPCC_OK;
+    if (!bits || !requant_mul || !zero_point || !out) return fail_arg("fill_bits_i8: null pointer");
+    hipLaunchKernelGGL(k_fill_bits_i8, dim3(blocks_for(n * (pad - col0), kThreads)), dim3(kThreads), 0, as_stream(stream), bits, n, fxp_one,
+                       requant_mul, zero_point, shift, out, ld, col0, pad);
+    FPCC_LAUNCHED(k_fill_bits_i8);
     return FPCC_OK;
 }
 

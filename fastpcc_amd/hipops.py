@@ -89,6 +89,10 @@ _SIGS = {
     'fpcc_device_count': (_i32, []),
     'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
     'fpcc_mlp_chain_set_form': (_i32, [_i32]),
+    'fpcc_conv_i8_also': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                 _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
+    'fpcc_epilogue_i32_also': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    'fpcc_fill_bits_i8': (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
@@ -830,15 +834,48 @@ def _rows_i8(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+class _Requant8(C.Structure):
+    _fields_ = [('out', _vp), ('ld', _i32), ('pad', _i32), ('requant_mul', _vp), ('zero_point', _vp), ('shift', _i32)]
+
+
+def _also8(also, n: int, c_out: int, device):
+    """also: sequence of (requant_mul uint32[1], zero_point int64[1], shift, width) -- one extra int8 copy of an int32 result per
+    consumer requantiser; width >= c_out is the row stride of the buffer (columns past c_out belong to the caller).  Returns the
+    ctypes array, its length and the int8 tensors [n, width]."""
+    if not also:
+        return None, 0, []
+    arr = (_Requant8 * len(also))()
+    outs = []
+    for i, (mul, zp, shift, width) in enumerate(also):
+        buf = torch.empty((n, width), dtype=torch.int8, device=device)
+        m = _mul_u32(mul)
+        arr[i].out, arr[i].ld, arr[i].pad = buf.data_ptr(), width, c_out
+        arr[i].requant_mul, arr[i].zero_point, arr[i].shift = _any(m, 'requant_mul', _U32), _dev(zp, torch.int64, 'zero_point'), int(shift)
+        outs.append(buf)
+    return arr, len(also), outs
+
+
+def fill_bits_i8(bits: torch.Tensor, out: torch.Tensor, col0: int, requant_mul: torch.Tensor, zero_point: torch.Tensor, shift: int,
+                 fxp_one: int = 1 << 23) -> None:
+    """out[:, col0:col0 + 8] = requant(bits ? fxp_one : 0); out[:, col0 + 8:] = 0   (fpcc_fill_bits_i8)"""
+    n = bits.shape[0]
+    if out.dtype != torch.int8 or out.dim() != 2 or out.shape[0] != n or out.stride(1) != 1:
+        raise ValueError('out must be int8 [n, width]')
+    _ok(lib().fpcc_fill_bits_i8(_dev(bits, torch.uint8, 'bits'), n, int(fxp_one), _any(_mul_u32(requant_mul), 'requant_mul', _U32),
+                                _dev(zero_point, torch.int64, 'zero_point'), int(shift), out.data_ptr(), out.stride(0), int(col0),
+                                out.shape[1], _stream()))
+
+
 def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_out: int, *,
             nbr: Optional[torch.Tensor] = None, n_offsets: int = 1, nbr_ks: int = 0, nbr_os: int = 1, nbr_bias: int = 0,
             zp_comp: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
             slope: Optional[torch.Tensor] = None, requant_mul: Optional[torch.Tensor] = None,
             zero_point: Optional[torch.Tensor] = None, shift: int = 0, out_bits: int = 32,
             row_order: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-            slope2: Optional[torch.Tensor] = None) -> torch.Tensor:
+            slope2: Optional[torch.Tensor] = None, also=None):
     """int8 sparse conv / linear with fused fixed-point epilogue; see fpcc_conv_i8.  w_padded: int8 [K, c_out, ldw].
-    residual (int32 [n_out, c_out]) + slope2: out = prelu(residual + out) fused behind the epilogue (fpcc_conv_i8_res)."""
+    residual (int32 [n_out, c_out]) + slope2: out = prelu(residual + out) fused behind the epilogue (fpcc_conv_i8_res).
+    also: extra int8 copies of an int32 result for its consumers' requantisers (see _also8): returns (out, [int8 tensors])."""
     a = _rows_i8(a, 'a')
     if not w_padded.is_cuda:
         raise FpccError('weights must live on the GPU (libfpcc_hip has no CPU path); move the model with .cuda()')
@@ -854,21 +891,22 @@ def conv_i8(a: torch.Tensor, w_padded: torch.Tensor, c_in: int, c_out: int, n_ou
             ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=a.device)
     if residual is not None and tuple(residual.shape) != (n_out, c_out):
         raise ValueError('residual must be int32 [n_out, c_out]')
-    _ok(lib().fpcc_conv_i8_res(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
-                               nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
-                               _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
-                               _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
-                               int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _dev(row_order, torch.int32, 'row_order', True),
-                               _dev(residual, torch.int32, 'residual', True), 0 if residual is None else c_out,
-                               _dev(slope2, torch.int32, 'slope2', True),
-                               None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
-    return out
+    arr, n_also, extra = _also8(also, n_out, c_out, a.device)
+    _ok(lib().fpcc_conv_i8_also(a.data_ptr(), c_in, a.shape[1], _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+                                nbr_bias, w_padded.data_ptr(), w_padded.shape[2], _dev(zp_comp, torch.int32, 'zp_comp', True),
+                                _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True),
+                                _any(mul, 'requant_mul', _U32, True), _dev(zero_point, torch.int64, 'zero_point', True),
+                                int(shift), out_bits, out.data_ptr(), c_out, 0, c_out, n_out, _dev(row_order, torch.int32, 'row_order', True),
+                                _dev(residual, torch.int32, 'residual', True), 0 if residual is None else c_out,
+                                _dev(slope2, torch.int32, 'slope2', True), None if arr is None else C.cast(arr, _vp), n_also,
+                                None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
+    return out if also is None else (out, extra)
 
 
 def epilogue_i32(x: torch.Tensor, requant_mul: torch.Tensor, zero_point: Optional[torch.Tensor], shift: int, out_bits: int,
                  *, bias: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None,
-                 row_group: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """requant_to_int8/int32 and their bias / PReLU variants on an int32 matrix [n, ch]"""
+                 row_group: Optional[torch.Tensor] = None, also=None):
+    """requant_to_int8/int32 and their bias / PReLU variants on an int32 matrix [n, ch]; also: see conv_i8"""
     if x.dtype != torch.int32 or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         raise TypeError('input must be a 2-D int32 GPU tensor with unit column stride')
     n, ch = x.shape
@@ -881,11 +919,13 @@ def epilogue_i32(x: torch.Tensor, requant_mul: torch.Tensor, zero_point: Optiona
     elif mul.numel() not in (1, ch):
         raise ValueError('requant_mul must have 1 or ch entries')
     out = torch.empty((n, ch), dtype=torch.int8 if out_bits == 8 else torch.int32, device=x.device)
-    _ok(lib().fpcc_epilogue_i32(x.data_ptr(), x.stride(0) if n > 1 else ch, _dev(bias, torch.int32, 'bias', True),
-                                _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
-                                per_channel, _dev(zero_point, torch.int64, 'zero_point', True), int(shift), out_bits,
-                                out.data_ptr(), ch, 0, n, ch, _dev(row_group, torch.int32, 'row_group', True), _stream()))
-    return out
+    arr, n_also, extra = _also8(also, n, ch, x.device)
+    _ok(lib().fpcc_epilogue_i32_also(x.data_ptr(), x.stride(0) if n > 1 else ch, _dev(bias, torch.int32, 'bias', True),
+                                     _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
+                                     per_channel, _dev(zero_point, torch.int64, 'zero_point', True), int(shift), out_bits,
+                                     out.data_ptr(), ch, 0, n, ch, _dev(row_group, torch.int32, 'row_group', True),
+                                     None if arr is None else C.cast(arr, _vp), n_also, _stream()))
+    return out if also is None else (out, extra)
 
 
 def octree_children(n: int, m: int, *, symbols: Optional[torch.Tensor] = None, bits: Optional[torch.Tensor] = None,

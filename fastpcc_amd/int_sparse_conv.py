@@ -112,10 +112,33 @@ def sparse_conv_in8w8out32(in_feats: torch.Tensor, weight: torch.Tensor, in_coor
         # neighbour-pattern row order, computed once per kernel map and kept with it (the table is the cache object)
         in_out_maps._fpcc_row_order = ops.conv_row_order(in_out_maps - 1, volume, 1, volume, n_out, ROW_ORDER_WINDOW_LOG2)
     w = weight if weight.shape[-1] % 16 == 0 and weight.is_contiguous() else _pad_weight(weight)
-    ep = _epilogue or {}
+    ep = dict(_epilogue or {})
+    hints = ep.pop('_hints', None)
     out = ops.conv_i8(in_feats, w, in_feats.shape[1], weight.shape[1], n_out, nbr=in_out_maps, n_offsets=volume, nbr_ks=1,
                       nbr_os=volume, nbr_bias=1, zp_comp=zero_point_comp, row_order=getattr(in_out_maps, '_fpcc_row_order', None), **ep)
+    if ep.get('also') is not None:                  # (int32 result, its requantised int8 copies): keep them with the tensor
+        out = _with_q8(out[0], hints, out[1])
     return out, hashmap_kv, in_out_maps
+
+
+# ---- requantisation hints --------------------------------------------------------------------------------------------------
+# A Q8.23 activation is requantised to int8 once per consumer (RequantFxpToScaledInt8, also the input_requant of a residual
+# block), each a launch that reads the [n, C] int32 matrix again.  A producer that is told its consumers' requantisers (`_also`)
+# writes those int8 copies from its own epilogue (fpcc_conv_i8_also / fpcc_epilogue_i32_also) and hangs them on the result
+# tensor; the requantiser then finds its output ready.  Purely an execution detail: same integers, module tree untouched.
+def _with_q8(t: torch.Tensor, hints, bufs) -> torch.Tensor:
+    t._fpcc_q8 = {id(h): b for h, b in zip(hints, bufs)}
+    return t
+
+
+def _also_of(hints, c_out: int):
+    """hints: RequantFxpToScaledInt8 modules, or (module, width) for a copy with a wider row (room for appended columns)"""
+    mods, spec = [], []
+    for h in hints or ():
+        mod, width = h if isinstance(h, tuple) else (h, c_out)
+        mods.append(mod)
+        spec.append(mod.hint(width))
+    return mods, spec
 
 
 def _conv_on_sparse_tensor(input: 'SparseTensor', kernel_size, stride, run, unique=torch.unique) -> 'SparseTensor':
@@ -421,15 +444,18 @@ class SparseConvIn8Out8(_RequantParams):
             return self.forward_with_sparse_tensor(*args, **kwargs)
         return self.forward_with_coords(*args, **kwargs)
 
-    def forward_with_sparse_tensor(self, input: SparseTensor, _residual=None) -> SparseTensor:
-        run = self.forward_with_coords if _residual is None else functools.partial(self.forward_with_coords, _residual=_residual)
+    def forward_with_sparse_tensor(self, input: SparseTensor, _residual=None, _also=None) -> SparseTensor:
+        run = self.forward_with_coords if _residual is None and not _also else \
+            functools.partial(self.forward_with_coords, _residual=_residual, _also=_also)
         return _conv_on_sparse_tensor(input, self.kernel_size, self.stride, run, self.unique)
 
     def forward_with_coords(self, in_feats, in_coords, out_coords, in_out_maps=None, hashmap_kv=None,
-                            if_in_coords_equals_out_coords: bool = False, _residual=None):
+                            if_in_coords_equals_out_coords: bool = False, _residual=None, _also=None):
         ep = self._epilogue()
         if _residual is not None:
             ep['residual'], ep['slope2'] = _residual
+        if _also and not self.out_scaled_int:
+            ep['_hints'], ep['also'] = _also_of(_also, self.out_ch)
         return sparse_conv_in8w8out32(
             in_feats, self._padded_weight(), in_coords, out_coords, self.kernel_size, self.stride, in_out_maps, hashmap_kv,
             self.int_zero_point_in_comp if self.use_zero_point_in else None, if_in_coords_equals_out_coords,
@@ -513,7 +539,16 @@ class RequantFxpToScaledInt8(LoadSaveUint32RequantMul):
         self._shift_host = None
         super()._load_from_state_dict(*args, **kwargs)
 
+    def hint(self, width: int):
+        """(multiplier, zero point, shift, row width) for a producer that writes this module's output from its own epilogue"""
+        if self._shift_host is None:
+            self._shift_host = int(self.requant_shift.item())
+        return self.requant_mul, self.int_zero_point_out, SharedFxpShift + self._shift_host, width
+
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        ready = getattr(input, '_fpcc_q8', None)
+        if ready is not None and id(self) in ready:          # written by the producer of `input` (see `_with_q8`)
+            return ready[id(self)]
         if self._shift_host is None:
             self._shift_host = int(self.requant_shift.item())
         return ops.epilogue_i32(input, self.requant_mul, self.int_zero_point_out, SharedFxpShift + self._shift_host, 8)
@@ -539,13 +574,14 @@ class SparseResBlockIn32W8Out32(nn.Module):
         self.conv2.import_parameters(scale2, zero_point2, block.conv2)                                      # int8 -> Q8.23
         self.prelu.import_parameters(block.act2)
 
-    def forward(self, input: SparseTensor) -> SparseTensor:
+    def forward(self, input: SparseTensor, _also=None) -> SparseTensor:
+        """_also: requantisers of this block's consumers; their int8 outputs are written by conv2's epilogue"""
         x = SparseTensor(self.input_requant(input.F), input.C, input.stride, input.spatial_range)
         x._caches = input._caches
         # prelu(input + conv2(...)) runs in the epilogue of conv2 (fpcc_conv_i8_res): three launches per block instead of four
         # and the [N, C] int32 intermediate never reaches HBM
         res = input.F if input.F.is_contiguous() else input.F.contiguous()
-        x = self.conv2.forward_with_sparse_tensor(self.conv_prelu(x), _residual=(res, self.prelu.slope))
+        x = self.conv2.forward_with_sparse_tensor(self.conv_prelu(x), _residual=(res, self.prelu.slope), _also=_also)
         out = SparseTensor(x.F, input.C, input.stride, input.spatial_range)
         out._caches = input._caches
         return out
@@ -567,8 +603,13 @@ class LinearIn8W8(_RequantParams):
                             linear.bias.detach().float().reshape(-1), None if prelu is None else prelu.weight.detach().float(),
                             fold_zero_point_into_bias=True)
 
-    def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return ops.conv_i8(input, self._padded_weight(), self.in_ch, self.out_ch, input.shape[0], **self._epilogue())
+    def forward(self, input: torch.Tensor, _also=None) -> torch.Tensor:
+        ep = self._epilogue()
+        if _also and not self.out_scaled_int:
+            hints, ep['also'] = _also_of(_also, self.out_ch)
+            out, extra = ops.conv_i8(input, self._padded_weight(), self.in_ch, self.out_ch, input.shape[0], **ep)
+            return _with_q8(out, hints, extra)
+        return ops.conv_i8(input, self._padded_weight(), self.in_ch, self.out_ch, input.shape[0], **ep)
 
 
 class LinearIn8W8Out8(LinearIn8W8):

@@ -479,6 +479,26 @@ int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift
  * lanes fetch probabilities 64 at a time and hold the byte window. */
 int fpcc_rans_binary_decode_dev(const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
                                 uint8_t *bits_out, int32_t *ones_out, int32_t *status, void *hip_stream);
+/* Additional int8 copies of a Q8.23 int32 result, requantised for its consumers (RequantFxpToScaledInt8, cuda_ops.py:473-509) inside
+ * the producer's epilogue: out8[r][c] = clamp8(rha(v * requant_mul[0] + zero_point[0], shift)), columns [c_out, pad) zeroed.
+ * fpcc_conv_i8_also / fpcc_epilogue_i32_also = fpcc_conv_i8_res / fpcc_epilogue_i32 with up to two such outputs (int32 primary
+ * output with requantisation only); the consumers' stand-alone requantisation launches then have nothing left to do.
+ * fpcc_fill_bits_i8 writes the occupancy bits of a level behind such a matrix: out[r][col0 + k] = q(bits[r][k] ? fxp_one : 0),
+ * columns [col0 + 8, pad) zero -- the int8 image of requant(cat(R, bits << 23)) without the int32 concatenation. */
+typedef struct {
+    int8_t *out; int ld; int pad;
+    const uint32_t *requant_mul; const int64_t *zero_point; int shift;
+} fpcc_requant8;
+int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
+                      int nbr_bias, const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope,
+                      const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo,
+                      int out_pad, int c_out, int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
+                      const int32_t *slope2, const fpcc_requant8 *also, int n_also, void *ws, int64_t ws_bytes, void *stream);
+int fpcc_epilogue_i32_also(const int32_t *in, int ldi, const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
+                           int mul_per_channel, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad,
+                           int64_t n, int ch, const int32_t *row_group, const fpcc_requant8 *also, int n_also, void *stream);
+int fpcc_fill_bits_i8(const uint8_t *bits, int64_t n, int32_t fxp_one, const uint32_t *requant_mul, const int64_t *zero_point,
+                      int shift, int8_t *out, int ld, int col0, int pad, void *stream);
 /* One octree step of the integer codec's traversal: from a level's child occupancy -- symbols int16 [n] (symbol + 1 = the 8 bits,
  * bit (7 - k) = child k = 4 dx + 2 dy + dz, model.py:60) or bits uint8 [n][8] -- and the parents' coordinates int32 [n][4]
  * (b, x, y, z), everything the reference derives with nonzero / index_select / shift / add / cat / scatter tensor operators
