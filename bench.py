@@ -328,11 +328,16 @@ def main():
     def barrier():
         replicas.barrier(device)
 
-    # Per-launch HIP events around every convolution cost ~6 us apiece (~3 ms a step), so they are recorded on ONE step
-    # of the timed region (the last); its launches are what `roofline` is computed from.
-    trace_steps = 1
+    # Per-launch HIP events around every convolution cost ~6 us apiece (~1 ms a step now), so they are recorded on the last
+    # THREE steps of the timed region (one step when fewer than 10 are timed); `roofline` is the mean over their launches.
+    trace_steps = 3 if args.steps >= 10 else 1
+    # a serving process does this once its models are loaded: everything allocated so far leaves the cyclic collector's
+    # generations, so the collections that do run between frames only scan what the frames themselves left behind
+    import gc
+    gc.collect()
+    gc.freeze()
     t_enc = t_dec = 0.0
-    hipops.reserve_trace_events(1200 * trace_steps)        # before the timed region: the traced step only records
+    hipops.reserve_trace_events(600 * trace_steps)         # before the timed region: the traced steps only record
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):

@@ -515,6 +515,7 @@ class Model(nn.Module):
     def _block(self, idx: int, blocks):
         return self.block_dec_recurrent if idx > len(blocks) else blocks[idx - 1]
 
+    @ops.no_gc_pause
     @torch.no_grad()
     def compress(self, xyz: torch.Tensor) -> bytes:
         if not xyz.is_cuda:
@@ -577,6 +578,7 @@ class Model(nn.Module):
         parts = [self.compress(p) for p in batched_coord[1:]]
         return b''.join(len(s).to_bytes(3, 'little') + s for s in parts)
 
+    @ops.no_gc_pause
     @torch.no_grad()
     def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
         device = self.fold2bin_kernel.device

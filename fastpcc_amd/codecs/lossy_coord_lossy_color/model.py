@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import engine as ME
+from ... import hipops
 from ...data import PCData
 from ..geo_lossl_em import GeoLosslessEntropyModel
 from .layers import Decoder, DecoderGeoLossl, Encoder, EncoderGeoLossl, HyperDecoderGenUpsample, HyperDecoderUpsample, \
@@ -65,6 +66,7 @@ class PCC(nn.Module):
         cm.build_pyramid(pc.coordinate_map_key, len(self.cfg.encoder_channels) - 1 + sum(self.cfg.geo_lossl_if_sample))
         return pc
 
+    @hipops.no_gc_pause
     @torch.no_grad()
     def compress(self, batched_coord: torch.Tensor, batched_color: torch.Tensor) -> bytes:
         if not batched_coord.is_cuda:
@@ -86,6 +88,7 @@ class PCC(nn.Module):
         parts = [self.compress(c, f) for c, f in zip(batched_coord[1:], batched_color[1:])]
         return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in parts)
 
+    @hipops.no_gc_pause
     @torch.no_grad()
     def decompress(self, compressed_bytes: bytes) -> Tuple[torch.Tensor, torch.Tensor]:
         dev = next(self.parameters()).device

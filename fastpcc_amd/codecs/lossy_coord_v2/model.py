@@ -111,6 +111,7 @@ class PCC(nn.Module):
         return loss_dict
 
     # ---------------------------------------------------------------------------------------------------------------
+    @hipops.no_gc_pause
     @torch.no_grad()
     def compress(self, batched_coord: torch.Tensor) -> bytes:
         if not batched_coord.is_cuda:
@@ -135,6 +136,7 @@ class PCC(nn.Module):
         parts = [self.compress(p) for p in batched_coord[1:]]
         return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in parts)
 
+    @hipops.no_gc_pause
     @torch.no_grad()
     def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
         dev = next(self.parameters()).device
