@@ -26,6 +26,32 @@ def _run(seq: nn.Sequential, x, last_clip: float = 0.0):
     return mods[-1](x, clip=last_clip) if last_clip > 0 else mods[-1](x)
 
 
+def classify_head(seq: nn.Sequential, fea):
+    """the decoder's classify block -- ConvBlock(ch, ch // 2, 1, 1) + ConvBlock(ch // 2, 1, 1, 1), layers.py:105-110 -- as ONE launch
+    when it is the narrow per-point head fpcc_pointwise_head_f32 takes (16 -> 8 -> 1): evaluated separately the hidden layer is
+    zero-padded to 32 MFMA columns on the 8 N candidates.  Same bits (the hidden layer keeps the summation order its separate
+    evaluation would use at this row count); falls back to the two blocks otherwise."""
+    blocks = list(seq)
+    ok = len(blocks) == 2 and not torch.is_grad_enabled() and len(fea.parts) == 1
+    if ok:
+        a, b = blocks
+        ok = all(isinstance(m, ConvBlock) and m.bn is None and m.conv.ks == 1 and
+                 (m.act_module is None or isinstance(m.act_module, (ME.MinkowskiPReLU, ME.MinkowskiReLU))) for m in blocks) and \
+            b.conv.out_channels == 1 and a.conv.out_channels == b.conv.in_channels and \
+            ops.pointwise_head_ok(a.conv.in_channels, a.conv.out_channels)
+    x = fea.parts[0] if ok else None
+    if not ok or x.dtype != torch.float32 or x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) % 4) or x.data_ptr() % 16:
+        return seq(fea)
+    da, db = a.conv._derived(), b.conv._derived()
+    act1, act2 = ME._act_of(a.act_module), ME._act_of(b.act_module)
+    order1 = ME.summation_order('k1', a.conv.in_channels, 0, a.conv.out_channels, x.shape[0])
+    if order1 not in (0, 1):
+        return seq(fea)
+    out = ops.pointwise_head(x, da['w'].reshape(a.conv.in_channels, a.conv.out_channels), da['b'], act1.kind, act1.slope, order1,
+                             db['w'].reshape(-1), db['b'], act2.kind, act2.slope)
+    return ME.SparseTensor(out, coordinate_map_key=fea.coordinate_map_key, coordinate_manager=fea.coordinate_manager)
+
+
 class Encoder(nn.Module):
     """conv3(in->c0) @stride 1, then per extra channel entry: conv2s2 + conv3 (layers.py:28-72)."""
 
@@ -141,7 +167,7 @@ class Decoder(nn.Module):
         top = fea.coordinate_manager._map(fea.coordinate_map_key)      # local maxima are taken inside the voxels of this level
         for i, (up, classify) in enumerate(zip(self.upsample_blocks, self.classify_blocks)):
             fea = up(fea)
-            keep = self.get_keep(classify(fea), points_num_list, top)
+            keep = self.get_keep(classify_head(classify, fea), points_num_list, top)
             if i != last:
                 fea = self.pruning(fea, keep)
             else:

@@ -416,6 +416,55 @@ __global__ __launch_bounds__(256, 1) void k_mlp_chain_b(WgArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow two-layer head C0 -> C1 -> 1 per point (the decoder's classify block, layers.py:105-110: 16 -> 8 -> 1 on the 8 N
+// candidate voxels): far too narrow for MFMA tiles -- evaluated separately the first layer is zero-padded to 32 output columns
+// (a [8N, 32] matrix written and a strided quarter of it read back).  One thread per row: C0 inputs as 16-byte loads, the C1
+// hidden values in registers, weights through LDS.  The hidden layer's FMA chain follows the order the separate launch would
+// use for this row count (order 1: 0,4,1,5,2,6,3,7 inside groups of 8 -- the padded MFMA evaluation; order 0: natural), the
+// output layer's the natural order: same bits.
+template <int C0, int C1>
+__global__ __launch_bounds__(256) void k_pointwise_head(const float *__restrict__ x, int ldx, const float *__restrict__ w1,
+                                                        const float *__restrict__ b1, int act1, const float *__restrict__ slope1, int order1,
+                                                        const float *__restrict__ w2, const float *__restrict__ b2, int act2,
+                                                        const float *__restrict__ slope2, float clip, float *__restrict__ out, int64_t n) {
+    __shared__ float s_w1[C0 * C1], s_b1[C1], s_w2[C1];
+    for (int e = threadIdx.x; e < C0 * C1; e += 256) {
+        // row c of s_w1 = the weights of the c-th channel IN CHAIN ORDER
+        const int pos = e / C1, j = e - pos * C1;
+        const int c = order1 ? (pos & ~7) + ((pos & 1) ? 4 : 0) + ((pos & 7) >> 1) : pos;
+        s_w1[e] = w1[c * C1 + j];
+    }
+    if (threadIdx.x < C1) { s_b1[threadIdx.x] = b1 ? b1[threadIdx.x] : 0.0f; s_w2[threadIdx.x] = w2[threadIdx.x]; }
+    __syncthreads();
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    float xv[C0];
+#pragma unroll
+    for (int q = 0; q < C0 / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + o * ldx + 4 * q);
+        xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+    }
+    float h[C1];
+#pragma unroll
+    for (int j = 0; j < C1; ++j) h[j] = 0.0f;
+#pragma unroll
+    for (int pos = 0; pos < C0; ++pos) {
+        const int c = order1 ? (pos & ~7) + ((pos & 1) ? 4 : 0) + ((pos & 7) >> 1) : pos;     // compile-time per branch after unrolling
+        const float xc = order1 ? xv[(pos & ~7) + ((pos & 1) ? 4 : 0) + ((pos & 7) >> 1)] : xv[pos];
+        (void)c;
+#pragma unroll
+        for (int j = 0; j < C1; ++j) h[j] = fmaf(xc, s_w1[pos * C1 + j], h[j]);
+    }
+    const float sl1 = (act1 == FPCC_ACT_PRELU && slope1) ? slope1[0] : 0.0f;
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < C1; ++j) acc = fmaf(finish(h[j], s_b1[j], act1, sl1, 0.0f), s_w2[j], acc);
+    const float sl2 = (act2 == FPCC_ACT_PRELU && slope2) ? slope2[0] : 0.0f;
+    out[o] = finish(acc, b2 ? b2[0] : 0.0f, act2, sl2, clip);
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool width_ok(int c) { return c == 32 || c == 64 || c == 128; }
 
@@ -505,4 +554,20 @@ extern "C" int fpcc_mlp_chain_f32(const fpcc_mlp_chain *d, void *stream) {
     a.n_waves = waves;
     hipLaunchKernelGGL(k_mlp_chain, dim3((waves + 3) / 4), dim3(256), 0, as_stream(stream), a);
     return check_hip(hipGetLastError(), "k_mlp_chain");
+}
+
+extern "C" int fpcc_pointwise_head_f32(const float *x, int c0, int ldx, const float *w1, const float *b1, int c1, int act1,
+                                       const float *slope1, int order1, const float *w2, const float *b2, int act2,
+                                       const float *slope2, float clip, float *out, int64_t n, void *stream) {
+    if (n < 0 || ldx < c0 || ldx % 4) return fail_arg("pointwise_head: bad sizes");
+    if (!((c0 == 16 && c1 == 8) || (c0 == 8 && c1 == 4))) return fail_arg("pointwise_head: shapes 16->8->1 and 8->4->1");
+    if (order1 != 0 && order1 != 1) return fail_arg("pointwise_head: hidden-layer order must be 0 (natural) or 1 (MFMA chain)");
+    if (n == 0) return FPCC_OK;
+    if (!x || !w1 || !w2 || !out || !aligned16(x)) return fail_arg("pointwise_head: null or unaligned pointer");
+    if ((act1 == FPCC_ACT_PRELU && !slope1) || (act2 == FPCC_ACT_PRELU && !slope2)) return fail_arg("pointwise_head: PReLU needs a slope pointer");
+    const dim3 grid(blocks_for(n, 256)), block(256);
+    hipStream_t s = as_stream(stream);
+    if (c0 == 16) hipLaunchKernelGGL((k_pointwise_head<16, 8>), grid, block, 0, s, x, ldx, w1, b1, act1, slope1, order1, w2, b2, act2, slope2, clip, out, n);
+    else hipLaunchKernelGGL((k_pointwise_head<8, 4>), grid, block, 0, s, x, ldx, w1, b1, act1, slope1, order1, w2, b2, act2, slope2, clip, out, n);
+    return check_hip(hipGetLastError(), "k_pointwise_head");
 }

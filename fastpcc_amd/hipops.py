@@ -89,6 +89,7 @@ _SIGS = {
     'fpcc_device_count': (_i32, []),
     'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
     'fpcc_mlp_chain_set_form': (_i32, [_i32]),
+    'fpcc_pointwise_head_f32': (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _vp]),
     'fpcc_conv_i8_also': (_i32, [_vp, _i32, _i32, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                  _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     'fpcc_epilogue_i32_also': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
@@ -456,6 +457,35 @@ class _MlpLayer(C.Structure):
 class _MlpChain(C.Structure):
     _fields_ = [('x', _vp), ('cx', _i32), ('ldx', _i32), ('y', _vp), ('cy', _i32), ('ldy', _i32), ('cat_layer', _i32),
                 ('n_layers', _i32), ('layers', _MlpLayer * 4), ('out', _vp), ('ldo', _i32), ('n', _i64)]
+
+
+def pointwise_head_ok(c0: int, c1: int) -> bool:
+    return (c0, c1) in ((16, 8), (8, 4))
+
+
+def pointwise_head(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], act1: int, slope1: Optional[torch.Tensor], order1: int,
+                   w2: torch.Tensor, b2: Optional[torch.Tensor], act2: int = ACT_NONE, slope2: Optional[torch.Tensor] = None,
+                   clip: float = 0.0) -> torch.Tensor:
+    """out [n, 1] = act2(act1(x @ w1 + b1) @ w2 + b2): the narrow two-layer head C0 -> C1 -> 1 as one launch (fpcc_pointwise_head_f32)"""
+    px, c0, ldx = _rows2d(x, 'x')
+    n = x.shape[0]
+    if w1.dtype != torch.float32 or not w1.is_contiguous() or w1.shape[0] != c0 or w2.numel() != w1.shape[1] or not w2.is_contiguous():
+        raise ValueError('weights must be contiguous fp32 [c0, c1] and [c1, 1]')
+    out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    trace = CONV_TRACE
+    if trace is not None:
+        ev0 = _trace_event()
+        ev0.record()
+    _ok(lib().fpcc_pointwise_head_f32(px, c0, ldx, _dev(w1, torch.float32, 'w1'), _dev(b1, torch.float32, 'b1', True), w1.shape[1], int(act1),
+                                      _dev(slope1, torch.float32, 'slope1', True), int(order1), _dev(w2, torch.float32, 'w2'),
+                                      _dev(b2, torch.float32, 'b2', True), int(act2), _dev(slope2, torch.float32, 'slope2', True),
+                                      float(clip), out.data_ptr(), n, _stream()))
+    if trace is not None:
+        ev1 = _trace_event()
+        ev1.record()
+        trace.append((ev0, ev1, {'mfma': False, 'c_in': c0, 'c_out': 1, 'n_out': n, 'groups': 1, 'n_offsets': 1, 'nbr': None,
+                                 'nbr_ks': 0, 'nbr_os': 1}))
+    return out
 
 
 def mlp_chain_set_form(form: int) -> int:

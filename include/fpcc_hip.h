@@ -229,6 +229,15 @@ int fpcc_mlp_chain_f32(const fpcc_mlp_chain *chain, void *stream);
  * workgroup form that keeps the weights in registers (default), 0 = every chain in the wave form; negative = query.  Returns
  * the previous setting. */
 int fpcc_mlp_chain_set_form(int form);
+/* Narrow per-point head C0 -> C1 -> 1 (the decoder's classify block, models/convolutional/lossy_coord_v2/layers.py:105-110:
+ * ConvBlock(16, 8, 1, 1) + ConvBlock(8, 1, 1, 1) on the 8 N candidates) as one launch, one thread per row:
+ *     out[o] = act2(sum_j act1(sum_c x[o][c] w1[c][j] + b1[j]) w2[j] + b2), clamped to [-clip, clip] when clip > 0.
+ * Shapes (C0, C1) in {(16, 8), (8, 4)}.  order1 = summation order the SEPARATE evaluation of the hidden layer would use for
+ * this row count (1: zero-padded MFMA chain on maps of >= FPCC_PAD_MIN_ROWS rows, 0: natural chain below); the output layer is a
+ * natural chain.  Same bits as the two fpcc_conv_f32 launches. */
+int fpcc_pointwise_head_f32(const float *x, int c0, int ldx, const float *w1, const float *b1, int c1, int act1,
+                            const float *slope1, int order1, const float *w2, const float *b2, int act2, const float *slope2,
+                            float clip, float *out, int64_t n, void *stream);
 /* row_order (MFMA path only, NULL = natural): a permutation of [0, n_out); tile position p computes output row
  * row_order[p].  It changes which rows share a 32-row MFMA block -- and with it how many (block, offset) products are
  * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows

@@ -124,3 +124,29 @@ def test_decoder_blocks_fused_and_unfused_write_the_same_stream():
     finally:
         scl.FUSE_MLP_CHAINS = True
     assert a == b and torch.equal(ra, rb)
+
+
+@pytest.mark.parametrize('n', [1, 255, 5000, 8192, 70001])
+@pytest.mark.parametrize('c0,c1', [(16, 8), (8, 4)])
+def test_narrow_head_equals_the_engine_blocks(n, c0, c1):
+    """fpcc_pointwise_head_f32 (the decoder's classify block as one launch) against the two ConvBlocks on fastpcc_amd.engine, below
+    and above the row count from which the hidden layer is evaluated zero-padded on the MFMA kernel (another summation order)"""
+    from fastpcc_amd import engine as ME
+    from fastpcc_amd.codecs.lossy_coord_v2.layers import classify_head
+    from fastpcc_amd.sparse_conv_layers import ConvBlock
+    import torch.nn as nn
+    torch.manual_seed(n + c0)
+    seq = nn.Sequential(ConvBlock(c0, c1, 1, 1, act='prelu'), ConvBlock(c1, 1, 1, 1, act=None)).cuda().eval()
+    with torch.no_grad():
+        for p in seq.parameters():
+            p.normal_(0, 0.4)
+        seq[0].act_module.module.weight.fill_(0.17)
+        coords = torch.zeros((n, 4), dtype=torch.int32, device='cuda')
+        coords[:, 1] = torch.arange(n, device='cuda') % 1024
+        coords[:, 2] = torch.arange(n, device='cuda') // 1024
+        cm = ME.CoordinateManager(D=3)
+        x = ME.SparseTensor(torch.randn((n, c0), device='cuda'), coordinates=coords, coordinate_manager=cm)
+        want = seq(x).F
+        got = classify_head(seq, x).F
+    assert got.shape == want.shape == (n, 1)
+    assert (_bits(got) == _bits(want)).all()
