@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
     __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
     __shared__ float s_part[OG == 4 ? 4 * 16 * NBW * 64 : 1];
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index is wave-uniform, but hipcc only knows that when told: everything derived from it (the wave's offset group, its
+    // offset mask, the stage iterator) otherwise lives in VGPRs, and the loop control below becomes ~25 vector instructions and
+    // three exec-mask branches per stage instead of scalar code beside the MFMAs
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const unsigned n_cg = (unsigned)(nbt / NBW);
     // unit = (32-row block, column group); the column groups of one row block are adjacent units (same workgroup: their A
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
         if (b >> 32) wmask |= 1u << (k0 + 1);
     }
     __builtin_amdgcn_wave_barrier();               // LDS operations of one wave execute in order; keep the compiler from reordering
+    wmask = __builtin_amdgcn_readfirstlane(wmask);
 
     f32x16 acc[NBW];
 #pragma unroll
