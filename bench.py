@@ -338,6 +338,20 @@ def main():
     gc.freeze()
     t_enc = t_dec = 0.0
     hipops.reserve_trace_events(600 * trace_steps)         # before the timed region: the traced steps only record
+    # The shader clock the step actually gets: beside every large 3x3x3 launch of ONE EXTRA step after the timed region a one-wave kernel on a second
+    # stream counts shader cycles against the constant 100 MHz counter for 100 us (fpcc_clock_probe).  MI355X's power management
+    # starts a burst of matrix work near 2.0 GHz and takes ~30 ms of uninterrupted load to reach the 2.4 GHz the peak is quoted at
+    # (profiles/r03/clock_ramp.md); a 24-ms step with host-paced gaps never gets there.
+    clock_stream = torch.cuda.Stream(device=device)
+    clock_buf = torch.zeros((64, 2), dtype=torch.int64, device=device)
+    clock_idx = []
+
+    def clock_hook(ev0, n_out, n_offsets):
+        if n_offsets == 27 and n_out >= 50000 and len(clock_idx) < clock_buf.shape[0]:
+            clock_stream.wait_event(ev0)
+            with torch.cuda.stream(clock_stream):
+                hipops.clock_probe(clock_buf[len(clock_idx)], 100)
+            clock_idx.append(len(hipops.CONV_TRACE))
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -357,6 +371,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     trace, hipops.CONV_TRACE = hipops.CONV_TRACE, None
+    # one more step, outside the timed region and outside `roofline`'s events, for the clock: the probe kernel beside a launch
+    # disturbs that launch's own timing (+15 % on the traced kernel time when both were taken in the same steps)
+    hipops.reserve_trace_events(600)
+    hipops.CONV_TRACE, hipops.CLOCK_HOOK = [], clock_hook
+    data = model.compress(frame)
+    torch.cuda.synchronize()
+    ME.clear_global_coordinate_manager()
+    rec = model.decompress(data)
+    torch.cuda.synchronize()
+    ME.clear_global_coordinate_manager()
+    clock_trace, hipops.CONV_TRACE, hipops.CLOCK_HOOK = hipops.CONV_TRACE, None, None
 
     elapsed_max, total_points = replicas.aggregate(elapsed, float(n_points) * args.steps, device)
 
@@ -406,6 +431,14 @@ def main():
             else:
                 ms_valu += dt
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # duration-weighted mean of the shader clock measured beside the large launches
+        clk_num = clk_den = 0.0
+        for (cyc, ticks), ti in zip(clock_buf[:len(clock_idx)].tolist(), clock_idx):
+            if ticks > 0 and ti < len(clock_trace):
+                dt = clock_trace[ti][0].elapsed_time(clock_trace[ti][1])
+                clk_num += cyc / ticks * 100.0 * dt
+                clk_den += dt
+        shader_mhz = clk_num / clk_den if clk_den > 0 else None
         if args.dump_trace:
             per_step = len(trace) // trace_steps
             with open(args.dump_trace, 'w') as f:
@@ -446,7 +479,13 @@ def main():
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),
                          'other_conv_ms_per_step': round(ms_valu / trace_steps, 3),
-                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region)'},
+                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region)',
+                         'shader_clock_mhz': None if shader_mhz is None else round(shader_mhz),
+                         'frac_at_shader_clock': None if shader_mhz is None else
+                         round(achieved / (MFMA_PEAK_TFLOPS * shader_mhz / 2400.0), 4),
+                         'shader_clock_note': 'mean clock measured beside the 3x3x3 launches on maps >= 50 K rows of one extra step after the timed '
+                                              'region (fpcc_clock_probe; profiles/r03/clock_ramp.md); `peak` and `frac` are quoted at the '
+                                              'nominal 2400 MHz'},
         }
         if args.secondary and world == 1:
             del model, frame

@@ -87,6 +87,7 @@ _SIGS = {
     'fpcc_rans_binary_decode_dev': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     'fpcc_simple_dec_pop_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'fpcc_device_count': (_i32, []),
+    'fpcc_clock_probe': (_i32, [_vp, _i32, _vp]),
     'fpcc_mlp_chain_f32': (_i32, [_vp, _vp]),
     'fpcc_mlp_chain_set_form': (_i32, [_i32]),
     'fpcc_pointwise_head_f32': (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _vp]),
@@ -375,6 +376,12 @@ def numerics_version() -> int:
     return lib().fpcc_numerics_version()
 
 
+def clock_probe(out2: torch.Tensor, spin_us: int = 20) -> None:
+    """diagnostic (fpcc_clock_probe): enqueue a one-wave kernel that leaves (shader cycles, 100 MHz ticks) of a spin_us spin in the
+    int64[2] device tensor out2"""
+    _ok(lib().fpcc_clock_probe(_dev(out2, torch.int64, 'out2'), int(spin_us), _stream()))
+
+
 def conv_set_tuning(which: int, value: int) -> int:
     """process-wide tuning knob of the wave kernel (fpcc_conv_set_tuning); returns the previous value"""
     before = _ok(lib().fpcc_conv_set_tuning(int(which), int(value)))
@@ -385,6 +392,7 @@ def conv_set_tuning(which: int, value: int) -> int:
 # When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
 # bench.py to time the dominant kernel inside the timed region (events only, no synchronisation).
 CONV_TRACE = None
+CLOCK_HOOK = None        # bench.py: callable(ev0, n_out, n_offsets) run right after a traced launch's start event (fpcc_clock_probe beside it)
 _EVENT_POOL: list = []
 
 
@@ -434,6 +442,8 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
     if trace is not None:
         ev0 = _trace_event()
         ev0.record()
+        if CLOCK_HOOK is not None:
+            CLOCK_HOOK(ev0, n_out, n_offsets)
     _ok(lib().fpcc_conv_f32_pk(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
                                w.data_ptr(), None if wp is None else wp.data_ptr(),
                                _dev(bias, torch.float32, 'bias', True), c_out, groups,

@@ -35,6 +35,10 @@ typedef enum {
 const char *fpcc_last_error(void);
 /* Number of visible HIP devices (0 without a GPU); never initialises a context beyond hipGetDeviceCount. */
 int fpcc_device_count(void);
+/* Diagnostic, no reference counterpart: one wave spins for spin_us (1 .. 10000) microseconds of the constant 100 MHz counter and
+ * writes out2[0] = shader-clock cycles that went by, out2[1] = 100 MHz ticks; cycles / ticks * 100 = the shader clock in MHz that
+ * the power management grants at that point of the stream (tools/gap_probe.py). */
+int fpcc_clock_probe(int64_t *out2, int spin_us, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Coordinates.  A coordinate set at pyramid level l is a sorted array of unique 64-bit keys                      */

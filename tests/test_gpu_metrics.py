@@ -129,3 +129,17 @@ def test_knn3d_takes_integer_and_strided_inputs():
     wide = torch.randint(0, 200, (2000, 6), generator=g, dtype=torch.int32).cuda()
     idx2, d3 = ops.knn3d(wide[:, ::2], wide[:, 1::2], 2)
     assert torch.equal(d3.long(), exact(wide[:, ::2], wide[:, 1::2], 2))
+
+
+@pytest.mark.gpu
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """fpcc_clock_probe (diagnostic): shader cycles per 100 MHz tick of a 200-us spin lie in a GPU's range"""
+    from fastpcc_amd import hipops
+    out = torch.zeros(2, dtype=torch.int64, device='cuda')
+    hipops.clock_probe(out, 200)
+    torch.cuda.synchronize()
+    cycles, ticks = out.tolist()
+    assert 200 * 100 <= ticks < 400 * 100
+    assert 500 < cycles / ticks * 100 < 3500
+    with pytest.raises(Exception):
+        hipops.clock_probe(out, 0)
