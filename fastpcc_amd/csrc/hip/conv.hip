@@ -364,9 +364,17 @@ struct WaveCfg {
 // lack (one partial round of waves, each latency-bound on its own chain).  The groups are a function of the offset index alone,
 // so a row's result does not depend on which rows share its block.
 __host__ __device__ __forceinline__ int offset_group_begin(int g, int n_off) { return (g * n_off + 3) / 4; }
+__host__ __device__ __forceinline__ int offset_group_of(int k, int n_off) {
+    return (k >= offset_group_begin(1, n_off)) + (k >= offset_group_begin(2, n_off)) + (k >= offset_group_begin(3, n_off));
+}
 
-template <int NBW, int CH, int SB, int DBG = 0, int OG = 1>
-__global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
+// FOLD (with OG == 1; "folded" evaluation of summation order 3): ONE wave walks all offsets of its unit as in order 1, but at every
+// boundary between two offset groups it adds the accumulator to a running sum t and restarts the accumulator from zero:
+// t = p0, t = t + p1, t = t + p2, t = t + p3 with p_g = 0 for a group without a present offset -- bit for bit what the four waves of
+// OG == 4 leave behind, without their LDS exchange, barrier and wait for the slowest group.  For maps with many row blocks, where
+// the fourfold parallelism of OG == 4 buys nothing (272 K rows: 100 against 95 TFLOP/s, profiles/r03/grouped_fold.md).
+template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false>
+__global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
                                                                                          int nbt, unsigned n_units) {
     constexpr int G8 = CH / 8;
     __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
@@ -412,6 +420,33 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    // FOLD: running sum over the offset groups finished so far (n_folded of them), see the template's comment
+    f32x16 tsum[FOLD ? NBW : 1];
+    int n_folded = 0, cur_g = 0;
+    auto fold_acc = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < (FOLD ? NBW : 0); ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tsum[nb][r] = n_folded ? tsum[nb][r] + acc[nb][r] : acc[nb][r];
+                acc[nb][r] = 0.0f;
+            }
+        ++n_folded;
+    };
+    auto fold_zero = [&]() {                              // a group none of whose offsets is present: its partial sum is +0
+#pragma unroll
+        for (int nb = 0; nb < (FOLD ? NBW : 0); ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tsum[nb][r] = n_folded ? tsum[nb][r] + 0.0f : 0.0f;
+        ++n_folded;
+    };
+    unsigned rest_c = wmask;
+    int cc_c = 0;
+    if (FOLD && wmask) {
+        cur_g = offset_group_of(__ffs(wmask) - 1, a.n_off);
+        for (int gz = 0; gz < cur_g; ++gz) fold_zero();
+    }
 
     const int n_stages = __popc(wmask) * n_chunks;
     if (n_stages > 0) {
@@ -477,6 +512,18 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
         }
         __builtin_amdgcn_sched_barrier(0);
         for (int s = 0; s < n_stages; ++s) {
+            if (FOLD) {
+                // compute position (one stage behind the fetch position): entering the first chunk of an offset of a later group
+                if (cc_c == 0) {
+                    const int gk = offset_group_of(__ffs(rest_c) - 1, a.n_off);
+                    if (gk != cur_g) {
+                        fold_acc();
+                        for (int gz = cur_g + 1; gz < gk; ++gz) fold_zero();
+                        cur_g = gk;
+                    }
+                }
+                if (++cc_c == n_chunks) { cc_c = 0; rest_c &= rest_c - 1; }
+            }
             next_stage();                                       // stage s + 1
             __builtin_amdgcn_sched_barrier(SB);
 #pragma unroll
@@ -503,6 +550,12 @@ __global__ __launch_bounds__(256, (WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wav
         }
     }
 
+    if (FOLD) {
+        if (wmask) { fold_acc(); ++cur_g; }
+        for (int gz = cur_g; gz < 4; ++gz) fold_zero();
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = tsum[nb];
+    }
     // output rows of my accumulator registers: register r holds row (r & 3) + 8 (r >> 2) + 4 h of the block
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
     if (OG == 4) {
@@ -749,16 +802,16 @@ int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
 // Tuning knobs (fpcc_conv_set_tuning; initial values from the environment).  None of them changes a result EXCEPT
 // kKnobGroupedOff (experiments only: 1 = multi-offset layers in order 1 on the plain wave kernel instead of grouped / order 3),
 // which is therefore refused unless the process runs with FPCC_EXPERIMENT=1 and has no environment variable.
-enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobReserved4 = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
+enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobGroupedFoldRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
        kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobCount = 10 };
 int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
-        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "",
+        static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_GROUPED_FOLD_ROWS",
                                                 "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS", "", "FPCC_GROUPED_NBW",
                                                 "FPCC_WAVE22_MIN_ROWS"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, 0, 0, 32 * 1024, 0, 0, 0};
-        const char *e = (k == kKnobReserved4 || k == kKnobGroupedOff) ? nullptr : getenv(names[k]);
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 100 * 1024, 0, 32 * 1024, 0, 0, 0};
+        const char *e = k == kKnobGroupedOff ? nullptr : getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
     return g_knob[k];
@@ -816,8 +869,21 @@ int launch_grouped_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t 
     return check_hip(hipGetLastError(), "k_conv_wave(grouped)");
 }
 
+// Folded evaluation of the same order (FOLD): one wave per unit, for maps with at least kKnobGroupedFoldRows rows.
+template <int NBW>
+int launch_folded_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
+    const int64_t units = ((a.n_out + 31) / 32) * (nbt / NBW);
+    if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
+    hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 1, true>), dim3((unsigned)((units + 3) / 4), a.groups), dim3(256), 0, s, a, wp, nbt,
+                       (unsigned)units);
+    return check_hip(hipGetLastError(), "k_conv_wave(folded)");
+}
+
 int launch_grouped(const ConvArgs &a, const float *wp, hipStream_t s) {
     const int nbt = a.c_out / 32;
+    const int64_t fold_rows = knob(kKnobGroupedFoldRows);
+    if (fold_rows > 0 && a.n_out >= fold_rows && knob(kKnobGroupedNbw) <= 0)
+        return nbt % 2 == 0 ? launch_folded_cfg<2>(a, wp, nbt, s) : launch_folded_cfg<1>(a, wp, nbt, s);
     int nbw = knob(kKnobGroupedNbw);
     if (nbw <= 0) nbw = a.n_out >= 40 * 1024 ? 2 : 1;        // measured: 64 columns per workgroup from ~40 K rows (profiles/r03/grouped_probe.md)
     while (nbw > nbt || nbt % nbw) nbw >>= 1;
@@ -1092,7 +1158,6 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
     if (which < 0 || which >= kKnobCount) return fail_arg("conv_set_tuning: unknown knob");
-    if (which == kKnobReserved4) return fail_arg("conv_set_tuning: knob 4 (offset-split threshold) no longer exists");
     if (which == kKnobGroupedOff) {
         const char *e = getenv("FPCC_EXPERIMENT");
         if (!e || atoi(e) != 1)

@@ -368,6 +368,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
 
 
 KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 5, 6
+KNOB_GROUPED_FOLD_ROWS = 4       # rows from which grouped (order 3) layers run folded on one wave per unit; 0 = never
 KNOB_GROUPED_OFF, KNOB_GROUPED_NBW, KNOB_WAVE22_ROWS = 7, 8, 9      # 7: experiments only (FPCC_EXPERIMENT=1), changes the summation order
 
 

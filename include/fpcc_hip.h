@@ -182,7 +182,8 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *   8  column blocks per workgroup of the grouped evaluation: 0 = by map size, else 1 | 2 (FPCC_GROUPED_NBW)
  *   9  rows from which order-1 multi-offset layers use 64 x 64 wave tiles (FPCC_WAVE22_MIN_ROWS; 0 = never, the default)
  *   7  (NOT result-neutral, refused unless FPCC_EXPERIMENT=1) 1 = evaluate grouped shapes in order 1 instead: A/B experiments
- *   4  removed (was the offset-split threshold of numerics version 1) */
+ *   4  rows from which the grouped evaluation runs FOLDED -- one wave per unit adds up the four offset groups itself -- instead of on
+ *      four waves per unit (FPCC_GROUPED_FOLD_ROWS, default 102400; 0 = never).  Same order 3, same bits. */
 int fpcc_conv_set_tuning(int which, int value);
 /* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
  * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks

@@ -541,3 +541,43 @@ def test_grouped_evaluation_is_order_3(ops, scene, c1, c2, c_out, n_off, nbw):
     assert (_bits(packed.cpu().numpy()) == _bits(want)).all()
     assert (_bits(plain.cpu().numpy()) == _bits(want)).all()
     assert (_bits(ordered.cpu().numpy()) == _bits(want)).all()
+
+
+@pytest.mark.parametrize('c1,c2,c_out,n_off', [(128, 0, 128, 27), (128, 128, 128, 27), (64, 0, 64, 27), (64, 0, 128, 8), (32, 0, 32, 27), (96, 0, 32, 27)])
+@pytest.mark.parametrize('sparse', [False, True])
+def test_folded_evaluation_is_order_3_too(ops, scene, c1, c2, c_out, n_off, sparse):
+    """the folded form of the grouped evaluation (ONE wave per unit adds the four offset groups up itself; the form large maps take) gives
+    the oracle's order-3 bits and the four-wave form's -- also when whole offset groups are absent from a block (sparse: the table keeps
+    the offsets of one or two groups per run of 48 rows, so leading, middle and trailing groups go missing) and with a row order"""
+    rng = np.random.default_rng(c1 + c2 + c_out + n_off + 1000 * sparse)
+    lvl = scene['lvl']
+    table = (scene['k3'] if n_off == 27 else scene['k2']).copy()
+    n = table.shape[1]
+    if sparse:
+        begins = [(g * n_off + 3) // 4 for g in range(5)]
+        for r0 in range(0, n, 48):
+            keep = [(r0 // 48) % 4] if (r0 // 96) % 2 else [(r0 // 48) % 4, (r0 // 48 + 2) % 4]
+            for g in range(4):
+                if g not in keep:
+                    table[begins[g]:begins[g + 1], r0:r0 + 48] = -1
+        table[:, 7] = -1                                                         # and a row without any neighbour
+    n_in = lvl.n
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32)
+    x2 = rng.normal(size=(n_in, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(n_off, c1 + c2, c_out)) / np.sqrt(n_off / 2 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.25], device='cuda')
+    kw = dict(x2=None if x2 is None else _cuda(x2), nbr=_cuda(table), n_offsets=n_off, nbr_ks=n, nbr_os=1, bias=_cuda(b),
+              act=ops.ACT_PRELU, slope=slope, clip=1.9)
+    order = ops.conv_row_order(kw['nbr'], n_off, n, 1, n) if n_off == 27 else None
+    four_waves = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, pack=True, **kw)
+    saved = ops.conv_set_tuning(ops.KNOB_GROUPED_FOLD_ROWS, 1)
+    try:
+        folded = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, pack=True, **kw)
+        ordered = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, pack=True, row_order=order, **kw)
+        plain = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, **kw)
+    finally:
+        ops.conv_set_tuning(ops.KNOB_GROUPED_FOLD_ROWS, saved)
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.25, clip=1.9, order=3)
+    for got in (four_waves, folded, ordered, plain):
+        assert (_bits(got.cpu().numpy()) == _bits(want)).all()

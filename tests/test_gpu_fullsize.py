@@ -27,16 +27,16 @@ def _key(xyz: np.ndarray) -> np.ndarray:
 class _Tuning:
     """context: one setting of every result-neutral knob; restores the defaults"""
 
-    def __init__(self, ops, ME, int_conv=None, *, row_order=True, wave=1, nbw=0, sb=1, tile=0, pointwise=32768, gnbw=0, w22=0):
+    def __init__(self, ops, ME, int_conv=None, *, row_order=True, wave=1, nbw=0, sb=1, tile=0, pointwise=32768, gnbw=0, w22=0, fold=102400):
         self.ops, self.ME, self.int_conv = ops, ME, int_conv
-        self.want = dict(row_order=row_order, wave=wave, nbw=nbw, sb=sb, tile=tile, pointwise=pointwise, gnbw=gnbw, w22=w22)
+        self.want = dict(row_order=row_order, wave=wave, nbw=nbw, sb=sb, tile=tile, pointwise=pointwise, gnbw=gnbw, w22=w22, fold=fold)
 
     def __enter__(self):
         o, w = self.ops, self.want
         self.saved = [o.conv_set_tuning(k, v) for k, v in ((o.KNOB_WAVE_ON, w['wave']), (o.KNOB_WAVE_NBW, w['nbw']),
                                                            (o.KNOB_WAVE_SB, w['sb']), (o.KNOB_MFMA_TILE, w['tile']),
                                                            (o.KNOB_POINTWISE_ROWS, w['pointwise']), (o.KNOB_GROUPED_NBW, w['gnbw']),
-                                                           (o.KNOB_WAVE22_ROWS, w['w22']))]
+                                                           (o.KNOB_WAVE22_ROWS, w['w22']), (o.KNOB_GROUPED_FOLD_ROWS, w['fold']))]
         self.saved_rows = self.ME.CoordinateManager.ROW_ORDER_MIN_ROWS
         if not w['row_order']:
             self.ME.CoordinateManager.ROW_ORDER_MIN_ROWS = 1 << 40
@@ -49,7 +49,7 @@ class _Tuning:
     def __exit__(self, *exc):
         o = self.ops
         for k, v in zip((o.KNOB_WAVE_ON, o.KNOB_WAVE_NBW, o.KNOB_WAVE_SB, o.KNOB_MFMA_TILE, o.KNOB_POINTWISE_ROWS, o.KNOB_GROUPED_NBW,
-                         o.KNOB_WAVE22_ROWS), self.saved):
+                         o.KNOB_WAVE22_ROWS, o.KNOB_GROUPED_FOLD_ROWS), self.saved):
             o.conv_set_tuning(k, v)
         self.ME.CoordinateManager.ROW_ORDER_MIN_ROWS = self.saved_rows
         if self.int_conv is not None:
@@ -59,7 +59,8 @@ class _Tuning:
 TUNINGS = [dict(row_order=False), dict(wave=0), dict(wave=0, tile=1), dict(wave=0, tile=2), dict(wave=0, tile=3),
            dict(wave=0, row_order=False, tile=2), dict(nbw=1), dict(nbw=2, sb=0), dict(nbw=4), dict(nbw=4, row_order=False),
            dict(pointwise=0), dict(pointwise=1), dict(pointwise=1, nbw=1, row_order=False),
-           dict(gnbw=1), dict(gnbw=2), dict(gnbw=2, row_order=False), dict(w22=1)]     # persistent per-point kernel: never / always
+           dict(gnbw=1), dict(gnbw=2), dict(gnbw=2, row_order=False), dict(w22=1),
+           dict(fold=0), dict(fold=1), dict(fold=1, row_order=False)]     # persistent per-point kernel: never / always
 
 
 @pytest.fixture(scope='module')

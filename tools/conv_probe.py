@@ -69,9 +69,16 @@ for dbg, (nbw, sb) in [(a, c) for a in DBG for c in variants]:
       ops.conv_set_tuning(ops.KNOB_WAVE_ON, int(nbw > 0)); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, nbw); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
       tag = f' [tiled kernel dbg={dbg}]' if nbw == 0 else f' [wave nbw={nbw} sb={sb} dbg={dbg}]'
   for name, ro in cases:
+    # MI355X's power management starts a burst of matrix work near 2.0 GHz and needs ~30 ms of uninterrupted load to reach 2.4 GHz
+    # (profiles/r03/clock_ramp.md): without this warm-up whichever variant runs LAST looks 5-10 % faster than the first
     for _ in range(3):
         run(ro)
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    while time.perf_counter() - t0 < float(os.environ.get('WARM_MS', '60')) * 1e-3:
+        for _ in range(4):
+            run(ro)
+        torch.cuda.synchronize()                              # (a few us of idle per four launches do not reset the ramp)
+    t0 = time.perf_counter()
     for _ in range(reps):
         run(ro)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
