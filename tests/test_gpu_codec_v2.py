@@ -196,6 +196,28 @@ def test_unused_encoder_tail_does_not_change_the_bytes(setup):
     assert model.decompress(short).shape[0] == len(xyz)
 
 
+def test_deferred_occupancy_predictors_do_not_change_the_bytes(setup):
+    """compress() runs the feature chain first and the occupancy predictors afterwards, finest level first (so that the longest host
+    coding pass starts while GPU work is left); in chain order -- the reference's -- the bytes and the kept symbols are the same."""
+    cfg, model, weights, ops = setup
+    xyz, coords = _cloud(7, 128, 60000)
+    dev = torch.from_numpy(coords).to(torch.int32).cuda()
+    em = model.em_lossless_based
+    assert em.defer_occupancy
+    deferred = model.compress(dev)
+    sym_deferred = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in em.last_symbols.items()}
+    em.defer_occupancy = False
+    try:
+        in_order = model.compress(dev)
+        sym_in_order = em.last_symbols
+    finally:
+        em.defer_occupancy = True
+    assert deferred == in_order
+    assert sym_deferred['sizes'] == sym_in_order['sizes'] and len(sym_deferred['sizes']) >= 2
+    assert (sym_deferred['occupancy'] == sym_in_order['occupancy']).all() and (sym_deferred['prob'] == sym_in_order['prob']).all()
+    assert model.decompress(deferred).shape[0] == len(xyz)
+
+
 def test_test_forward_reports_rate_and_d1(setup):
     """PCC.forward in eval mode = the reference's test_forward: bytes, bpp, timings, and the evaluator's D1 numbers
     (computed on the device) equal the CPU oracle's on the same reconstruction"""
