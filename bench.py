@@ -287,8 +287,12 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    # Dry run of the N > 1 path on a box with ONE GPU (tools/r03/two_ranks.sh): FPCC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
+    # FPCC_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Not a measurement; the driver's runs set neither.
+    if os.environ.get('FPCC_BENCH_ONE_DEVICE') == '1':
+        local = 0
     torch.cuda.set_device(local)
-    replicas.init('nccl')          # RCCL; only the barrier and two scalar reductions use it
+    replicas.init(os.environ.get('FPCC_BENCH_BACKEND', 'nccl'))          # RCCL; only the barrier and two scalar reductions use it
     device = torch.device('cuda', local)
 
     from fastpcc_amd.synthetic import enliven

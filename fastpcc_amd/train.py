@@ -202,6 +202,7 @@ def ddp_bench(trainer: Trainer, data: Iterator[PCData], steps: int, warmup: int,
         t1 = time.perf_counter()
         for _ in range(steps):
             batch = next(data)
+            batch.training_step = trainer.optimisation_step
             with trainer.model.no_sync():
                 (trainer.model(batch)['loss']).backward()
             for opt in trainer.optimizers:

@@ -25,6 +25,8 @@ class Toy(torch.nn.Module):
         self.scale = torch.nn.Parameter(torch.ones(4))
 
     def forward(self, batch):
+        # like PCC.train_forward (warm-up schedule): every forward needs the optimisation step the trainer stamps on the batch
+        assert isinstance(batch.training_step, int) and batch.training_step >= 0
         y, d = self.bottom_fea_entropy_model(batch.xyz * self.scale)
         return {'loss': d['bits_loss'] + 0.01 * (y ** 2).sum(), 'bits': float(d['bits_loss'].detach())}
 
