@@ -523,6 +523,35 @@ extern "C" int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_
     return FPCC_OK;
 }
 
+// Row counts of ALL coarser levels of a sorted key array in one pass: two neighbouring keys fall into different cells of level l iff
+// their highest differing bit lies at or above bit 3 l, so a key pair adds one row to every level l <= top, top = (highest differing
+// bit) / 3.  hist[t] counts the pairs with top == t (t clamped to `levels`); rows of level l = 1 + sum_{t >= l} hist[t].
+__global__ __launch_bounds__(256) void k_level_histogram(const int64_t *__restrict__ keys, int64_t n, int levels, int32_t *hist) {
+    __shared__ int32_t s_hist[32];
+    if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = (uint64_t)(keys[i] ^ keys[i - 1]);
+        if (d) {
+            const int top = (63 - __clzll((long long)d)) / 3;
+            atomicAdd(&s_hist[top < levels ? top : levels], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= levels && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+extern "C" int64_t fpcc_level_histogram(const int64_t *keys, int64_t n, int levels, int32_t *hist, void *stream) {
+    if (n < 0 || levels < 1 || levels > 21) return fail_arg("level_histogram: n < 0 or levels outside 1..21");
+    if (!hist || (n > 0 && !keys)) return fail_arg("level_histogram: null pointer");
+    FPCC_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (levels + 1), as_stream(stream)));
+    if (n < 2) return FPCC_OK;
+    const int64_t blocks = blocks_for(n, 256 * 8);
+    hipLaunchKernelGGL(k_level_histogram, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, as_stream(stream), keys, n, levels, hist);
+    FPCC_LAUNCHED(k_level_histogram);
+    return FPCC_OK;
+}
+
 extern "C" int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_t *keys_out,
                                int32_t *parent_of, int32_t *child_row, int32_t *count_out, void *ws, int64_t ws_bytes,
                                void *stream) {

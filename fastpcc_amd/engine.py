@@ -223,26 +223,33 @@ class CoordinateManager:
         key = self._register(m, string_id)
         return key, (rows, n)
 
-    def _ensure_parent(self, m: _Map) -> _Map:
+    def _ensure_parent(self, m: _Map, rows: Optional[int] = None) -> _Map:
+        """rows: the parent map's row count when the caller already knows it (build_pyramid) -- no read-back then"""
         if m.parent is None:
             if m.bits <= 1:
                 raise ValueError('cannot stride past the coordinate range')
             parent_of, pkeys, child_row, count = ops.coarsen(self._keys(m))
-            cnt = int(count.item())
+            cnt = int(count.item()) if rows is None else rows
             p = _Map(m.level + 1, m.bits - 1, cnt, pkeys[:cnt])
             m.parent, m.parent_of, m.child_row = p, parent_of, child_row[:cnt]
             self._register(p, '')
         return m.parent
 
     def build_pyramid(self, key: CoordinateMapKey, levels: int) -> None:
-        """Create the `levels` next coarser maps of `key` now.  Every coarsening reads its row count back (a blocking
-        device->host transfer); done up front, while the stream is nearly empty, those round trips cost ~0.1 ms each --
-        in the middle of a long enqueue they would stop the host from running ahead of the GPU."""
+        """Create the `levels` next coarser maps of `key` now, up front, so that no row count is read back in the middle of a long
+        enqueue (it would stop the host from running ahead of the GPU).  The row counts of all levels come from one pass over the
+        finest keys and ONE blocking read-back (ops.level_counts; a read-back per level -- ~0.1 ms each with the stream nearly
+        empty -- before round 3)."""
         m = self._map(key)
-        for _ in range(levels):
-            if m.bits <= 1:
-                break
-            m = self._ensure_parent(m)
+        # levels still to build below the deepest existing ancestor: their row counts come from ONE pass over that map's keys
+        while m.parent is not None and levels > 0:
+            m, levels = m.parent, levels - 1
+        levels = min(levels, m.bits - 1)
+        if levels <= 0:
+            return
+        rows = ops.level_counts(self._keys(m), levels) if not m.generated else [None] * levels
+        for r in rows:
+            m = self._ensure_parent(m, r)
 
     def stride(self, key: CoordinateMapKey, stride) -> CoordinateMapKey:
         """Key of the map `stride` times coarser (ME: cm.stride)."""

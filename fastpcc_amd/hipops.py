@@ -7,7 +7,7 @@ there is no alternative implementation: without the library or a GPU these funct
 import collections
 import ctypes as C
 import functools
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -26,6 +26,7 @@ _SIGS = {
     'fpcc_sort_keys': (_i64, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_unique_keys': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_coarsen': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_level_histogram': (_i64, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -261,6 +262,22 @@ def coarsen(keys: torch.Tensor):
     _ok(L.fpcc_coarsen(kp, n, parent_of.data_ptr(), pkeys.data_ptr(), child_row.data_ptr(), count.data_ptr(),
                        ws.data_ptr(), need, _stream()))
     return parent_of, pkeys, child_row, count
+
+
+def level_counts(keys: torch.Tensor, levels: int) -> List[int]:
+    """rows of the `levels` next coarser maps of a sorted key array: ONE kernel, ONE blocking 4 (levels + 1)-byte read-back
+    (fpcc_level_histogram) instead of a read-back per fpcc_coarsen"""
+    n = keys.shape[0]
+    if n == 0:
+        return [0] * levels
+    hist = torch.empty(levels + 1, dtype=torch.int32, device=keys.device)
+    _ok(lib().fpcc_level_histogram(_dev(keys, torch.int64, 'keys'), n, levels, hist.data_ptr(), _stream()))
+    h = hist.tolist()
+    out, acc = [], 0
+    for t in range(levels, 0, -1):
+        acc += h[t]
+        out.append(1 + acc)
+    return out[::-1]
 
 
 def refine(pkeys: torch.Tensor, mask: torch.Tensor):

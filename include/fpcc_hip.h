@@ -86,6 +86,11 @@ int64_t fpcc_unique_keys(const int64_t *keys, int64_t n, int64_t *ukeys_out, int
  *   count_out             device int32[1], number of parents. */
 int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_of, int64_t *pkeys, int32_t *child_row,
                      int32_t *count_out, void *ws, int64_t ws_bytes, void *stream);
+/* Row counts of the `levels` (1..21) next coarser levels of a sorted, duplicate-free key array in ONE pass, so that a whole pyramid
+ * costs one count read-back instead of one per level: hist[t], t = 0..levels (int32, zeroed here), = number of neighbouring key pairs
+ * whose highest differing bit is in [3 t, 3 t + 3) (t clamped to `levels`); the map `l` levels coarser has
+ * 1 + sum_{t >= l} hist[t] rows (n > 0).  No reference counterpart (MinkowskiEngine builds strided maps one at a time). */
+int64_t fpcc_level_histogram(const int64_t *keys, int64_t n, int levels, int32_t *hist, void *stream);
 
 /* Occupancy-driven refinement (decoder side; replaces coords = pred.C[mask]; cm.insert_and_map(...),
  * models/convolutional/lossy_coord_lossy_color/geo_lossl_em.py:278-283, and MinkowskiPruning on a generated set):

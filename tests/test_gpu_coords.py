@@ -131,6 +131,38 @@ def test_batched_clouds_do_not_mix(ops):
     assert (nbr == oc.dense_table(oc.kernel_map(lvl, lvl, 3), lvl.n)).all()
 
 
+@pytest.mark.parametrize('clouds', [1, 3])
+def test_level_counts_equal_the_coarsening_counts(ops, clouds):
+    """fpcc_level_histogram: the rows of every coarser level from one pass over the finest keys = what level-by-level fpcc_coarsen
+    counts (also across batch entries), and CoordinateManager.build_pyramid builds the same maps with it"""
+    coords = np.concatenate([batched(surface_cloud(20 + b, 64, 5000), b) for b in range(clouds)])
+    bits = 7
+    keys, _ = ops.sort_keys(ops.keys_from_coords(_dev(coords, torch.int32), 0, bits))
+    got = ops.level_counts(keys, bits - 1)
+    want, cur = [], keys
+    for _ in range(bits - 1):
+        _, pkeys, _, cnt = ops.coarsen(cur)
+        want.append(int(cnt.item()))
+        cur = pkeys[:want[-1]].contiguous()
+    assert got == want and want[-1] == clouds
+    assert ops.level_counts(keys[:1], 3) == [1, 1, 1] and ops.level_counts(keys[:0], 2) == [0, 0]
+    from fastpcc_amd import engine as ME
+    cm = ME.CoordinateManager(D=3)
+    key, _ = cm.insert_and_map(_dev(coords, torch.int32), 1)
+    cm.build_pyramid(key, 4)
+    m, rows = cm._map(key), []
+    for _ in range(4):
+        assert m.parent is not None
+        m = m.parent
+        rows.append(m.n)
+    lvl, expect = oc.Level(coords, 1), []
+    for _ in range(4):
+        lvl = oc.strided(lvl)
+        expect.append(lvl.n)
+    assert rows == expect
+    ME.clear_global_coordinate_manager()
+
+
 def test_empty_and_tiny_inputs(ops):
     e = torch.zeros(0, dtype=torch.int64, device='cuda')
     s, p = ops.sort_keys(e)
