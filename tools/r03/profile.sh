@@ -11,4 +11,4 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $CMD > $O/write.log 2>&1
 fi
 find $O -name '*.csv' | xargs ls -la | head -30
-python profiles/summarize.py $(find $O/stats -name '*kernel_stats.csv' | head -1) 4 | head -60
+python profiles/summarize.py $(find $O/stats -name "*kernel_stats.csv" | head -1) 5 | head -60
