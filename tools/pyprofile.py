@@ -21,3 +21,5 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable()
 st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(35)
+print('---- callers of the blocking calls ----')
+st.print_callers('item|synchronize|tolist')
