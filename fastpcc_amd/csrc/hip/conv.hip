@@ -21,11 +21,14 @@
 //                 <= 16 output channels, weights through the scalar cache.  Bandwidth-bound, tiny in this codec.
 // Multi-offset layers with 32-multiple channel counts are evaluated GROUPED (summation order 3 -- part of the stream format, see
 // FPCC_NUMERICS_VERSION): the kernel offsets form four fixed groups, one wave of a workgroup each, partial sums added in group
-// order (k_conv_wave<..., OG = 4>).
+// order -- by four waves of a workgroup that meet in LDS (k_conv_wave<..., OG = 4>: maps below 100 K rows, which need the
+// parallelism) or by one wave that folds its accumulator into a running sum at every group boundary (k_conv_wave<..., FOLD>: large
+// maps); both leave the same bits.
 //
 // Roofline: 2 * pairs * C_in * C_out algorithmic flop against the fp32 MFMA peak.  Measured limits of this design are in
-// profiles/r02/wave_kernel_sweeps.md: each VMEM instruction costs ~30 SIMD cycles of issue that more waves do not hide,
-// and the B stream (256 B per MFMA from L2) caps the wave kernel at ~100 TFLOP/s on the 272 K-row maps.
+// profiles/r02/wave_kernel_sweeps.md and profiles/r03/{sq_counters,grouped_occupancy,grouped_fold,clock_ramp}.md: each VMEM
+// instruction costs ~30 SIMD cycles of issue that more waves do not hide, the B stream (256 B per MFMA from L2) caps the wave
+// kernel at ~100 TFLOP/s on the 272 K-row maps at 2.4 GHz, and inside a codec step the power management grants ~2.16 GHz.
 #include "common.h"
 #include <cstdlib>
 
