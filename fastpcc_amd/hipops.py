@@ -456,19 +456,23 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
         ws_bytes = lib().fpcc_conv_f32_ws_bytes(c1, c2, c_out, n_offsets, groups, n_out)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x1.device)
+    # arguments first, start event last: on a host-paced stretch the GPU reaches the event before the host has launched the kernel,
+    # and whatever the host does in between (pointer checks, ctypes marshalling) would be timed as part of the launch
+    fn = lib().fpcc_conv_f32_pk
+    call = (p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
+            w.data_ptr(), None if wp is None else wp.data_ptr(),
+            _dev(bias, torch.float32, 'bias', True), c_out, groups,
+            _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
+            _dev(slope, torch.float32, 'slope', True), float(clip),
+            _dev(row_order, torch.int32, 'row_order', True),
+            None if ws is None else ws.data_ptr(), ws_bytes, _stream())
     trace = CONV_TRACE
     if trace is not None:
         ev0 = _trace_event()
         ev0.record()
         if CLOCK_HOOK is not None:
             CLOCK_HOOK(ev0, n_out, n_offsets)
-    _ok(lib().fpcc_conv_f32_pk(p1, c1, ld1, p2, c2, ld2, _dev(nbr, torch.int32, 'nbr', True), n_offsets, nbr_ks, nbr_os,
-                               w.data_ptr(), None if wp is None else wp.data_ptr(),
-                               _dev(bias, torch.float32, 'bias', True), c_out, groups,
-                               _dev(out_map, torch.int32, 'out_map', True), om_os, om_gs, po, ldo, n_out, act,
-                               _dev(slope, torch.float32, 'slope', True), float(clip),
-                               _dev(row_order, torch.int32, 'row_order', True),
-                               None if ws is None else ws.data_ptr(), ws_bytes, _stream()))
+    _ok(fn(*call))
     if trace is not None:
         ev1 = _trace_event()
         ev1.record()
@@ -500,14 +504,16 @@ def pointwise_head(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor]
     if w1.dtype != torch.float32 or not w1.is_contiguous() or w1.shape[0] != c0 or w2.numel() != w1.shape[1] or not w2.is_contiguous():
         raise ValueError('weights must be contiguous fp32 [c0, c1] and [c1, 1]')
     out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    fn = lib().fpcc_pointwise_head_f32
+    call = (px, c0, ldx, _dev(w1, torch.float32, 'w1'), _dev(b1, torch.float32, 'b1', True), w1.shape[1], int(act1),
+            _dev(slope1, torch.float32, 'slope1', True), int(order1), _dev(w2, torch.float32, 'w2'),
+            _dev(b2, torch.float32, 'b2', True), int(act2), _dev(slope2, torch.float32, 'slope2', True),
+            float(clip), out.data_ptr(), n, _stream())
     trace = CONV_TRACE
     if trace is not None:
         ev0 = _trace_event()
         ev0.record()
-    _ok(lib().fpcc_pointwise_head_f32(px, c0, ldx, _dev(w1, torch.float32, 'w1'), _dev(b1, torch.float32, 'b1', True), w1.shape[1], int(act1),
-                                      _dev(slope1, torch.float32, 'slope1', True), int(order1), _dev(w2, torch.float32, 'w2'),
-                                      _dev(b2, torch.float32, 'b2', True), int(act2), _dev(slope2, torch.float32, 'slope2', True),
-                                      float(clip), out.data_ptr(), n, _stream()))
+    _ok(fn(*call))
     if trace is not None:
         ev1 = _trace_event()
         ev1.record()
@@ -572,11 +578,12 @@ def mlp_chain(x: torch.Tensor, layers, y: Optional[torch.Tensor] = None, cat_lay
     d.out, co, d.ldo = _rows2d(out, 'out')
     if co != c_in or out.shape[0] != n:
         raise ValueError('output shape mismatch')
+    fn, ref, stream = lib().fpcc_mlp_chain_f32, C.byref(d), _stream()
     trace = CONV_TRACE
     if trace is not None:
         ev0 = _trace_event()
         ev0.record()
-    _ok(lib().fpcc_mlp_chain_f32(C.byref(d), _stream()))
+    _ok(fn(ref, stream))
     if trace is not None:
         ev1 = _trace_event()
         ev1.record()
