@@ -13,3 +13,4 @@ for c in int color train; do cp $S/$c/s_kernel_stats.csv $D/final_${c}_kernel_st
 { echo "# rocprofv3 --kernel-trace --stats -- colour codec (cfg#4): tools/timeline_color.py   (round 3, final state)"; python profiles/summarize.py $S/color/s_kernel_stats.csv 5; } > $D/final_color_summary.md
 { echo "# rocprofv3 --kernel-trace --stats -- training step (cfg#5): bench_train.py --steps 4 --warmup 1, 8 clouds per step   (round 3, final state)"; python profiles/summarize.py $S/train/s_kernel_stats.csv 5; } > $D/final_train_summary.md
 tail -1 $S/pytest_gpu.txt; tail -3 $S/pytest_gpu.txt | head -1
+{ echo; echo "## The helper kernels by launch size (profiles/hbm_bandwidth_by_size.py)"; echo; python profiles/hbm_bandwidth_by_size.py $S/fetch $S/write; } >> $D/final_hbm_bandwidth.md
