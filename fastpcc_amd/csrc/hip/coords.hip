@@ -237,36 +237,46 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
     const int32_t p = parent_of ? parent_of[i] : (int32_t)(i >> 3);
     // The 27 neighbours of a child lie in the 2x2x2 block of parents {ox-1, ox} x {oy-1, oy} x {oz-1, oz} (parent offsets):
     // 8 parent rows are looked up once (instead of once per neighbour) and their 8 children each fetched as two 16-byte
-    // loads; the 27 answers are then selected from registers.
-    __shared__ int32_t s_kids[64 * kThreads];                    // [parent in the block * 8 + octant][thread] -> child row or -1
-    int32_t *kids = s_kids + threadIdx.x;                        // (indexed at run time by the child's own octant: not registers)
+    // loads.  Child c of block parent b sits at offset (2 P + c_axis - o_axis) per axis from this row, P = o - 1 + b in
+    // {-1, 0, 1}; the 27 of the 64 children whose offsets lie in {-1, 0, 1}^3 are the answers.  They go through an LDS tile
+    // [27][threads] (so that every store instruction writes consecutive rows of ONE offset): 27 KB per workgroup -- five
+    // workgroups per CU; the [64][threads] tile of all children that round 2 kept allowed two, and the kernel ran latency-bound.
+    __shared__ int32_t s_out[MASK_ONLY ? 1 : 27 * kThreads];
+    int32_t *mine = s_out + (MASK_ONLY ? 0 : threadIdx.x);
+    if (!MASK_ONLY) {
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const int px = ox - 1 + (b & 1), py = oy - 1 + ((b >> 1) & 1), pz = oz - 1 + (b >> 2);     // in {-1, 0, 1}
-        const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
-        const int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
-        if (q >= 0 && child_row) {
-            const int4 lo = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8);
-            const int4 hi = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8 + 4);
-            int32_t *kb = kids + b * 8 * kThreads;
-            kb[0] = lo.x; kb[kThreads] = lo.y; kb[2 * kThreads] = lo.z; kb[3 * kThreads] = lo.w;
-            kb[4 * kThreads] = hi.x; kb[5 * kThreads] = hi.y; kb[6 * kThreads] = hi.z; kb[7 * kThreads] = hi.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) kids[(b * 8 + c) * kThreads] = q >= 0 ? q * 8 + c : -1;
-        }
+        for (int d = 0; d < 27; ++d) mine[d * kThreads] = -1;
     }
     uint32_t bits = 0;
 #pragma unroll
-    for (int d = 0; d < 27; ++d) {
-        const int tx = ox + (d % 3) - 1, ty = oy + (d / 3) % 3 - 1, tz = oz + d / 9 - 1;   // in {-1,0,1,2}
-        // parent offset floor(t/2) in {-1,0,1} -> index in the block; child octant t mod 2
-        const int bx = (tx + 2) / 2 - ox, by = (ty + 2) / 2 - oy, bz = (tz + 2) / 2 - oz;  // in {0, 1}
-        const int b = bx | (by << 1) | (bz << 2);
-        const int co = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-        const int32_t v = kids[(b * 8 + co) * kThreads];
-        if (MASK_ONLY) bits |= (uint32_t)(v >= 0) << d;
-        else nbr[(int64_t)d * n + i] = v;
+    for (int b = 0; b < 8; ++b) {
+        const int bx = b & 1, by = (b >> 1) & 1, bz = b >> 2;
+        const int px = ox - 1 + bx, py = oy - 1 + by, pz = oz - 1 + bz;                             // in {-1, 0, 1}
+        const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
+        const int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
+        if (q < 0) continue;
+        int32_t kid[8];
+        if (child_row) {
+            const int4 lo = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8);
+            const int4 hi = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8 + 4);
+            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w; kid[4] = hi.x; kid[5] = hi.y; kid[6] = hi.z; kid[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kid[c] = q * 8 + c;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int dx = 2 * px + (c & 1) - ox, dy = 2 * py + ((c >> 1) & 1) - oy, dz = 2 * pz + (c >> 2) - oz;
+            if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
+            const int d = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+            if (MASK_ONLY) bits |= (uint32_t)(kid[c] >= 0) << d;
+            else mine[d * kThreads] = kid[c];
+        }
+    }
+    if (!MASK_ONLY) {
+        // own column of the tile only: no barrier needed
+#pragma unroll
+        for (int d = 0; d < 27; ++d) nbr[(int64_t)d * n + i] = mine[d * kThreads];
     }
     if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }
