@@ -292,6 +292,8 @@ def main():
     if os.environ.get('FPCC_BENCH_ONE_DEVICE') == '1':
         local = 0
     torch.cuda.set_device(local)
+    # before anything allocates pinned memory or starts threads: run on the CPUs of the GPU's own NUMA node (two-socket hosts)
+    numa = replicas.bind_to_device_numa_node(local)
     replicas.init(os.environ.get('FPCC_BENCH_BACKEND', 'nccl'))          # RCCL; only the barrier and two scalar reductions use it
     device = torch.device('cuda', local)
 
@@ -469,7 +471,8 @@ def main():
                        'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
                        'bytes': n_bytes, 'bpp': round(8 * n_bytes / n_points, 4),
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
-                       'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results'},
+                       'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results',
+                       'host_binding': numa if numa is not None else 'none'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
                          'traffic': None if traffic is None else round(traffic),

@@ -5,7 +5,7 @@ path; the only collectives are the barrier around a timed region and the two sca
 timings into one whole-job figure.  Backend 'nccl' (= RCCL over xGMI) on GPUs, 'gloo' in the CPU tests.
 """
 import os
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -19,6 +19,48 @@ def env_rank() -> Tuple[int, int, int]:
 def init(backend: str) -> None:
     if env_rank()[1] > 1 and not dist.is_initialized():
         dist.init_process_group(backend, init_method='env://')
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_device_numa_node(device_index: int) -> Optional[dict]:
+    """Pin the calling thread (and every thread it starts later: the coder pool, torch's workers) to the CPUs of the NUMA node the
+    GPU hangs off, read from sysfs by its PCI address.  MI355X hosts here are two-socket machines; a process scheduled on the far
+    socket allocates its pinned staging buffers there and every device<->host copy, flag write and launch crosses the inter-socket
+    link.  What `numactl --cpunodebind` does for a
+    serving process.  Default: on for the ranks of a multi-process job (one rank per GPU, the usual practice), off for a single
+    process -- on the one box where it was A/B'd (`tools/r03/numa.sh`, GPU on node 1) the unpinned process ran as fast, so the
+    box-to-box spread of the single-GPU bench (22-26 ms per frame at equal kernel times) is not shown to come from placement;
+    FPCC_NUMA_BIND=1 / 0 forces.  Returns None when nothing was changed (topology unreadable, one node, switched off)."""
+    want = os.environ.get('FPCC_NUMA_BIND')
+    if want is None:
+        want = '1' if env_rank()[1] > 1 else '0'
+    if want == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        addr = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0'
+        base = f'/sys/bus/pci/devices/{addr}'
+        with open(f'{base}/local_cpulist') as f:
+            cpus = _parse_cpulist(f.read())
+        with open(f'{base}/numa_node') as f:
+            node = int(f.read().strip())
+        allowed = os.sched_getaffinity(0)
+        target = sorted(set(cpus) & allowed)
+        if not target or len(target) == len(allowed):
+            return None
+        os.sched_setaffinity(0, target)
+        return {'pci': addr, 'numa_node': node, 'cpus': len(target)}
+    except (OSError, AttributeError, ValueError, RuntimeError, AssertionError):      # no device / no sysfs entry: nothing to bind to
+        return None
 
 
 def frames_of_rank(frames: Sequence, rank: int, world: int) -> List:

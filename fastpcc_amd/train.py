@@ -253,6 +253,7 @@ def bench(steps: int, warmup: int, gpus: int, resolution: int = 128, cfg: Option
         raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    replicas.bind_to_device_numa_node(local)
     replicas.init('nccl')
     rec = ddp_training_record(steps, warmup, device, resolution, cfg)
     if rank != 0:

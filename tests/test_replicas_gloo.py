@@ -54,3 +54,17 @@ def test_single_process_is_identity():
     assert replicas.aggregate(0.5, 7.0, torch.device('cpu')) == (0.5, 7.0)
     assert replicas.gather_bytes(b'abc', torch.device('cpu')) == [b'abc']
     assert replicas.frames_of_rank('abcd', 0, 1) == list('abcd')
+
+
+def test_cpulist_parsing_and_binding_is_a_noop_without_a_gpu(monkeypatch):
+    """bind_to_device_numa_node: sysfs cpulist syntax; nothing happens (None) where the device or its topology cannot be read"""
+    from fastpcc_amd import replicas
+    assert replicas._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    assert replicas._parse_cpulist('') == []
+    monkeypatch.setenv('FPCC_NUMA_BIND', '1')
+    import os
+    before = os.sched_getaffinity(0)
+    assert replicas.bind_to_device_numa_node(0) is None or os.sched_getaffinity(0) <= before
+    os.sched_setaffinity(0, before)
+    monkeypatch.setenv('FPCC_NUMA_BIND', '0')
+    assert replicas.bind_to_device_numa_node(0) is None
