@@ -551,6 +551,76 @@ __global__ void k_epilogue_i32(const int32_t *__restrict__ in, int ldi, const in
     }
 }
 
+// The same epilogue, four columns per thread: one 16-byte read of the int32 sums, one 4-byte (int8) or 16-byte (int32) write, the int8
+// copies packed four to a store.  For ch, the row strides and the paddings multiples of 4 and 16-byte-aligned rows (checked by
+// epilogue_v4_ok on the host); the element-wise kernel above wrote single bytes.
+__global__ void k_epilogue_i32_v4(const int32_t *__restrict__ in, int ldi, const int32_t *bias, const int32_t *slope,
+                                  const uint32_t *mul, int mul_stride, const int64_t *zp, int shift, int out_bits,
+                                  void *out, int ldo, int64_t n, int ch, int out_pad, const int32_t *row_group,
+                                  const int32_t *res, int ld_res, const int32_t *slope2, Also8 also) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int own = out_pad > ch ? out_pad : ch;
+    int width = own;
+    if (also.n > 0 && also.pad0 > width) width = also.pad0;
+    if (also.n > 1 && also.pad1 > width) width = also.pad1;
+    const int w4 = width >> 2;
+    if (e >= n * w4) return;
+    const int64_t r = e / w4;
+    const int c = 4 * (int)(e - r * w4);
+    int32_t v[4] = {0, 0, 0, 0};
+    if (c < ch) {
+        const i32x4 x = *reinterpret_cast<const i32x4 *>(in + r * ldi + c);
+        const int32_t xs[4] = {x.x, x.y, x.z, x.w};
+        const int64_t pc = (row_group ? (int64_t)row_group[r] * ch : 0) + c;
+        const int64_t z = zp ? zp[0] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t t = (int64_t)xs[j] + (bias ? (int64_t)bias[pc + j] : 0);
+            if (slope) t = prelu_q625(t, slope[0]);
+            v[j] = requant(t, mul[(pc + j) * mul_stride], z, shift, out_bits);
+        }
+    }
+    if (out_bits == 8) {
+        if (c < own) *reinterpret_cast<int32_t *>(static_cast<int8_t *>(out) + r * ldo + c) = pack4_i8(v[0], v[1], v[2], v[3]);
+        return;
+    }
+    if (c < ch && res) {
+        const i32x4 q = *reinterpret_cast<const i32x4 *>(res + r * ld_res + c);
+        const int32_t qs[4] = {q.x, q.y, q.z, q.w};
+        const int32_t s2 = slope2[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = residual_prelu(v[j], qs[j], s2);
+    }
+    if (c < ch) {
+        const i32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<i32x4 *>(static_cast<int32_t *>(out) + r * ldo + c) = o;
+    }
+    for (int i = 0; i < also.n; ++i) {
+        int8_t *dst = i == 0 ? also.out0 : also.out1;
+        const int ld = i == 0 ? also.ld0 : also.ld1, pad = i == 0 ? also.pad0 : also.pad1, sh = i == 0 ? also.shift0 : also.shift1;
+        if (c < ch) {
+            const uint32_t m8 = (i == 0 ? also.mul0 : also.mul1)[0];
+            const int64_t z8 = (i == 0 ? also.zp0 : also.zp1)[0];
+            *reinterpret_cast<int32_t *>(dst + r * ld + c) = pack4_i8(requant(v[0], m8, z8, sh, 8), requant(v[1], m8, z8, sh, 8),
+                                                                      requant(v[2], m8, z8, sh, 8), requant(v[3], m8, z8, sh, 8));
+        } else if (c < pad) {
+            *reinterpret_cast<int32_t *>(dst + r * ld + c) = 0;
+        }
+    }
+}
+
+__host__ inline bool epilogue_v4_ok(const void *in, int ldi, const void *out, int ldo, int out_bits, int ch, int out_pad,
+                                    const void *res, int ld_res, const Also8 &a) {
+    auto al = [](const void *p, unsigned m) { return (reinterpret_cast<uintptr_t>(p) & (m - 1)) == 0; };
+    if (ch % 4 || ldi % 4 || !al(in, 16)) return false;
+    if (out_bits == 8) { if (ldo % 4 || out_pad % 4 || !al(out, 4)) return false; }
+    else if (ldo % 4 || !al(out, 16)) return false;
+    if (res && (ld_res % 4 || !al(res, 16))) return false;
+    if (a.n > 0 && (a.ld0 % 4 || a.pad0 % 4 || !al(a.out0, 4))) return false;
+    if (a.n > 1 && (a.ld1 % 4 || a.pad1 % 4 || !al(a.out1, 4))) return false;
+    return true;
+}
+
 // out = clamp_i32(prelu_q625(a (+ b)))
 __global__ void k_prelu_i32(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const int32_t *slope, int64_t n,
                             int32_t *__restrict__ out) {
@@ -866,9 +936,15 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
         else hipLaunchKernelGGL((k_conv_i8<1, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
         FPCC_LAUNCHED(k_conv_i8_split);
         if (requant_mul) {
-            hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
-                               slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, out_bits == 8 ? out_pad : 0, nullptr,
-                               residual, ld_res, slope2, p.also);
+            const int pad8 = out_bits == 8 ? out_pad : 0;
+            if (epilogue_v4_ok(acc, c_out, out, ldo, out_bits, c_out, pad8, residual, ld_res, p.also))
+                hipLaunchKernelGGL(k_epilogue_i32_v4, dim3(blocks_for(n_out * ((width + 3) / 4), kThreads)), dim3(kThreads), 0, s, acc, c_out,
+                                   bias, slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, pad8, nullptr,
+                                   residual, ld_res, slope2, p.also);
+            else
+                hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n_out * width, kThreads)), dim3(kThreads), 0, s, acc, c_out, bias,
+                                   slope, requant_mul, 1, zero_point, shift, out_bits, out, ldo, n_out, c_out, pad8, nullptr,
+                                   residual, ld_res, slope2, p.also);
             FPCC_LAUNCHED(k_epilogue_i32);
         }
         return FPCC_OK;
@@ -910,9 +986,15 @@ extern "C" int fpcc_epilogue_i32_also(const int32_t *in, int ldi, const int32_t 
     if (int rc = make_also(also, n_also, out_bits, true, ch, 1 << 30, e)) return rc;
     if (e.n > 0 && e.pad0 > width) width = e.pad0;
     if (e.n > 1 && e.pad1 > width) width = e.pad1;
-    hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n * width, kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
-                       bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch,
-                       out_bits == 8 ? out_pad : 0, row_group, nullptr, 0, nullptr, e);
+    const int pad8 = out_bits == 8 ? out_pad : 0;
+    if (epilogue_v4_ok(in, ldi, out, ldo, out_bits, ch, pad8, nullptr, 0, e))
+        hipLaunchKernelGGL(k_epilogue_i32_v4, dim3(blocks_for(n * ((width + 3) / 4), kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
+                           bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch, pad8, row_group,
+                           nullptr, 0, nullptr, e);
+    else
+        hipLaunchKernelGGL(k_epilogue_i32, dim3(blocks_for(n * width, kThreads)), dim3(kThreads), 0, as_stream(stream), in, ldi,
+                           bias, slope, requant_mul, mul_per_channel ? 1 : 0, zero_point, shift, out_bits, out, ldo, n, ch,
+                           pad8, row_group, nullptr, 0, nullptr, e);
     FPCC_LAUNCHED(k_epilogue_i32);
     return FPCC_OK;
 }
