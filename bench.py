@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--secondary', type=int, default=1, help='0 skips the figures reported next to the headline: cfg#3 / #4 / #5 at N = 1, '
                                                              'the cfg#5 DDP training step over all N ranks at N > 1')
     ap.add_argument('--ddp-steps', type=int, default=10, help='optimisation steps of the cfg#5 DDP figure (N > 1)')
+    ap.add_argument('--ddp-deadline', type=float, default=420.0, help='seconds after which rank 0 prints the headline without the DDP figure')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
     return ap.parse_args()
 
@@ -292,9 +293,12 @@ def main():
     if os.environ.get('FPCC_BENCH_ONE_DEVICE') == '1':
         local = 0
     torch.cuda.set_device(local)
-    # before anything allocates pinned memory or starts threads: run on the CPUs of the GPU's own NUMA node (two-socket hosts)
+    # before anything allocates pinned memory: every thread of the process (the HIP runtime's included) onto the CPUs of the GPU's
+    # own NUMA node (two-socket hosts)
     numa = replicas.bind_to_device_numa_node(local)
-    replicas.init(os.environ.get('FPCC_BENCH_BACKEND', 'nccl'))          # RCCL; only the barrier and two scalar reductions use it
+    # RCCL; only the barrier and two scalar reductions of the headline use it.  Collectives are bounded: a rank that died leaves the
+    # others with an error after 5 minutes instead of a job that never ends
+    replicas.init(os.environ.get('FPCC_BENCH_BACKEND', 'nccl'), timeout_s=300)
     device = torch.device('cuda', local)
 
     from fastpcc_amd.synthetic import enliven
@@ -396,23 +400,8 @@ def main():
     from fastpcc_amd.evaluators import d1_metrics
     quality = d1_metrics(frame[:, 1:], rec, args.resolution)
 
-    # N > 1: the training configuration (cfg#5) shards over the same ranks -- global batch 8 split 8 / N, gradients
-    # all-reduced over RCCL by DDP -- so the driver's own `bench.py --gpus N` runs produce the DDP curve next to the replica
-    # curve.  Collective over all ranks, after (outside) the timed region of the headline metric.
-    ddp_record = None
-    if args.secondary and world > 1:
-        n_bytes = len(data)
-        del model, rec
-        ME.clear_global_coordinate_manager()
-        torch.cuda.empty_cache()
-        from fastpcc_amd.train import ddp_training_record
-        try:
-            ddp_record = ddp_training_record(args.ddp_steps, 3, device)
-        except Exception as e:                                           # the headline number must survive a secondary failure
-            ddp_record = {'error': repr(e)[:200]}
-    else:
-        n_bytes = len(data)
-
+    n_bytes = len(data)
+    out = None
     if rank == 0:
         # dominant kernel: the MFMA sparse convolution.  algorithmic flop / measured duration of its launches
         cache = {}
@@ -494,14 +483,52 @@ def main():
                                               'region (fpcc_clock_probe; profiles/r03/clock_ramp.md); `peak` and `frac` are quoted at the '
                                               'nominal 2400 MHz'},
         }
+
+    # N > 1: the training configuration (cfg#5) shards over the same ranks -- global batch 8 split 8 / N, gradients
+    # all-reduced over RCCL by DDP -- so the driver's own `bench.py --gpus N` runs produce the DDP curve next to the replica
+    # curve.  Collective over all ranks, after (outside) the timed region of the headline metric.  The headline record above is
+    # complete before this leg starts: should a rank fail inside it and leave the others blocked in a collective, rank 0's watchdog
+    # prints the record and ends the job with a non-zero code instead of losing the measurement (the process group's own
+    # timeout, 5 minutes, would otherwise be the only way out).
+    failed = False
+    if args.secondary and world > 1:
+        watchdog = None
+        if rank == 0:
+            import threading
+
+            def give_up():
+                out['config']['secondary'] = {'cfg5_training_ddp': {'error': f'no result within {args.ddp_deadline} s: a rank failed or a '
+                                                                             'collective hung; headline emitted by the watchdog'}}
+                print(json.dumps(out), flush=True)
+                os._exit(3)
+            watchdog = threading.Timer(args.ddp_deadline, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        del model, rec
+        ME.clear_global_coordinate_manager()
+        torch.cuda.empty_cache()
+        from fastpcc_amd.train import ddp_training_record
+        try:
+            ddp_record = ddp_training_record(args.ddp_steps, 3, device)
+        except Exception as e:                                           # the headline number must survive a secondary failure
+            ddp_record = {'error': repr(e)[:200]}
+            failed = True
+        if watchdog is not None:
+            watchdog.cancel()
+        if rank == 0:
+            out['config']['secondary'] = {'cfg5_training_ddp': ddp_record}
+            failed = failed or (ddp_record is not None and 'error' in ddp_record)
+    if rank == 0:
         if args.secondary and world == 1:
             del model, frame
             out['config']['secondary'] = secondary(device)
-        elif ddp_record is not None:
-            out['config']['secondary'] = {'cfg5_training_ddp': ddp_record}
         if cpu_job is not None:
             out['cpu_baseline'] = cpu_job.result()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if failed:
+        # no further collective after a failed one (the other ranks may never arrive): leave without tearing the group down
+        sys.stdout.flush()
+        os._exit(4)
     if world > 1:
         dist.destroy_process_group()
 

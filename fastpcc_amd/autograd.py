@@ -75,8 +75,9 @@ def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     if s.kind == 'tab':
         k = s.table.shape[1]
         out = None
-        for a in range(0, k, _TAB_FWD_CHUNK):
-            b = min(a + _TAB_FWD_CHUNK, k)
+        step = ops.table_conv_chunk(c_in, c_out, k)   # the SAME partition as the inference path (int_sparse_conv.Conv3d._run), so
+        for a in range(0, k, step):                   # a float model gives the same fp32 bits whether or not grad mode is on
+            b = min(a + step, k)
             part = ops.conv_f32(x, w.reshape(k, c_in, c_out)[a:b].contiguous(), c_out, s.n_out,
                                 nbr=s.table[:, a:b].contiguous(), n_offsets=b - a, nbr_ks=1, nbr_os=b - a)
             out = part if out is None else out.add_(part)
@@ -85,8 +86,6 @@ def _forward(x: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
 
 
 _TAB_CHUNK = 16       # kernel offsets per weight-gradient launch of the general-table path (a 4x4x4 kernel has 64)
-_TAB_FWD_CHUNK = 32   # ... per forward launch: the SAME partition as the inference path (int_sparse_conv.Conv3d._run), so a float
-#                       model gives the same fp32 bits whether or not grad mode is on
 
 
 def _wide(call, wt: torch.Tensor, width: int, rows: int, device) -> torch.Tensor:

@@ -29,42 +29,11 @@
 // profiles/r02/wave_kernel_sweeps.md and profiles/r03/{sq_counters,grouped_occupancy,grouped_fold,clock_ramp}.md: each VMEM
 // instruction costs ~30 SIMD cycles of issue that more waves do not hide, the B stream (256 B per MFMA from L2) caps the wave
 // kernel at ~100 TFLOP/s on the 272 K-row maps at 2.4 GHz, and inside a codec step the power management grants ~2.16 GHz.
-#include "common.h"
+#include "conv_common.h"
 #include <cstdlib>
 
 namespace fpcc {
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const float *x1; int c1; int ld1;
-    const float *x2; int c2; int ld2;
-    const int32_t *nbr; int n_off; int64_t nbr_ks; int64_t nbr_os;
-    const float *w; const float *bias; int c_out; int groups;
-    const int32_t *out_map; int64_t om_os; int64_t om_gs; float *out; int ldo; int64_t n_out;
-    int act; const float *slope; float clip;
-    const int32_t *row_order;  // tile position -> output row (NULL: identity); see fpcc_conv_row_keys
-};
-
-__device__ float g_zero_row[64];   // 256 bytes of zeros: the source of every absent neighbour
-
-__device__ __forceinline__ float finish(float v, float b, int act, float slope, float clip) {
-    v = v + b;
-    if (act == FPCC_ACT_PRELU) v = v < 0.0f ? v * slope : v;
-    else if (act == FPCC_ACT_RELU) v = v < 0.0f ? 0.0f : v;
-    if (clip > 0.0f) v = fminf(fmaxf(v, -clip), clip);
-    return v;
-}
-
-// blockIdx.x -> tile so that tiles adjacent in row order share an XCD (and therefore its L2); bijective for any grid size
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
-    const unsigned q = n / 8, r = n % 8, x = bid % 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-}
-
-constexpr int kMaxOffsets = 27;   // the MFMA kernel keeps the tile's neighbour indices in LDS: [27][rows]
 
 // Tile geometry.  A workgroup of WM x WN waves owns TM = 32*WM output rows and all 32*NBT output columns; wave (wr, wc)
 // computes rows [32*wr, 32*wr+32) x column blocks [wc*NBW, (wc+1)*NBW).  Large maps use 128-row tiles (4x1 waves);
@@ -366,9 +335,17 @@ struct WaveCfg {
 // stages is four times shorter and the launch has four times the waves: what maps of a few thousand to a few ten thousand rows
 // lack (one partial round of waves, each latency-bound on its own chain).  The groups are a function of the offset index alone,
 // so a row's result does not depend on which rows share its block.
-__host__ __device__ __forceinline__ int offset_group_begin(int g, int n_off) { return (g * n_off + 3) / 4; }
-__host__ __device__ __forceinline__ int offset_group_of(int k, int n_off) {
-    return (k >= offset_group_begin(1, n_off)) + (k >= offset_group_begin(2, n_off)) + (k >= offset_group_begin(3, n_off));
+// DBG bit 4 (value 16): s_memtime stamps of one wave's life -- kernel entry, neighbour table read, first operands requested, the top
+// of every (offset, chunk) stage, loop end, partial sums exchanged, outputs stored -- for profiles/r04/small_level_stage.md.  A stamp
+// is one LDS store by lane 0 with the exec mask narrowed in place (no branch: a branch in the stage loop makes hipcc drain vmcnt);
+// every wave copies its kStampSlots stamps to the buffer set with fpcc_conv_debug_stamps() when it ends.
+constexpr int kStampSlots = 48;
+__device__ unsigned long long *g_stamp_buf = nullptr;
+__device__ long long g_stamp_cap = 0;
+__device__ __forceinline__ void stamp_lds(unsigned long long *slot) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned addr = (unsigned)(uintptr_t)slot;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(t) : "memory");
 }
 
 // FOLD (with OG == 1; "folded" evaluation of summation order 3): ONE wave walks all offsets of its unit as in order 1, but at every
@@ -376,18 +353,27 @@ __host__ __device__ __forceinline__ int offset_group_of(int k, int n_off) {
 // t = p0, t = t + p1, t = t + p2, t = t + p3 with p_g = 0 for a group without a present offset -- bit for bit what the four waves of
 // OG == 4 leave behind, without their LDS exchange, barrier and wait for the slowest group.  For maps with many row blocks, where
 // the fourfold parallelism of OG == 4 buys nothing (272 K rows: 100 against 95 TFLOP/s, profiles/r03/grouped_fold.md).
-template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false>
+// ASTAGE (experiment, same bits): the A fragments of the NEXT stage are requested all at once at the top of a stage into a second
+// register set (the four 32-byte pieces of a gathered 128-byte line are then touched back to back instead of a quarter stage apart).
+template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false, bool ASTAGE = false>
 __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
                                                                                          int nbt, unsigned n_units) {
     constexpr int G8 = CH / 8;
     __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
     __shared__ float s_part[OG == 4 ? 4 * 16 * NBW * 64 : 1];
+    __shared__ unsigned long long s_stamp[(DBG & 16) ? 4 * kStampSlots : 1];
+#define FPCC_STAMP(i) do { if (DBG & 16) stamp_lds(&s_stamp[wv * kStampSlots + (i)]); } while (0)
 
     // the wave index is wave-uniform, but hipcc only knows that when told: everything derived from it (the wave's offset group, its
     // offset mask, the stage iterator) otherwise lives in VGPRs, and the loop control below becomes ~25 vector instructions and
     // three exec-mask branches per stage instead of scalar code beside the MFMAs
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    if (DBG & 16) {
+        for (int i = lane; i < kStampSlots; i += 64) s_stamp[wv * kStampSlots + i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    FPCC_STAMP(0);
     const unsigned n_cg = (unsigned)(nbt / NBW);
     // unit = (32-row block, column group); the column groups of one row block are adjacent units (same workgroup: their A
     // rows hit the CU's vector L1).  Natural order: contiguous unit ranges per XCD; with a row order: dispatch order.
@@ -417,6 +403,7 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
     }
     __builtin_amdgcn_wave_barrier();               // LDS operations of one wave execute in order; keep the compiler from reordering
     wmask = __builtin_amdgcn_readfirstlane(wmask);
+    FPCC_STAMP(1);
 
     f32x16 acc[NBW];
 #pragma unroll
@@ -503,10 +490,18 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
         // wait counts at the loop head are merged over both ways into it, and a different order here (the scheduler reverses
         // it if left alone) turns them into vmcnt(0) on every iteration.
         next_stage();
+        f32x4 ran[ASTAGE ? G8 : 1];
+        if (ASTAGE) {
+#pragma unroll
+            for (int g8 = 0; g8 < G8; ++g8) {
+                __builtin_amdgcn_sched_barrier(0);
+                ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+            }
+        }
 #pragma unroll
         for (int g8 = 0; g8 < G8; ++g8) {
             __builtin_amdgcn_sched_barrier(0);
-            ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+            if (!ASTAGE) ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -514,7 +509,9 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        FPCC_STAMP(2);
         for (int s = 0; s < n_stages; ++s) {
+            FPCC_STAMP(3 + (s < 36 ? s : 36));
             if (FOLD) {
                 // compute position (one stage behind the fetch position): entering the first chunk of an offset of a later group
                 if (cc_c == 0) {
@@ -529,6 +526,13 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
             }
             next_stage();                                       // stage s + 1
             __builtin_amdgcn_sched_barrier(SB);
+            if (ASTAGE) {
+#pragma unroll
+                for (int g8 = 0; g8 < G8; ++g8) {
+                    ran[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+                    __builtin_amdgcn_sched_barrier(SB);
+                }
+            }
 #pragma unroll
             for (int g8 = 0; g8 < G8; ++g8) {
                 const f32x4 av = ra[g8];
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
                 for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, rb[g8][nb].w, acc[nb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(SB);
                 // the registers of this group are free now: refill them for the next stage
-                ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
+                if (!ASTAGE) ra[g8] = *reinterpret_cast<const f32x4 *>(ap + 8 * g8);
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
                     __builtin_amdgcn_sched_barrier(SB);
@@ -550,9 +554,15 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
                 }
                 __builtin_amdgcn_sched_barrier(SB);
             }
+            if (ASTAGE) {
+#pragma unroll
+                for (int g8 = 0; g8 < G8; ++g8) ra[g8] = ran[g8];
+                __builtin_amdgcn_sched_barrier(SB);
+            }
         }
     }
 
+    FPCC_STAMP(40);
     if (FOLD) {
         if (wmask) { fold_acc(); ++cur_g; }
         for (int gz = cur_g; gz < 4; ++gz) fold_zero();
@@ -569,6 +579,7 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) s_part[((wv * NBW + nb) * 16 + reg) * 64 + lane] = acc[nb][reg];
         __syncthreads();
+        FPCC_STAMP(41);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int reg = 4 * wv + q;
@@ -585,6 +596,19 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
                 const float b = a.bias ? a.bias[col] : 0.0f;
                 a.out[dst * a.ldo + col] = finish(v, b, a.act, slope, a.clip);
             }
+        }
+        if (DBG & 16) {
+            FPCC_STAMP(42);
+            if (lane == 0) {
+                s_stamp[wv * kStampSlots + 44] = (unsigned long long)n_stages;
+                s_stamp[wv * kStampSlots + 45] = ((unsigned long long)blockIdx.x << 8) | (unsigned)wv;
+                s_stamp[wv * kStampSlots + 46] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+                s_stamp[wv * kStampSlots + 47] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            }
+            __builtin_amdgcn_wave_barrier();
+            const long long w_id = (long long)blockIdx.x * 4 + wv;
+            if (g_stamp_buf && (w_id + 1) * kStampSlots <= g_stamp_cap && lane < kStampSlots)
+                g_stamp_buf[w_id * kStampSlots + lane] = s_stamp[wv * kStampSlots + lane];
         }
         return;
     }
@@ -806,14 +830,14 @@ int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
 // kKnobGroupedOff (experiments only: 1 = multi-offset layers in order 1 on the plain wave kernel instead of grouped / order 3),
 // which is therefore refused unless the process runs with FPCC_EXPERIMENT=1 and has no environment variable.
 enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobGroupedFoldRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
-       kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobCount = 10 };
-int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+       kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobLdsRows = 10, kKnobLdsRowBlocks = 11, kKnobCount = 12 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
         static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_GROUPED_FOLD_ROWS",
                                                 "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS", "", "FPCC_GROUPED_NBW",
-                                                "FPCC_WAVE22_MIN_ROWS"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, 100 * 1024, 0, 32 * 1024, 0, 0, 0};
+                                                "FPCC_WAVE22_MIN_ROWS", "FPCC_LDS_MIN_ROWS", "FPCC_LDS_ROW_BLOCKS"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 100 * 1024, 0, 32 * 1024, 0, 0, 0, 0, 2};
         const char *e = k == kKnobGroupedOff ? nullptr : getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
@@ -868,7 +892,17 @@ int launch_grouped_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t 
     const int64_t row_blocks = (a.n_out + 31) / 32;
     const int64_t units = row_blocks * (nbt / NBW);
     if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
-    hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    const int dbg = knob(kKnobWaveDbg);
+    if (dbg == 16)                      // stage stamps (fpcc_conv_debug_stamps)
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 16, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (NBW == 1 && dbg == 17)     // + no gather traffic / weights from one chunk / both (results wrong)
+        hipLaunchKernelGGL((k_conv_wave<1, 32, 0x6, 17, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (NBW == 1 && dbg == 18)
+        hipLaunchKernelGGL((k_conv_wave<1, 32, 0x6, 18, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else if (NBW == 1 && dbg == 19)
+        hipLaunchKernelGGL((k_conv_wave<1, 32, 0x6, 19, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
+    else
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
     return check_hip(hipGetLastError(), "k_conv_wave(grouped)");
 }
 
@@ -877,13 +911,23 @@ template <int NBW>
 int launch_folded_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
     const int64_t units = ((a.n_out + 31) / 32) * (nbt / NBW);
     if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
-    hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 1, true>), dim3((unsigned)((units + 3) / 4), a.groups), dim3(256), 0, s, a, wp, nbt,
-                       (unsigned)units);
+    if (NBW == 2 && knob(kKnobWaveDbg) == 32)        // experiment: A fragments a whole stage at a time
+        hipLaunchKernelGGL((k_conv_wave<2, 32, 0x6, 0, 1, true, true>), dim3((unsigned)((units + 3) / 4), a.groups), dim3(256), 0, s, a, wp, nbt,
+                           (unsigned)units);
+    else
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 1, true>), dim3((unsigned)((units + 3) / 4), a.groups), dim3(256), 0, s, a, wp, nbt,
+                           (unsigned)units);
     return check_hip(hipGetLastError(), "k_conv_wave(folded)");
 }
 
 int launch_grouped(const ConvArgs &a, const float *wp, hipStream_t s) {
     const int nbt = a.c_out / 32;
+    // both operands through LDS (conv_lds.hip) on maps of at least FPCC_LDS_MIN_ROWS rows (knob 10; 0 = never); same order 3
+    const int64_t lds_rows = knob(kKnobLdsRows);
+    if (lds_rows > 0 && a.n_out >= lds_rows) {
+        const int rc = launch_conv_lds(a, wp, knob(kKnobLdsRowBlocks), knob(kKnobWaveDbg) & 3, s);
+        if (rc != -1) return rc;
+    }
     const int64_t fold_rows = knob(kKnobGroupedFoldRows);
     if (fold_rows > 0 && a.n_out >= fold_rows && knob(kKnobGroupedNbw) <= 0)
         return nbt % 2 == 0 ? launch_folded_cfg<2>(a, wp, nbt, s) : launch_folded_cfg<1>(a, wp, nbt, s);
@@ -1157,6 +1201,14 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
     hipLaunchKernelGGL(k_conv_ones_k3, dim3(blocks_for(n * (c_out / 4), 256)), dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out,
                        act, slope, clip, out, ldo);
     return check_hip(hipGetLastError(), "k_conv_ones_k3");
+}
+
+extern "C" int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64) {
+    if (n_u64 < 0 || (n_u64 > 0 && !buf)) return fail_arg("conv_debug_stamps: null buffer");
+    const long long cap = buf ? n_u64 : 0;
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &cap, sizeof(cap)));
+    return FPCC_OK;
 }
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {

@@ -37,6 +37,7 @@ _SIGS = {
     'fpcc_conv_f32_pk': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32,
                                 _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
+    'fpcc_conv_debug_stamps': (_i32, [_vp, _i64]),
     'fpcc_numerics_version': (_i32, []),
     'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
     'fpcc_conv_pack_weights_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
@@ -387,6 +388,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
 KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 5, 6
 KNOB_GROUPED_FOLD_ROWS = 4       # rows from which grouped (order 3) layers run folded on one wave per unit; 0 = never
 KNOB_GROUPED_OFF, KNOB_GROUPED_NBW, KNOB_WAVE22_ROWS = 7, 8, 9      # 7: experiments only (FPCC_EXPERIMENT=1), changes the summation order
+KNOB_LDS_ROWS, KNOB_LDS_ROW_BLOCKS = 10, 11   # rows from which order-3 layers take both operands through LDS (0 = never); row blocks per workgroup (2 | 3 | 4)
 
 
 def numerics_version() -> int:
@@ -398,6 +400,15 @@ def clock_probe(out2: torch.Tensor, spin_us: int = 20) -> None:
     """diagnostic (fpcc_clock_probe): enqueue a one-wave kernel that leaves (shader cycles, 100 MHz ticks) of a spin_us spin in the
     int64[2] device tensor out2"""
     _ok(lib().fpcc_clock_probe(_dev(out2, torch.int64, 'out2'), int(spin_us), _stream()))
+
+
+def conv_debug_stamps(buf: Optional[torch.Tensor]) -> None:
+    """diagnostic (fpcc_conv_debug_stamps): int64 device buffer the grouped kernel's waves leave their stage stamps in while knob 3
+    is 16; None detaches"""
+    if buf is None:
+        _ok(lib().fpcc_conv_debug_stamps(None, 0))
+    else:
+        _ok(lib().fpcc_conv_debug_stamps(_dev(buf, torch.int64, 'buf'), buf.numel()))
 
 
 def conv_set_tuning(which: int, value: int) -> int:
@@ -750,6 +761,17 @@ def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, 
 
 LPT_MAX_GROUPS = 1 << 14
 
+def table_conv_chunk(c_in: int, c_out: int, k: int) -> int:
+    """Kernel offsets per launch of a general-table convolution (kernels other than 3x3x3 / 2x2x2, e.g. the 4x4x4 occupancy embedding
+    with 64 offsets), whose launches' results are added in order.  fpcc_conv_f32 takes up to 32 offsets per launch on the VALU path
+    and up to 27 on the MFMA path: shapes of the VALU path keep the partition into 32s they always had (their fp32 bits are pinned
+    by fixtures), MFMA-capable shapes with more than 27 offsets go in 16s.  ONE rule for the inference partition
+    (int_sparse_conv.Conv3d._run) and the training partition (autograd._forward), so that both sum in the same order."""
+    mfma = conv_order(c_in, 0, c_out, 1, 1, 0) != 0
+    if not mfma:
+        return 32
+    return k if k <= 27 else 16
+
 
 @functools.lru_cache(maxsize=8192)
 def conv_order(c1: int, c2: int, c_out: int, n_offsets: int = 1, groups: int = 1, n_out: int = 0) -> int:
@@ -932,12 +954,15 @@ def _also8(also, n: int, c_out: int, device):
         return None, 0, []
     arr = (_Requant8 * len(also))()
     outs = []
+    keep = []          # converted multipliers: a temporary freed before the launch could be handed out again by the caching allocator
     for i, (mul, zp, shift, width) in enumerate(also):
         buf = torch.empty((n, width), dtype=torch.int8, device=device)
         m = _mul_u32(mul)
+        keep.append(m)
         arr[i].out, arr[i].ld, arr[i].pad = buf.data_ptr(), width, c_out
         arr[i].requant_mul, arr[i].zero_point, arr[i].shift = _any(m, 'requant_mul', _U32), _dev(zp, torch.int64, 'zero_point'), int(shift)
         outs.append(buf)
+    arr._keep = keep   # lives as long as the descriptor array the caller passes to the launch
     return arr, len(also), outs
 
 

@@ -207,8 +207,9 @@ class Conv3d(nn.Module):
         x = in_feats.float().contiguous()
         bias = None if self.bias is None else self.bias.detach()
         out = None
-        for a in range(0, k, 32):                  # fpcc_conv_f32 takes up to 32 offsets per launch (a 4x4x4 kernel has 64)
-            b = min(a + 32, k)
+        step = ops.table_conv_chunk(self.in_channels, self.out_channels, k)
+        for a in range(0, k, step):                # fpcc_conv_f32 takes up to 32 (MFMA path: 27) offsets per launch (a 4x4x4 kernel has 64)
+            b = min(a + step, k)
             part = ops.conv_f32(x, w[a:b].reshape(1, b - a, self.in_channels, self.out_channels).contiguous(), self.out_channels,
                                 n_out, nbr=nbr if (a, b) == (0, k) else nbr[:, a:b].contiguous(), n_offsets=b - a, nbr_ks=1,
                                 nbr_os=b - a, bias=bias if a == 0 else None)

@@ -16,9 +16,23 @@ def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
-def init(backend: str) -> None:
+def init(backend: str, timeout_s: Optional[float] = None) -> None:
+    """timeout_s bounds every collective of the group: a rank that died leaves the others with an error after that long instead of
+    a process that never ends (the default of the backends is 10 - 30 minutes)"""
     if env_rank()[1] > 1 and not dist.is_initialized():
-        dist.init_process_group(backend, init_method='env://')
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw['timeout'] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend, init_method='env://', **kw)
+
+
+def all_ok(ok: bool, device: torch.device) -> bool:
+    """collective: True when every rank passed True (one MIN all-reduce); lets the ranks leave a multi-rank phase together"""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
 
 
 def _parse_cpulist(text: str) -> List[int]:
@@ -32,8 +46,8 @@ def _parse_cpulist(text: str) -> List[int]:
 
 
 def bind_to_device_numa_node(device_index: int) -> Optional[dict]:
-    """Pin the calling thread (and every thread it starts later: the coder pool, torch's workers) to the CPUs of the NUMA node the
-    GPU hangs off, read from sysfs by its PCI address.  MI355X hosts here are two-socket machines; a process scheduled on the far
+    """Pin every thread of the process (those the HIP runtime has already started included, and with them every thread started
+    later: the coder pool, torch's workers) to the CPUs of the NUMA node the GPU hangs off, read from sysfs by its PCI address.  MI355X hosts here are two-socket machines; a process scheduled on the far
     socket allocates its pinned staging buffers there and every device<->host copy, flag write and launch crosses the inter-socket
     link.  What `numactl --cpunodebind` does for a
     serving process.  Default: on for the ranks of a multi-process job (one rank per GPU, the usual practice), off for a single
@@ -57,8 +71,17 @@ def bind_to_device_numa_node(device_index: int) -> Optional[dict]:
         target = sorted(set(cpus) & allowed)
         if not target or len(target) == len(allowed):
             return None
+        # every thread the process already has (reading the device properties started the HIP runtime's), not only the caller:
+        # sched_setaffinity(0, ...) binds one thread, and only threads created afterwards inherit it
+        n_threads = 0
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                os.sched_setaffinity(int(tid), target)
+                n_threads += 1
+            except (OSError, ValueError):                            # a thread that ended meanwhile
+                pass
         os.sched_setaffinity(0, target)
-        return {'pci': addr, 'numa_node': node, 'cpus': len(target)}
+        return {'pci': addr, 'numa_node': node, 'cpus': len(target), 'threads_bound': n_threads}
     except (OSError, AttributeError, ValueError, RuntimeError, AssertionError):      # no device / no sysfs entry: nothing to bind to
         return None
 

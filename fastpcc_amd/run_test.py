@@ -43,13 +43,20 @@ def build_model(config_path: Optional[str], weights: Optional[str], device: torc
     if config_path is None:
         from .codecs.lossy_coord_v2 import Model
         from .codecs.lossy_coord_v2.model_config import baseline_r1
-        model, sections = Model(baseline_r1()), {}
+        cfg = baseline_r1()
+        cfg.numerics_version_in_header = True
+        model, sections = Model(cfg), {}
     else:
         sections = _yaml_sections(config_path)
         ref_path = sections.get('model_module_path', 'models.convolutional.lossy_coord_v2')
         module = importlib.import_module(MODEL_MODULES.get(ref_path, ref_path))
         cfg_cls = getattr(module, 'Config', None) or getattr(module, 'ModelConfig')
         cfg = cfg_cls(**(sections.get('model') or {}))
+        # Streams of the float codecs are only decodable under the summation-order rules they were written with (include/fpcc_hip.h,
+        # 'Numerics version'): evaluation runs carry the version byte unless the YAML says otherwise, so that a build with other
+        # rules refuses the stream instead of decoding garbage.  (The library default stays the reference's byte layout.)
+        if hasattr(cfg, 'numerics_version_in_header') and 'numerics_version_in_header' not in (sections.get('model') or {}):
+            cfg.numerics_version_in_header = True
         try:
             model = module.Model(cfg, device)
         except TypeError:

@@ -227,9 +227,27 @@ def ddp_training_record(steps: int, warmup: int, device: torch.device, resolutio
     rank, world, _ = replicas.env_rank()
     if cfg.batch_size % world:
         return {'skipped': f'global batch {cfg.batch_size} does not divide over {world} ranks'} if rank == 0 else None
-    torch.manual_seed(0)                                  # same initial weights on every rank
-    trainer = Trainer(Model(baseline_r1()), cfg, device)
-    data = synthetic_batches(rank, world, cfg, device, resolution)
+    # Everything a rank can fail at on its own (model construction, its share of the data, one local forward + backward: memory,
+    # a kernel error) happens BEFORE the first collective of this leg, and the ranks then agree on one verdict: a rank that failed
+    # alone would otherwise leave the others blocked in DDP's parameter broadcast or the first gradient all-reduce.
+    failure = None
+    model = data = None
+    try:
+        torch.manual_seed(0)                              # same initial weights on every rank
+        model = Model(baseline_r1()).to(device).train()
+        data = synthetic_batches(rank, world, cfg, device, resolution)
+        probe = next(data)
+        probe.training_step = 0
+        model(probe)['loss'].backward()
+        model.zero_grad(set_to_none=True)
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
+    except Exception as e:                                # noqa: BLE001 -- any local failure becomes the job's verdict
+        failure = repr(e)[:200]
+    if not replicas.all_ok(failure is None, device):
+        del model, data
+        return {'error': failure or 'another rank failed before the first collective'} if rank == 0 else None
+    trainer = Trainer(model, cfg, device)
     torch.manual_seed(1000 + rank)                        # different bottleneck noise per rank
     elapsed_max, total_voxels, comm_ms, last = ddp_bench(trainer, data, steps, warmup, device, cfg.batch_size)
     if rank != 0:

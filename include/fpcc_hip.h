@@ -180,16 +180,25 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *   0  use the wave kernel when packed weights are given (1) or the workgroup-tiled kernel (0)
  *   1  column blocks per wave: 0 = by map size, else 1 | 2 | 4
  *   2  1 = the next stage's address arithmetic may be scheduled between the MFMAs, 0 = nothing crosses the load points
- *   3  timing experiments only (results are WRONG): 1 = no gather traffic, 2 = weights from one chunk, 3 = both; 0 = off
+ *   3  timing experiments only (results are WRONG): 1 = no gather traffic, 2 = weights from one chunk, 3 = both; 0 = off;
+ *      16 = stage stamps of the grouped kernel (results exact, see fpcc_conv_debug_stamps)
  *   5  row tile of the workgroup-tiled kernel: 0 = by map size, 1 | 2 | 3 = 128 | 64 | 32 rows
  *   6  rows from which per-point layers (one offset, identity map) run on the persistent kernel that keeps the weights in
  *      registers (FPCC_POINTWISE_MIN_ROWS, default 32768); 0 = never
  *   8  column blocks per workgroup of the grouped evaluation: 0 = by map size, else 1 | 2 (FPCC_GROUPED_NBW)
  *   9  rows from which order-1 multi-offset layers use 64 x 64 wave tiles (FPCC_WAVE22_MIN_ROWS; 0 = never, the default)
  *   7  (NOT result-neutral, refused unless FPCC_EXPERIMENT=1) 1 = evaluate grouped shapes in order 1 instead: A/B experiments
+ *  10  rows from which order-3 layers with 64 or 128 output channels take BOTH MFMA operands through LDS (k_conv_lds, conv_lds.hip:
+ *      LDS-DMA staging, 2-4 row blocks of a workgroup in lockstep; FPCC_LDS_MIN_ROWS; 0 = never).  Same order 3, same bits.
+ *  11  row blocks per workgroup of that kernel: 2 | 3 | 4 (FPCC_LDS_ROW_BLOCKS, default 2)
  *   4  rows from which the grouped evaluation runs FOLDED -- one wave per unit adds up the four offset groups itself -- instead of on
  *      four waves per unit (FPCC_GROUPED_FOLD_ROWS, default 102400; 0 = never).  Same order 3, same bits. */
 int fpcc_conv_set_tuning(int which, int value);
+/* Diagnostics (profiles/r04/small_level_stage.md): with knob 3 set to 16 every wave of the grouped kernel leaves 48 64-bit words in
+ * `buf` (device memory, n_u64 words; NULL / 0 detaches): s_memtime at kernel entry [0], after the neighbour-table read [1], after the
+ * first operands were requested [2], at the top of stage s [3 + min(s, 36)], after the last stage [40], after the partial-sum
+ * exchange [41], after the stores [42]; [44] stages, [45] workgroup << 8 | wave, [46] HW_ID, [47] XCC_ID.  Results stay exact. */
+int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64);
 /* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
  * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks
  * (fpcc_mask27_from_parent / fpcc_conv_row_keys) -- the chain of fpcc_conv_f32 with x = 1, bit for bit, without the 27-entry

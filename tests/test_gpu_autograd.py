@@ -203,3 +203,42 @@ def test_weight_gradient_in_pattern_row_order(c_in, c_out):
     base = torch.ones_like(got)
     ops.conv_wgrad(x, dy, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=order, out=base, accumulate=True)
     assert torch.allclose(base, got + 1, rtol=0, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize('k,c_in,c_out', [(64, 32, 32), (64, 1, 16), (30, 32, 64), (27, 32, 32)])
+def test_general_table_convolution_with_many_offsets(k, c_in, c_out):
+    """a lookup-table convolution with more offsets than one launch takes (the 4x4x4 occupancy embedding has 64; the MFMA path takes 27,
+    the VALU path 32 per launch): the partition of hipops.table_conv_chunk is the same in the autograd forward and in the inference
+    operator, so both give the same bits, and forward / weight gradient match a float64 evaluation"""
+    from fastpcc_amd import hipops as ops
+    from fastpcc_amd.autograd import ConvSpec, sparse_conv
+    g = torch.Generator().manual_seed(k + c_in)
+    n_in, n_out = 700, 500
+    table = torch.randint(-1, n_in, (n_out, k), generator=g).to(torch.int32)
+    table[torch.rand((n_out, k), generator=g) < 0.4] = -1
+    table = table.cuda()
+    x = torch.randn((n_in, c_in), generator=g).cuda()
+    w = (torch.randn((k, c_in, c_out), generator=g) / (k * c_in) ** 0.5).cuda().requires_grad_()
+    y = sparse_conv(x, w, ConvSpec('tab', n_in, n_out, table))
+    gy = torch.randn((n_out, c_out), generator=g).cuda()
+    y.backward(gy)
+    xd, wd = x.double(), w.detach().double().requires_grad_()
+    yr = torch.zeros((n_out, c_out), dtype=torch.float64, device='cuda')
+    for j in range(k):
+        idx = table[:, j].long()
+        ok = idx >= 0
+        yr = yr + torch.where(ok[:, None], xd[idx.clamp(min=0)] @ wd[j], torch.zeros((), dtype=torch.float64, device='cuda'))
+    yr.backward(gy.double())
+    _close(y.detach(), yr.detach(), 'tab forward')
+    _close(w.grad, wd.grad, 'tab dW')
+    # the inference partition: the same launches, added in the same order
+    step = ops.table_conv_chunk(c_in, c_out, k)
+    assert step <= (27 if ops.conv_order(c_in, 0, c_out, 1, 1, 0) else 32)
+    out = None
+    with torch.no_grad():
+        for a in range(0, k, step):
+            b = min(a + step, k)
+            part = ops.conv_f32(x, w.detach()[a:b].contiguous(), c_out, n_out, nbr=table[:, a:b].contiguous(), n_offsets=b - a, nbr_ks=1,
+                                nbr_os=b - a)
+            out = part if out is None else out.add_(part)
+    assert torch.equal(out, y.detach())

@@ -581,3 +581,45 @@ def test_folded_evaluation_is_order_3_too(ops, scene, c1, c2, c_out, n_off, spar
     want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.25, clip=1.9, order=3)
     for got in (four_waves, folded, ordered, plain):
         assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
+@pytest.mark.parametrize('c1,c2,c_out,n_off', [(128, 0, 128, 27), (128, 128, 128, 27), (64, 0, 64, 27), (64, 0, 128, 8), (128, 0, 64, 27), (96, 0, 64, 27)])
+@pytest.mark.parametrize('sparse', [False, True])
+@pytest.mark.parametrize('row_blocks', [2, 3, 4])
+def test_lds_operand_kernel_is_order_3_too(ops, scene, c1, c2, c_out, n_off, sparse, row_blocks):
+    """k_conv_lds (both MFMA operands staged through LDS by LDS-DMA, 2 | 3 | 4 row blocks of a workgroup in lockstep over the union of
+    their offsets) leaves the oracle's order-3 bits: dense and sparse tables (whole offset groups missing from a block, blocks of one
+    tile with different offset sets, a row without neighbours), natural and pattern row order, a ragged last tile"""
+    rng = np.random.default_rng(c1 + c2 + c_out + n_off + 1000 * sparse + row_blocks)
+    lvl = scene['lvl']
+    table = (scene['k3'] if n_off == 27 else scene['k2']).copy()
+    n = table.shape[1]
+    if sparse:
+        begins = [(g * n_off + 3) // 4 for g in range(5)]
+        for r0 in range(0, n, 48):
+            keep = [(r0 // 48) % 4] if (r0 // 96) % 2 else [(r0 // 48) % 4, (r0 // 48 + 2) % 4]
+            for g in range(4):
+                if g not in keep:
+                    table[begins[g]:begins[g + 1], r0:r0 + 48] = -1
+        table[:, 7] = -1
+        table[:, 4096:4096 + 32 * row_blocks] = -1                                # a whole tile without any neighbour
+    n_in = lvl.n
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32)
+    x2 = rng.normal(size=(n_in, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(n_off, c1 + c2, c_out)) / np.sqrt(n_off / 2 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    slope = torch.tensor([0.25], device='cuda')
+    kw = dict(x2=None if x2 is None else _cuda(x2), nbr=_cuda(table), n_offsets=n_off, nbr_ks=n, nbr_os=1, bias=_cuda(b),
+              act=ops.ACT_PRELU, slope=slope, clip=1.9)
+    order = ops.conv_row_order(kw['nbr'], n_off, n, 1, n) if n_off == 27 else None
+    saved = [ops.conv_set_tuning(ops.KNOB_LDS_ROWS, 1), ops.conv_set_tuning(ops.KNOB_LDS_ROW_BLOCKS, row_blocks)]
+    try:
+        natural = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, pack=True, **kw)
+        ordered = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, pack=True, row_order=order, **kw)
+        plain = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, **kw)
+    finally:
+        ops.conv_set_tuning(ops.KNOB_LDS_ROWS, saved[0])
+        ops.conv_set_tuning(ops.KNOB_LDS_ROW_BLOCKS, saved[1])
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.25, clip=1.9, order=3)
+    for got in (natural, ordered, plain):
+        assert (_bits(got.cpu().numpy()) == _bits(want)).all()

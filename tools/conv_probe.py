@@ -53,9 +53,18 @@ if os.environ.get('W22'):        # W22=1: the default unit against 64 x 64 wave 
     variants = [(-1, 1), (-2, 1)]
 if os.environ.get('GROUPED'):    # GROUPED=1 (needs FPCC_EXPERIMENT=1): order 1 default unit against the grouped (order 3) evaluation
     variants = [(-1, 1), (-3, 1), (-4, 1)]
+if os.environ.get('LDS'):        # LDS=0,2,3,4: the default kernels (0) against k_conv_lds with 2 | 3 | 4 row blocks per workgroup
+    variants = [(-100 - int(v), 1) for v in os.environ['LDS'].split(',')]
 for dbg, (nbw, sb) in [(a, c) for a in DBG for c in variants]:
   ops.conv_set_tuning(3, dbg)
   tag = ''
+  if nbw is not None and nbw <= -100:
+      rb = -100 - nbw
+      ops.conv_set_tuning(ops.KNOB_LDS_ROWS, 1 if rb else 0)
+      if rb:
+          ops.conv_set_tuning(ops.KNOB_LDS_ROW_BLOCKS, rb)
+      tag = f' [lds kernel, {rb} row blocks, dbg={dbg}]' if rb else f' [default kernel dbg={dbg}]'
+      nbw = None
   if nbw is not None and nbw < 0:
       ops.conv_set_tuning(ops.KNOB_WAVE_ON, 1); ops.conv_set_tuning(ops.KNOB_WAVE_NBW, 0); ops.conv_set_tuning(ops.KNOB_WAVE_SB, sb)
       ops.conv_set_tuning(ops.KNOB_WAVE22_ROWS, 1 if nbw == -2 else 0)
