@@ -209,19 +209,26 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
         }
     }
 
+    // Every load the epilogue needs (slope, bias, output-map entries) BEFORE the first store: a load placed between two stores makes
+    // the wave wait for it with vmcnt(0), i.e. for every store issued so far -- a full memory round trip per output row
+    // (profiles/r04/prologue_epilogue.md: the stores of a wave took 36-70 K cycles on a loaded chip).
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    float bias[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) bias[nb] = a.bias ? a.bias[32 * (wc * NBW + nb) + li] : 0.0f;
+    int64_t dsts[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int64_t o = s_row[wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh];
-        if (o < 0) continue;
-        const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+        dsts[reg] = o < 0 ? -1 : a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t dst = dsts[reg];
         if (dst < 0) continue;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int col = 32 * (wc * NBW + nb) + li;
-            const float b = a.bias ? a.bias[col] : 0.0f;
-            a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
-        }
+        for (int nb = 0; nb < NBW; ++nb)
+            a.out[dst * a.ldo + 32 * (wc * NBW + nb) + li] = finish(acc[nb][reg], bias[nb], a.act, slope, a.clip);
     }
 }
 
@@ -339,14 +346,6 @@ struct WaveCfg {
 // of every (offset, chunk) stage, loop end, partial sums exchanged, outputs stored -- for profiles/r04/small_level_stage.md.  A stamp
 // is one LDS store by lane 0 with the exec mask narrowed in place (no branch: a branch in the stage loop makes hipcc drain vmcnt);
 // every wave copies its kStampSlots stamps to the buffer set with fpcc_conv_debug_stamps() when it ends.
-constexpr int kStampSlots = 48;
-__device__ unsigned long long *g_stamp_buf = nullptr;
-__device__ long long g_stamp_cap = 0;
-__device__ __forceinline__ void stamp_lds(unsigned long long *slot) {
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    const unsigned addr = (unsigned)(uintptr_t)slot;
-    asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(t) : "memory");
-}
 
 // FOLD (with OG == 1; "folded" evaluation of summation order 3): ONE wave walks all offsets of its unit as in order 1, but at every
 // boundary between two offset groups it adds the accumulator to a running sum t and restarts the accumulator from zero:
@@ -359,7 +358,7 @@ template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false, b
 __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
                                                                                          int nbt, unsigned n_units) {
     constexpr int G8 = CH / 8;
-    __shared__ int32_t s_nbr_all[4][kMaxOffsets * 32];
+    __shared__ int32_t s_nbr_all[4][32 * 32];      // [offset (padded to 32)][row] per wave
     __shared__ float s_part[OG == 4 ? 4 * 16 * NBW * 64 : 1];
     __shared__ unsigned long long s_stamp[(DBG & 16) ? 4 * kStampSlots : 1];
 #define FPCC_STAMP(i) do { if (DBG & 16) stamp_lds(&s_stamp[wv * kStampSlots + (i)]); } while (0)
@@ -392,14 +391,37 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
     // neighbour rows of my 32 output rows -> this wave's LDS slice; lane half h takes the offsets of parity h
     unsigned wmask = 0;
     const int k_lo = OG == 4 ? offset_group_begin(wv, a.n_off) : 0, k_hi = OG == 4 ? offset_group_begin(wv + 1, a.n_off) : a.n_off;
-    for (int k0 = k_lo; k0 < k_hi; k0 += 2) {
-        const int k = k0 + lh;
-        int32_t v = -1;
-        if (k < k_hi && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
-        if (k < k_hi) s_nbr[k * 32 + li] = v;
-        const unsigned long long b = __ballot(v >= 0);
-        if (b & 0xffffffffull) wmask |= 1u << k0;
-        if (b >> 32) wmask |= 1u << (k0 + 1);
+    if (table_is_row_major(a)) {
+        // row-major table: lane (i, h) fetches entries [16 h, 16 h + 16) of row i as four 16-byte pieces of the row's line (pieces past
+        // the row's last one re-read it; entries past n_off are discarded) -- all requests first, then the LDS writes and the ballots
+        const int last_piece = (a.n_off - 1) >> 2;
+        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + (int64_t)(my_row < 0 ? 0 : my_row) * a.nbr_os);
+        i32x4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = rowp[min(4 * lh + j, last_piece)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * lh + 4 * j + e;                           // this lane's offset; k0 = the offset of lane half 0
+                const int k0 = 4 * j + e;
+                const int32_t v = (k < a.n_off && my_row >= 0) ? q[j][e] : -1;
+                s_nbr[k * 32 + li] = v;                                      // slots 27 .. 31 exist and are never read
+                const unsigned long long b = __ballot(v >= 0);
+                if (b & 0xffffffffull) wmask |= 1u << k0;
+                if (b >> 32) wmask |= 1u << (k0 + 16);
+            }
+        if (OG == 4) wmask &= (k_hi >= 32 ? ~0u : (1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+    } else {
+        for (int k0 = k_lo; k0 < k_hi; k0 += 2) {
+            const int k = k0 + lh;
+            int32_t v = -1;
+            if (k < k_hi && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
+            if (k < k_hi) s_nbr[k * 32 + li] = v;
+            const unsigned long long b = __ballot(v >= 0);
+            if (b & 0xffffffffull) wmask |= 1u << k0;
+            if (b >> 32) wmask |= 1u << (k0 + 1);
+        }
     }
     __builtin_amdgcn_wave_barrier();               // LDS operations of one wave execute in order; keep the compiler from reordering
     wmask = __builtin_amdgcn_readfirstlane(wmask);
@@ -578,23 +600,30 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) s_part[((wv * NBW + nb) * 16 + reg) * 64 + lane] = acc[nb][reg];
+        // bias and output-map entries before the barrier and the stores (see k_conv_mfma's epilogue: no load between two stores)
+        float bias4[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) bias4[nb] = a.bias ? a.bias[32 * ((int)cg * NBW + nb) + li] : 0.0f;
+        int64_t dst4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int reg = 4 * wv + q;
+            const int64_t o = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+            dst4[q] = o < 0 ? -1 : a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+        }
         __syncthreads();
         FPCC_STAMP(41);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int reg = 4 * wv + q;
-            const int64_t o = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
-            if (o < 0) continue;
-            const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+            const int64_t dst = dst4[q];
             if (dst < 0) continue;
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 const float *p = s_part + (nb * 16 + reg) * 64 + lane;
                 constexpr int kStride = NBW * 16 * 64;
                 const float v = ((p[0] + p[kStride]) + p[2 * kStride]) + p[3 * kStride];
-                const int col = 32 * ((int)cg * NBW + nb) + li;
-                const float b = a.bias ? a.bias[col] : 0.0f;
-                a.out[dst * a.ldo + col] = finish(v, b, a.act, slope, a.clip);
+                a.out[dst * a.ldo + 32 * ((int)cg * NBW + nb) + li] = finish(v, bias4[nb], a.act, slope, a.clip);
             }
         }
         if (DBG & 16) {
@@ -612,22 +641,22 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
         }
         return;
     }
-    int32_t orow[16];
+    float bias1[NBW];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)              // lane rr (< 32) holds that row's output index; all lanes active here
-        orow[reg] = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+    for (int nb = 0; nb < NBW; ++nb) bias1[nb] = a.bias ? a.bias[32 * ((int)cg * NBW + nb) + li] : 0.0f;
+    int64_t dsts[16];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int64_t o = orow[reg];
-        if (o < 0) continue;
-        const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+    for (int reg = 0; reg < 16; ++reg) {            // lane rr (< 32) holds that row's output index; all lanes active here
+        const int64_t o = __shfl(my_row, (reg & 3) + 8 * (reg >> 2) + 4 * lh);
+        dsts[reg] = o < 0 ? -1 : a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {            // no load from here on (see k_conv_mfma's epilogue)
+        const int64_t dst = dsts[reg];
         if (dst < 0) continue;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int col = 32 * ((int)cg * NBW + nb) + li;
-            const float b = a.bias ? a.bias[col] : 0.0f;
-            a.out[dst * a.ldo + col] = finish(acc[nb][reg], b, a.act, slope, a.clip);
-        }
+        for (int nb = 0; nb < NBW; ++nb)
+            a.out[dst * a.ldo + 32 * ((int)cg * NBW + nb) + li] = finish(acc[nb][reg], bias1[nb], a.act, slope, a.clip);
     }
 }
 
@@ -762,20 +791,24 @@ __global__ __launch_bounds__(256, 3) void k_conv_wave22(ConvArgs a, const float 
     }
 
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    float bias2[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bias2[nb] = a.bias ? a.bias[32 * ((int)cg * 2 + nb) + li] : 0.0f;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+        int64_t dsts[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int64_t o = __shfl(my_row, 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * lh);
-            if (o < 0) continue;
-            const int64_t dst = a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+            dsts[reg] = o < 0 ? -1 : a.out_map ? (int64_t)a.out_map[o * a.om_os + g * a.om_gs] : o * a.groups + g;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t dst = dsts[reg];
             if (dst < 0) continue;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int col = 32 * ((int)cg * 2 + nb) + li;
-                const float b = a.bias ? a.bias[col] : 0.0f;
-                a.out[dst * a.ldo + col] = finish(acc[rb][nb][reg], b, a.act, slope, a.clip);
-            }
+            for (int nb = 0; nb < 2; ++nb)
+                a.out[dst * a.ldo + 32 * ((int)cg * 2 + nb) + li] = finish(acc[rb][nb][reg], bias2[nb], a.act, slope, a.clip);
         }
     }
 }
@@ -925,7 +958,7 @@ int launch_grouped(const ConvArgs &a, const float *wp, hipStream_t s) {
     // both operands through LDS (conv_lds.hip) on maps of at least FPCC_LDS_MIN_ROWS rows (knob 10; 0 = never); same order 3
     const int64_t lds_rows = knob(kKnobLdsRows);
     if (lds_rows > 0 && a.n_out >= lds_rows) {
-        const int rc = launch_conv_lds(a, wp, knob(kKnobLdsRowBlocks), knob(kKnobWaveDbg) & 3, s);
+        const int rc = launch_conv_lds(a, wp, knob(kKnobLdsRowBlocks), knob(kKnobWaveDbg) & 63, s);
         if (rc != -1) return rc;
     }
     const int64_t fold_rows = knob(kKnobGroupedFoldRows);
@@ -1208,7 +1241,7 @@ extern "C" int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64) {
     const long long cap = buf ? n_u64 : 0;
     FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
     FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &cap, sizeof(cap)));
-    return FPCC_OK;
+    return set_lds_stamp_buffer(buf, cap);
 }
 
 extern "C" int fpcc_conv_set_tuning(int which, int value) {
@@ -1466,6 +1499,37 @@ extern "C" int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr
     hipLaunchKernelGGL(k_conv_row_keys, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), nbr, n_offsets, nbr_ks,
                        nbr_os, n, window_log2, keys_out, masks_out);
     return check_hip(hipGetLastError(), "k_conv_row_keys");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Offset-major table [n_off][n] -> row-major [n][ld] (entries n_off .. ld - 1 of a row = -1): the layout in which a convolution's
+// prologue fetches the entries of a row as pieces of one cache line (conv_common.h, table_is_row_major).
+namespace fpcc {
+namespace {
+__global__ __launch_bounds__(256) void k_transpose_table(const int32_t *__restrict__ src, int n_off, int64_t n, int32_t *__restrict__ dst, int ld) {
+    __shared__ int32_t s_t[256 * 33];
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int tid = threadIdx.x;
+    for (int k = 0; k < 32; ++k) {
+        int32_t v = -1;
+        if (k < n_off && row0 + tid < n) v = src[(int64_t)k * n + row0 + tid];          // consecutive threads, consecutive rows
+        s_t[tid * 33 + k] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < 256 * ld; e += 256) {                                            // consecutive threads, consecutive words
+        const int r = e / ld, k = e - r * ld;
+        if (row0 + r < n) dst[(row0 + r) * ld + k] = k < 32 ? s_t[r * 33 + k] : -1;
+    }
+}
+}  // namespace
+}  // namespace fpcc
+
+extern "C" int fpcc_transpose_table_i32(const int32_t *table, int n_offsets, int64_t n, int32_t *rows_out, int ld, void *stream) {
+    if (n < 0 || n_offsets < 1 || n_offsets > 32 || ld < n_offsets || ld % 4) return fail_arg("transpose_table: 1 <= n_offsets <= 32, ld >= n_offsets, ld % 4 == 0");
+    if (n == 0) return FPCC_OK;
+    if (!table || !rows_out) return fail_arg("transpose_table: null pointer");
+    hipLaunchKernelGGL(k_transpose_table, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), table, n_offsets, n, rows_out, ld);
+    return check_hip(hipGetLastError(), "k_transpose_table");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

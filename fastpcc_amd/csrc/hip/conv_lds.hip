@@ -31,23 +31,34 @@ struct LdsCfg {
     static constexpr int A_BYTES = R * 4096;                  // R row blocks x 32 rows x 128 bytes
     static constexpr int B_HALF = 4 * NBW * 1024;             // one column half: 4 groups of 8 channels x NBW column blocks x 1 KB
     static constexpr int BUF = A_BYTES + 2 * B_HALF;
-    static constexpr int LDS = 2 * BUF + 64;                  // two staging buffers + the row blocks' offset masks
+    static constexpr int LDS = 2 * BUF + 64;                  // two staging buffers + the row blocks' offset masks (+ stamps when traced)
     static constexpr int WGS = (160 * 1024) / LDS > 4 ? 4 : (160 * 1024) / LDS;          // workgroups per CU that LDS admits
     static constexpr int MIN_WAVES = WGS * WAVES / 4 > 4 ? 4 : WGS * WAVES / 4;          // per SIMD
 };
 
-// DBG (timing experiments only, results are wrong): bit 0 = every gathered row is row 0, bit 1 = every stage reads the weights of chunk 0
+// DBG (timing experiments only, results are wrong): bit 0 = every gathered row is row 0, bit 1 = every stage reads the weights of chunk 0,
+// bit 2 = no fragment reads (the MFMAs run on whatever the registers hold), bit 3 = no DMAs, bit 4 = no wait / barrier per stage;
+// bit 5 (results stay exact without the other bits) = stamps: [0] entry, [1] masks known, [2] first DMAs issued, [40] loop end, [41] folded,
+// [42] stored, [43] stages this wave computed, [44] stages of the workgroup, [45] workgroup << 8 | wave, [46] HW_ID, [47] XCC_ID
 template <int R, int NBW, int DBG>
 __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_lds(ConvArgs a, const float *__restrict__ wp, int nbt,
                                                                                unsigned n_tiles) {
     using C = LdsCfg<R, NBW>;
     constexpr int ROWS = C::ROWS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];       // ONE array: staging buffers and masks
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS + ((DBG & 32) ? C::WAVES * kStampSlots * 8 : 0)];   // ONE array
     unsigned *const s_mask = reinterpret_cast<unsigned *>(smem + 2 * C::BUF);
+    unsigned long long *const s_stamp = reinterpret_cast<unsigned long long *>(smem + C::LDS);
+#define FPCC_STAMP(i) do { if (DBG & 32) stamp_lds(&s_stamp[wv * kStampSlots + (i)]); } while (0)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = wv >> 1, c = wv & 1;                          // row block, column half of this wave
     const int li = lane & 31, lh = lane >> 5;
+    if (DBG & 32) {
+        for (int i = lane; i < kStampSlots; i += 64) s_stamp[wv * kStampSlots + i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    FPCC_STAMP(0);
+    int n_computed = 0;
     const unsigned tile = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= n_tiles) return;
     const int64_t row0 = (int64_t)tile * ROWS;
@@ -65,8 +76,26 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
     auto nbr_of = [&](int k, int32_t row) -> int32_t { return row >= 0 ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)row * a.nbr_os] : -1; };
     const int32_t my_row = out_row(32 * r + li);                // output row of lane (i, *)
     unsigned wmask = 0;                                         // offsets present in MY row block
-    for (int k = 0; k < n_off; ++k)
-        if (__ballot(nbr_of(k, my_row) >= 0) != 0ull) wmask |= 1u << k;
+    if (table_is_row_major(a)) {
+        // lane (i, h) fetches entries [16 h, 16 h + 16) of row i as four 16-byte pieces of the row's one cache line (conv_common.h)
+        const int last_piece = (n_off - 1) >> 2;
+        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + (int64_t)(my_row < 0 ? 0 : my_row) * a.nbr_os);
+        i32x4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = rowp[min(4 * lh + j, last_piece)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * lh + 4 * j + e, k0 = 4 * j + e;
+                const unsigned long long b = __ballot(k < n_off && my_row >= 0 && q[j][e] >= 0);
+                if (b & 0xffffffffull) wmask |= 1u << k0;
+                if (b >> 32) wmask |= 1u << (k0 + 16);
+            }
+    } else {
+        for (int k = 0; k < n_off; ++k)
+            if (__ballot(nbr_of(k, my_row) >= 0) != 0ull) wmask |= 1u << k;
+    }
     wmask = __builtin_amdgcn_readfirstlane(wmask);
     if (lane == 0 && c == 0) s_mask[r] = wmask;
     __syncthreads();
@@ -74,6 +103,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
 #pragma unroll
     for (int i = 0; i < R; ++i) tmask |= s_mask[i];
     tmask = __builtin_amdgcn_readfirstlane(tmask);
+    FPCC_STAMP(1);
 
     f32x16 acc[NBW], tsum[NBW];
 #pragma unroll
@@ -140,6 +170,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         const int64_t chunk_floats = (int64_t)4 * nbt * 256;
         const float *const wp_l = wp + ((int64_t)c * NBW) * 256 + lane * 4;
         auto issue = [&](int k, int cc, int buf) {
+            if (DBG & 8) return;
             unsigned char *const base = smem + buf * C::BUF;
             const bool in1 = cc < n1;                                        // wave-uniform
 #pragma unroll
@@ -172,10 +203,13 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
             load_offset(r2 ? __ffs(r2) - 1 : k);                             // the second offset's rows
         }
         issue(k, 0, 0);
+        FPCC_STAMP(2);
         for (int s = 0; s < n_stages; ++s) {
             // stage s has landed everywhere, and everyone is done with stage s - 1 (whose buffer the next DMAs overwrite)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(DBG & 16)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             int k_n = k, cc_n = cc + 1;
             if (cc_n == n_chunks) {
                 cc_n = 0;
@@ -191,6 +225,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
                 issue(k_n, cc_n, (s + 1) & 1);
             }
             if ((wmask >> k) & 1u) {                                         // wave-uniform
+                if (DBG & 32) ++n_computed;
                 if (cc == 0) {
                     const int gk = offset_group_of(k, n_off);
                     if (gk != cur_g) {
@@ -203,7 +238,16 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
                 // fragments of group g8 + 1 are requested before the MFMAs of group g8 (two register sets): hipcc otherwise reads each
                 // group right before its use and exposes the LDS latency four times per stage
                 f32x4 av[2], bv[2][NBW];
+                if (DBG & 4) {
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        av[sl] = f32x4{1.0f, 2.0f, 3.0f, 4.0f} * (float)lane;
+#pragma unroll
+                        for (int nb = 0; nb < NBW; ++nb) bv[sl][nb] = f32x4{0.5f, 0.25f, 0.125f, 1.0f} * (float)(nb + lane);
+                    }
+                }
                 auto read_group = [&](int g8, int slot) {
+                    if (DBG & 4) { asm volatile("" : "+v"(av[slot])); return; }
                     av[slot] = *reinterpret_cast<const f32x4 *>(base + a_frag + (((2 * g8 + lh) ^ a_swz) << 4));
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb)
@@ -231,11 +275,17 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         }
     }
 
+    FPCC_STAMP(40);
     if (wmask) { fold_acc(); ++cur_g; }
     for (int gz = cur_g; gz < 4; ++gz) fold_zero();
+    FPCC_STAMP(41);
 
-    // output rows of my accumulator registers: register q holds row (q & 3) + 8 (q >> 2) + 4 h of the block
+    // output rows of my accumulator registers: register q holds row (q & 3) + 8 (q >> 2) + 4 h of the block.  Slope and bias are read
+    // BEFORE the first store: a load between two stores waits (vmcnt(0)) for every store issued so far.
     const float slope = (a.act == FPCC_ACT_PRELU && a.slope) ? a.slope[0] : 0.0f;
+    float bias[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) bias[nb] = a.bias ? a.bias[32 * (c * NBW + nb) + li] : 0.0f;
     int32_t orow[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) orow[q] = __shfl(my_row, (q & 3) + 8 * (q >> 2) + 4 * lh);
@@ -244,12 +294,24 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         const int64_t o = orow[q];
         if (o < 0) continue;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int col = 32 * (c * NBW + nb) + li;
-            const float b = a.bias ? a.bias[col] : 0.0f;
-            a.out[o * a.ldo + col] = finish(tsum[nb][q], b, a.act, slope, a.clip);
-        }
+        for (int nb = 0; nb < NBW; ++nb)
+            a.out[o * a.ldo + 32 * (c * NBW + nb) + li] = finish(tsum[nb][q], bias[nb], a.act, slope, a.clip);
     }
+    if (DBG & 32) {
+        FPCC_STAMP(42);
+        if (lane == 0) {
+            s_stamp[wv * kStampSlots + 43] = (unsigned long long)n_computed;
+            s_stamp[wv * kStampSlots + 44] = (unsigned long long)n_stages;
+            s_stamp[wv * kStampSlots + 45] = ((unsigned long long)blockIdx.x << 8) | (unsigned)wv;
+            s_stamp[wv * kStampSlots + 46] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            s_stamp[wv * kStampSlots + 47] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long long w_id = (long long)blockIdx.x * C::WAVES + wv;
+        if (g_stamp_buf && (w_id + 1) * kStampSlots <= g_stamp_cap && lane < kStampSlots)
+            g_stamp_buf[w_id * kStampSlots + lane] = s_stamp[wv * kStampSlots + lane];
+    }
+#undef FPCC_STAMP
 }
 
 template <int R, int NBW>
@@ -258,14 +320,22 @@ int launch_cfg(const ConvArgs &a, const float *wp, int nbt, int dbg, hipStream_t
     const int64_t tiles = (a.n_out + ROWS - 1) / ROWS;
     if (tiles > 0x7fffffffll) return fail_arg("conv_f32: too many tiles");
     const dim3 grid((unsigned)tiles), block(128 * R);
-    if (dbg == 1) hipLaunchKernelGGL((k_conv_lds<R, NBW, 1>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles);
-    else if (dbg == 2) hipLaunchKernelGGL((k_conv_lds<R, NBW, 2>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles);
-    else if (dbg == 3) hipLaunchKernelGGL((k_conv_lds<R, NBW, 3>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles);
-    else hipLaunchKernelGGL((k_conv_lds<R, NBW, 0>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles);
+    switch (dbg) {
+#define FPCC_LDS_CASE(D) case D: hipLaunchKernelGGL((k_conv_lds<R, NBW, D>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles); break;
+        FPCC_LDS_CASE(1) FPCC_LDS_CASE(2) FPCC_LDS_CASE(3) FPCC_LDS_CASE(4) FPCC_LDS_CASE(8) FPCC_LDS_CASE(16) FPCC_LDS_CASE(24) FPCC_LDS_CASE(28) FPCC_LDS_CASE(32) FPCC_LDS_CASE(60)
+#undef FPCC_LDS_CASE
+        default: hipLaunchKernelGGL((k_conv_lds<R, NBW, 0>), grid, block, 0, s, a, wp, nbt, (unsigned)tiles);
+    }
     return check_hip(hipGetLastError(), "k_conv_lds");
 }
 
 }  // namespace
+
+int set_lds_stamp_buffer(unsigned long long *buf, long long cap) {
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &cap, sizeof(cap)));
+    return FPCC_OK;
+}
 
 int launch_conv_lds(const ConvArgs &a, const float *wp, int row_blocks, int dbg, hipStream_t s) {
     const int nbt = a.c_out / 32;

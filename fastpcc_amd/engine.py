@@ -135,7 +135,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key', 'row_order', 'mask27')
+                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -144,6 +144,7 @@ class _Map:
         self.child_row: Optional[torch.Tensor] = None     # [parent.n, 8] row of (parent, octant) in THIS map or -1
         self.generated = False                            # all 8 children of every parent row, row = 8p + octant
         self.nbr27: Optional[torch.Tensor] = None
+        self.nbr27_rows: Optional[torch.Tensor] = None    # the same table row-major [n, 32] (what the MFMA kernels' prologue reads)
         self.mask27: Optional[torch.Tensor] = None        # [n] 27-bit neighbour presence (first layer on a constant input)
         self.row_order = False                            # False: not decided; None: natural order; tensor: permutation
         self.coords: Optional[torch.Tensor] = None
@@ -304,6 +305,26 @@ class CoordinateManager:
                 else:
                     m.nbr27 = ops.nbr27_search(m.keys, m.bits)
         return m.nbr27
+
+    # FPCC_NBR_ROWS=0: the MFMA kernels read the offset-major table (A/B of the prologue; result-neutral)
+    NBR_ROWS = os.environ.get('FPCC_NBR_ROWS', '1') != '0'
+
+    def _nbr27_rows(self, m: _Map) -> Optional[torch.Tensor]:
+        """the 3x3x3 table row-major, [n, 32] int32 (entries 27 .. 31 = -1): a row's 27 entries are one 128-byte line, which the MFMA
+        kernels' prologue fetches as 16-byte pieces -- from the offset-major table it is 27 four-byte requests to 27 lines per row
+        as soon as a block's rows are not consecutive (neighbour-pattern row order).  Built once per map, shared by its layers."""
+        if not self.NBR_ROWS:
+            return None
+        if m.nbr27_rows is None:
+            m.nbr27_rows = ops.transpose_table(self._nbr27(m), 32)
+        return m.nbr27_rows
+
+    def _k3_table(self, m: _Map, mfma: bool) -> dict:
+        """neighbour-table arguments of a 3x3x3 conv_f32 call on map m"""
+        rows = self._nbr27_rows(m) if mfma else None
+        if rows is not None:
+            return dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32)
+        return dict(nbr=self._nbr27(m), n_offsets=27, nbr_ks=m.n, nbr_os=1)
 
     def _mask27(self, m: _Map) -> Optional[torch.Tensor]:
         """int32 [n]: which of the 27 neighbours of every row exist, derived from the parent level without building the row table;
@@ -778,7 +799,7 @@ class _ConvBase(nn.Module):
             elif plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
-                                   nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1, act=act.kind, slope=act.slope,
+                                   act=act.kind, slope=act.slope, **cm._k3_table(src, True),
                                    clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None, pack=True)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
@@ -790,7 +811,7 @@ class _ConvBase(nn.Module):
                 out = ops.conv_ones_k3(cm._mask27(src), w, c_out, bias=kw['bias'], act=act.kind, slope=act.slope, clip=clip)
             else:
                 mfma = ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out) != 0
-                out = ops.conv_f32(x1, w, c_out, src.n, nbr=cm._nbr27(src), n_offsets=27, nbr_ks=src.n, nbr_os=1,
+                out = ops.conv_f32(x1, w, c_out, src.n, **cm._k3_table(src, mfma and kw.get('pack', False) is True),
                                    # 16 input channels: one 64-byte gather per neighbour -- Morton locality beats block skipping
                                    row_order=cm._row_order(src) if mfma and x1.shape[1] + (0 if x2 is None else x2.shape[1]) > 16 else None, **kw)
         else:   # kernel 2, stride 2

@@ -38,6 +38,7 @@ _SIGS = {
                                 _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
     'fpcc_conv_debug_stamps': (_i32, [_vp, _i64]),
+    'fpcc_transpose_table_i32': (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
     'fpcc_numerics_version': (_i32, []),
     'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
     'fpcc_conv_pack_weights_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
@@ -400,6 +401,14 @@ def clock_probe(out2: torch.Tensor, spin_us: int = 20) -> None:
     """diagnostic (fpcc_clock_probe): enqueue a one-wave kernel that leaves (shader cycles, 100 MHz ticks) of a spin_us spin in the
     int64[2] device tensor out2"""
     _ok(lib().fpcc_clock_probe(_dev(out2, torch.int64, 'out2'), int(spin_us), _stream()))
+
+
+def transpose_table(table: torch.Tensor, ld: int = 32) -> torch.Tensor:
+    """offset-major neighbour table [n_offsets, n] -> row-major [n, ld] (pad -1): conv_f32(nbr=rows, nbr_ks=1, nbr_os=ld)"""
+    k, n = table.shape
+    out = torch.empty((n, ld), dtype=torch.int32, device=table.device)
+    _ok(lib().fpcc_transpose_table_i32(_dev(table, torch.int32, 'table', n == 0), k, n, out.data_ptr(), ld, _stream()))
+    return out
 
 
 def conv_debug_stamps(buf: Optional[torch.Tensor]) -> None:

@@ -330,6 +330,11 @@ int fpcc_gather_sum_f32(const float *y, int ldy, const int32_t *nbr, int n_offse
 /* out[i, :] = x[index[i], :] -- features re-ordered into the canonical (Morton) row order of a coordinate map, the
  * permutation ME.SparseTensor applies to its features (models/convolutional/lossy_coord_v2/model.py:147-153). */
 int fpcc_gather_rows_f32(const float *x, int c, int ld, const int32_t *index, int64_t n, float *out, int ldo, void *stream);
+/* Offset-major neighbour table [n_offsets][n] (fpcc_nbr27_from_parent) -> row-major rows_out [n][ld] (entries n_offsets .. ld - 1 of a
+ * row are -1; ld % 4 == 0).  fpcc_conv_f32 takes either layout through (nbr_ks, nbr_os) = (n, 1) / (1, ld); from the row-major one
+ * (16-byte aligned) the MFMA kernels read a row's entries as 16-byte pieces of ONE cache line instead of n_offsets 4-byte requests to
+ * n_offsets lines -- what their prologue costs once the rows of a block are not consecutive (row_order). */
+int fpcc_transpose_table_i32(const int32_t *table, int n_offsets, int64_t n, int32_t *rows_out, int ld, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Entropy-model glue that has to sit next to the features                                                         */

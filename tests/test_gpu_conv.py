@@ -623,3 +623,38 @@ def test_lds_operand_kernel_is_order_3_too(ops, scene, c1, c2, c_out, n_off, spa
     want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_PRELU, slope=0.25, clip=1.9, order=3)
     for got in (natural, ordered, plain):
         assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
+@pytest.mark.parametrize('c1,c2,c_out', [(128, 0, 128), (64, 0, 64), (128, 128, 128), (32, 0, 32)])
+def test_row_major_neighbour_table_changes_no_result(ops, scene, c1, c2, c_out):
+    """the same 3x3x3 table offset-major [27, n] and row-major [n, 32] (fpcc_transpose_table_i32; what the engine hands the MFMA kernels):
+    every kernel form -- four-wave grouped, folded, LDS operands -- in natural and pattern row order gives the oracle's bits from both"""
+    rng = np.random.default_rng(c1 + c2 + c_out + 5)
+    lvl = scene['lvl']
+    table = scene['k3'].copy()
+    n = table.shape[1]
+    table[:, 11] = -1
+    x1 = rng.normal(size=(lvl.n, c1)).astype(np.float32)
+    x2 = rng.normal(size=(lvl.n, c2)).astype(np.float32) if c2 else None
+    w = (rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32)
+    b = rng.normal(size=c_out).astype(np.float32)
+    want = sc.conv_chain(x1, table, w, b, n, x2=x2, act=sc.ACT_RELU, order=3)
+    nbr = _cuda(table)
+    rows = ops.transpose_table(nbr, 32)
+    assert rows.shape == (n, 32) and torch.equal(rows[:, :27].t().contiguous(), nbr) and bool((rows[:, 27:] == -1).all())
+    order = ops.conv_row_order(nbr, 27, n, 1, n)
+    base = dict(x2=None if x2 is None else _cuda(x2), bias=_cuda(b), act=ops.ACT_RELU, pack=True)
+    layouts = (dict(nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1), dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32))
+    forms = [((ops.KNOB_GROUPED_FOLD_ROWS, 0),), ((ops.KNOB_GROUPED_FOLD_ROWS, 1),)]
+    if c_out >= 64:
+        forms += [((ops.KNOB_LDS_ROWS, 1), (ops.KNOB_LDS_ROW_BLOCKS, 2)), ((ops.KNOB_LDS_ROWS, 1), (ops.KNOB_LDS_ROW_BLOCKS, 4))]
+    for form in forms:
+        saved = [(k, ops.conv_set_tuning(k, v)) for k, v in form]
+        try:
+            for lay in layouts:
+                for ro in (None, order):
+                    got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, row_order=ro, **lay, **base)
+                    assert (_bits(got.cpu().numpy()) == _bits(want)).all(), (form, lay['nbr_ks'], ro is not None)
+        finally:
+            for k, v in saved:
+                ops.conv_set_tuning(k, v)

@@ -27,8 +27,10 @@ f = torch.randn((n, c_in), device='cuda')
 w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
 pairs = int((nbr >= 0).sum().item())
 PACK = bool(int(os.environ.get('PACK', '1')))
+# ROWS=0: offset-major neighbour table [27, n]; default: the row-major copy the engine hands the MFMA kernels
+TABLE = cm._k3_table(m, os.environ.get('ROWS', '1') != '0')
 def run(row_order):
-    return ops.conv_f32(f, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, row_order=row_order, pack=PACK)
+    return ops.conv_f32(f, w, c_out, n, row_order=row_order, pack=PACK, **TABLE)
 def lpt(order, group):
     present = (nbr >= 0)[:, order.long()]
     pad = (-n) % group
