@@ -373,7 +373,11 @@ class GeoLosslessEntropyModel(nn.Module):
                     continue
                 prob_t = torch.empty(prob_d.shape, dtype=prob_d.dtype, pin_memory=True)
                 prob_t.copy_(prob_d, non_blocking=True)
-                torch.cuda.current_stream().synchronize()                # the level's dependency: D2H of its probabilities
+                # the level's dependency: D2H of its probabilities.  An event, not a stream synchronise: with several frames in flight
+                # on the stream (fastpcc_amd/serving.py) this frame waits for its copy, not for what other frames queued behind it
+                copied = torch.cuda.Event()
+                copied.record()
+                copied.synchronize()
                 tb = time.perf_counter()
                 bits_t = torch.empty(prob_t.numel(), dtype=torch.uint8, pin_memory=True)
                 stream = np.frombuffer(coord_bytes_list.pop(0), dtype=np.uint8)

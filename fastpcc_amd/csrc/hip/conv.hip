@@ -30,6 +30,7 @@
 // instruction costs ~30 SIMD cycles of issue that more waves do not hide, the B stream (256 B per MFMA from L2) caps the wave
 // kernel at ~100 TFLOP/s on the 272 K-row maps at 2.4 GHz, and inside a codec step the power management grants ~2.16 GHz.
 #include "conv_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace fpcc {
@@ -354,13 +355,22 @@ struct WaveCfg {
 // the fourfold parallelism of OG == 4 buys nothing (272 K rows: 100 against 95 TFLOP/s, profiles/r03/grouped_fold.md).
 // ASTAGE (experiment, same bits): the A fragments of the NEXT stage are requested all at once at the top of a stage into a second
 // register set (the four 32-byte pieces of a gathered 128-byte line are then touched back to back instead of a quarter stage apart).
-template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false, bool ASTAGE = false>
-__global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
-                                                                                         int nbt, unsigned n_units) {
+// PERSIST (round 4; needs a row-major table, conv_common.h): a wave (OG == 1) / workgroup (OG == 4) walks units first, first + stride, ...
+// of the launch order instead of one, and requests the NEXT unit's table rows and output rows while it computes the current one: on a
+// loaded chip the prologue's dependent loads (row order -> table rows -> gather addresses) took a wave 20-70 K cycles and its stores
+// 20-40 K, a fifth of its life in which it feeds no MFMA (profiles/r04/prologue_epilogue.md).  Same chains, same bits.
+// WPW (OG == 1 only): waves per workgroup.  The waves of a workgroup share nothing but the launch, and a workgroup's slot on the CU is
+// held until its SLOWEST wave has finished: with one wave per workgroup a finished wave's slot is refilled at once.
+template <int NBW, int CH, int SB, int DBG = 0, int OG = 1, bool FOLD = false, bool ASTAGE = false, bool PERSIST = false, int WPW = 4>
+__global__ __launch_bounds__(64 * WPW, ((FOLD || PERSIST) ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void k_conv_wave(ConvArgs a, const float *__restrict__ wp,
+                                                                                                           int nbt, unsigned n_units,
+                                                                                                           unsigned *unit_counter = nullptr) {
     constexpr int G8 = CH / 8;
-    __shared__ int32_t s_nbr_all[4][32 * 32];      // [offset (padded to 32)][row] per wave
+    static_assert(OG == 1 || WPW == 4, "the four waves of a grouped workgroup are its four offset groups");
+    __shared__ int32_t s_nbr_all[WPW][32 * 32];    // [offset (padded to 32)][row] per wave
     __shared__ float s_part[OG == 4 ? 4 * 16 * NBW * 64 : 1];
     __shared__ unsigned long long s_stamp[(DBG & 16) ? 4 * kStampSlots : 1];
+    __shared__ unsigned s_next[(PERSIST && OG == 4) ? 4 : 1];   // OG == 4: {unit, pass tag} x 2, written by wave 0 for its workgroup
 #define FPCC_STAMP(i) do { if (DBG & 16) stamp_lds(&s_stamp[wv * kStampSlots + (i)]); } while (0)
 
     // the wave index is wave-uniform, but hipcc only knows that when told: everything derived from it (the wave's offset group, its
@@ -376,29 +386,75 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
     const unsigned n_cg = (unsigned)(nbt / NBW);
     // unit = (32-row block, column group); the column groups of one row block are adjacent units (same workgroup: their A
     // rows hit the CU's vector L1).  Natural order: contiguous unit ranges per XCD; with a row order: dispatch order.
-    const unsigned blk = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned unit = OG == 4 ? blk : blk * 4u + (unsigned)wv;
+    const unsigned blk = (PERSIST || a.row_order) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned slot = OG == 4 ? blk : blk * (unsigned)WPW + (unsigned)wv;
+    const unsigned n_slots = OG == 4 ? gridDim.x : gridDim.x * (unsigned)WPW;
+    // PERSIST: the first unit of a slot is its own index; every further one is drawn from a counter (*unit_counter starts at the number
+    // of slots) WHILE the current unit is computed -- the units come heaviest first (fpcc_conv_tile_keys) and take different times, so
+    // a fixed stride or a serpentine would leave the slots up to 10 % apart at the end (measured: slower than one unit per workgroup)
+    unsigned pass = 0, unit_next = 0xffffffffu;
+    unsigned unit = slot;
     if (unit >= n_units) return;                    // OG == 1: no barrier below, a wave may leave on its own (OG == 4: whole workgroups)
-    const unsigned rb_ = unit / n_cg, cg = unit - rb_ * n_cg;
+    if (PERSIST && OG == 4) {
+        if (threadIdx.x < 4) s_next[threadIdx.x] = 0xffffffffu;
+        __syncthreads();
+    }
     const int g = blockIdx.y;
-    const int64_t row0 = (int64_t)rb_ * 32;
     const int c_in = a.c1 + a.c2;
     const int n_chunks = c_in / CH;
     int32_t *s_nbr = s_nbr_all[wv];
-
-    int32_t my_row = -1;
-    if (row0 + li < a.n_out) my_row = a.row_order ? a.row_order[row0 + li] : (int32_t)(row0 + li);
-    // neighbour rows of my 32 output rows -> this wave's LDS slice; lane half h takes the offsets of parity h
-    unsigned wmask = 0;
     const int k_lo = OG == 4 ? offset_group_begin(wv, a.n_off) : 0, k_hi = OG == 4 ? offset_group_begin(wv + 1, a.n_off) : a.n_off;
-    if (table_is_row_major(a)) {
-        // row-major table: lane (i, h) fetches entries [16 h, 16 h + 16) of row i as four 16-byte pieces of the row's line (pieces past
-        // the row's last one re-read it; entries past n_off are discarded) -- all requests first, then the LDS writes and the ballots
+    const bool row_major = table_is_row_major(a);   // always so when PERSIST
+    // Row-major table: lane (i, h) fetches entries [16 h, 16 h + 16) of its row as four 16-byte pieces of the row's line (pieces past the
+    // row's last one re-read it; entries past n_off are discarded) and the output row of position i; no load depends on another.
+    auto fetch_unit = [&](unsigned u, i32x4 (&q)[4], int32_t &orow) {
+        const int64_t p = (int64_t)(u / n_cg) * 32 + li;
+        const int64_t pc = p < a.n_out ? p : a.n_out - 1;                        // past the end: re-read the last row, marked absent below
+        const int32_t o = a.row_order ? a.row_order[pc] : (int32_t)pc;
+        orow = p < a.n_out ? o : -1;
+        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + (a.row_order ? pc : (int64_t)o) * a.nbr_os);   // by position beside a row order
         const int last_piece = (a.n_off - 1) >> 2;
-        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + (int64_t)(my_row < 0 ? 0 : my_row) * a.nbr_os);
-        i32x4 q[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) q[j] = rowp[min(4 * lh + j, last_piece)];
+    };
+    i32x4 q_next[4];
+    int32_t row_next = -1;
+    if (PERSIST) fetch_unit(unit, q_next, row_next);
+
+  for (;;) {                                        // one pass unless PERSIST
+    const unsigned rb_ = unit / n_cg, cg = unit - rb_ * n_cg;
+    const int64_t row0 = (int64_t)rb_ * 32;
+
+    int32_t my_row = -1;
+    // neighbour rows of my 32 output rows -> this wave's LDS slice
+    unsigned wmask = 0;
+    if (row_major) {
+        i32x4 q[4];
+        if (PERSIST) {                                                       // requested after the previous unit's last stage
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = q_next[j];
+            my_row = row_next;
+            // draw the next unit now: the answer is back long before this unit's last stage
+            if (OG == 4) {
+                if (wv == 0) {
+                    unsigned n = 0;
+                    if (lane == 0) n = __hip_atomic_fetch_add(unit_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    n = __builtin_amdgcn_readfirstlane(n);
+                    if (lane == 0) {
+                        volatile unsigned *sn = s_next;
+                        sn[2 * (pass & 1u)] = n;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        sn[2 * (pass & 1u) + 1] = pass;                      // the tag after the value
+                    }
+                }
+            } else {
+                unsigned n = 0;
+                if (lane == 0) n = __hip_atomic_fetch_add(unit_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unit_next = __builtin_amdgcn_readfirstlane(n);
+            }
+        } else {
+            fetch_unit(unit, q, my_row);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -413,7 +469,8 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
             }
         if (OG == 4) wmask &= (k_hi >= 32 ? ~0u : (1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
     } else {
-        for (int k0 = k_lo; k0 < k_hi; k0 += 2) {
+        if (row0 + li < a.n_out) my_row = a.row_order ? a.row_order[row0 + li] : (int32_t)(row0 + li);
+        for (int k0 = k_lo; k0 < k_hi; k0 += 2) {                            // lane half h takes the offsets of parity h
             const int k = k0 + lh;
             int32_t v = -1;
             if (k < k_hi && my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
@@ -585,6 +642,17 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
     }
 
     FPCC_STAMP(40);
+    if (PERSIST) {
+        // the next unit's table rows and output rows travel while this unit's sums are finished and stored (requested here and not at the
+        // unit's start: sixteen more registers through the stage loop would spill)
+        if (OG == 4) {                                                       // wave 0 drew it at this unit's start
+            volatile unsigned *sn = s_next;
+            while (sn[2 * (pass & 1u) + 1] != pass) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            unit_next = __builtin_amdgcn_readfirstlane(sn[2 * (pass & 1u)]);
+        }
+        fetch_unit(unit_next < n_units ? unit_next : unit, q_next, row_next);
+    }
     if (FOLD) {
         if (wmask) { fold_acc(); ++cur_g; }
         for (int gz = cur_g; gz < 4; ++gz) fold_zero();
@@ -639,7 +707,12 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
             if (g_stamp_buf && (w_id + 1) * kStampSlots <= g_stamp_cap && lane < kStampSlots)
                 g_stamp_buf[w_id * kStampSlots + lane] = s_stamp[wv * kStampSlots + lane];
         }
-        return;
+        if (!PERSIST) return;
+        unit = unit_next;
+        ++pass;
+        if (unit >= n_units) return;                // the same decision in all four waves
+        __syncthreads();                            // the partial sums are read: the next unit may overwrite them
+        continue;
     }
     float bias1[NBW];
 #pragma unroll
@@ -658,6 +731,11 @@ __global__ __launch_bounds__(256, (FOLD ? 3 : WaveCfg<NBW, CH>::MIN_WAVES)) void
         for (int nb = 0; nb < NBW; ++nb)
             a.out[dst * a.ldo + 32 * ((int)cg * NBW + nb) + li] = finish(acc[nb][reg], bias1[nb], a.act, slope, a.clip);
     }
+    if (!PERSIST) return;
+    unit = unit_next;
+    ++pass;
+    if (unit >= n_units) return;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -863,14 +941,15 @@ int launch_mfma_cfg(ConvArgs a, hipStream_t s) {
 // kKnobGroupedOff (experiments only: 1 = multi-offset layers in order 1 on the plain wave kernel instead of grouped / order 3),
 // which is therefore refused unless the process runs with FPCC_EXPERIMENT=1 and has no environment variable.
 enum { kKnobWaveOn = 0, kKnobWaveNbw = 1, kKnobWaveSb = 2, kKnobWaveDbg = 3, kKnobGroupedFoldRows = 4, kKnobMfmaCfg = 5, kKnobPointwiseRows = 6,
-       kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobLdsRows = 10, kKnobLdsRowBlocks = 11, kKnobCount = 12 };
-int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+       kKnobGroupedOff = 7, kKnobGroupedNbw = 8, kKnobWave22Rows = 9, kKnobLdsRows = 10, kKnobLdsRowBlocks = 11, kKnobPersist = 12, kKnobCount = 13 };
+int g_knob[kKnobCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int knob(int k) {
     if (g_knob[k] < 0) {
         static const char *names[kKnobCount] = {"FPCC_CONV_WAVE", "FPCC_WAVE_NBW", "FPCC_WAVE_SB", "FPCC_WAVE_DBG", "FPCC_GROUPED_FOLD_ROWS",
                                                 "FPCC_MFMA_TILE", "FPCC_POINTWISE_MIN_ROWS", "", "FPCC_GROUPED_NBW",
-                                                "FPCC_WAVE22_MIN_ROWS", "FPCC_LDS_MIN_ROWS", "FPCC_LDS_ROW_BLOCKS"};
-        static const int defaults[kKnobCount] = {1, 0, 1, 0, 100 * 1024, 0, 32 * 1024, 0, 0, 0, 0, 2};
+                                                "FPCC_WAVE22_MIN_ROWS", "FPCC_LDS_MIN_ROWS", "FPCC_LDS_ROW_BLOCKS",
+                                                "FPCC_CONV_PERSIST"};
+        static const int defaults[kKnobCount] = {1, 0, 1, 0, 100 * 1024, 0, 32 * 1024, 0, 0, 0, 0, 2, 0};
         const char *e = k == kKnobGroupedOff ? nullptr : getenv(names[k]);
         g_knob[k] = e ? atoi(e) : defaults[k];
     }
@@ -919,6 +998,44 @@ int launch_wave_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) 
     return check_hip(hipGetLastError(), "k_conv_wave");
 }
 
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+// Persistent form (knob 12 / FPCC_CONV_PERSIST = workgroups per CU, 0 = off): when a launch has more workgroups than the chip holds
+// at once and the table is row-major, that many workgroups walk the units with a stride and prefetch the next unit's table rows.
+// Unit counters of the persistent launches: a ring of words in device memory; a launch takes the next one, sets it to its number of
+// slots on its stream (a 4-byte fill ahead of the kernel) and its slots draw their further units from it.
+constexpr int kUnitCounters = 256;
+__device__ unsigned g_unit_counters[kUnitCounters];
+unsigned *next_unit_counter(unsigned start, hipStream_t s, int *rc) {
+    static std::atomic<unsigned> seq{0};           // launches come from several host threads
+    static unsigned *base = nullptr;
+    if (!base && hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_unit_counters)) != hipSuccess) {
+        *rc = check_hip(hipGetLastError(), "unit counters");
+        return nullptr;
+    }
+    unsigned *c = base + (seq++ % kUnitCounters);
+    *rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), (int)start, 1, s), "unit counter fill");
+    return c;
+}
+
+inline int64_t persist_slots() {                 // knob values above 16 are an absolute number of workgroups (tests)
+    const int v = knob(kKnobPersist);
+    return v > 16 ? v : (int64_t)v * cu_count();
+}
+inline bool persist_ok(const ConvArgs &a) {
+    return knob(kKnobPersist) > 0 && a.nbr && a.nbr_ks == 1 && (a.nbr_os & 3) == 0 && a.nbr_os >= ((a.n_off + 3) & ~3) &&
+           (reinterpret_cast<uintptr_t>(a.nbr) & 15) == 0 && a.groups == 1;
+}
+
 // Grouped evaluation (summation order 3): one workgroup per (32-row block, column group), its four waves = the four offset groups.
 template <int NBW>
 int launch_grouped_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
@@ -926,6 +1043,15 @@ int launch_grouped_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t 
     const int64_t units = row_blocks * (nbt / NBW);
     if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
     const int dbg = knob(kKnobWaveDbg);
+    const int64_t slots = persist_slots();
+    if (dbg == 0 && persist_ok(a) && units > slots) {
+        int rc = FPCC_OK;
+        unsigned *counter = next_unit_counter((unsigned)slots, s, &rc);
+        if (rc != FPCC_OK) return rc;
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 4, false, false, true>), dim3((unsigned)slots, 1), dim3(256), 0, s, a, wp, nbt, (unsigned)units,
+                           counter);
+        return check_hip(hipGetLastError(), "k_conv_wave(grouped, persistent)");
+    }
     if (dbg == 16)                      // stage stamps (fpcc_conv_debug_stamps)
         hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 16, 4>), dim3((unsigned)units, a.groups), dim3(256), 0, s, a, wp, nbt, (unsigned)units);
     else if (NBW == 1 && dbg == 17)     // + no gather traffic / weights from one chunk / both (results wrong)
@@ -944,6 +1070,20 @@ template <int NBW>
 int launch_folded_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) {
     const int64_t units = ((a.n_out + 31) / 32) * (nbt / NBW);
     if (units > 0x7fffffffll) return fail_arg("conv_f32: too many work units");
+    const int64_t slots = persist_slots();
+    if (knob(kKnobWaveDbg) == 0 && persist_ok(a) && (units + 3) / 4 > slots) {
+        int rc = FPCC_OK;
+        unsigned *counter = next_unit_counter((unsigned)(4 * slots), s, &rc);
+        if (rc != FPCC_OK) return rc;
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 1, true, false, true>), dim3((unsigned)slots, 1), dim3(256), 0, s, a, wp, nbt, (unsigned)units,
+                           counter);
+        return check_hip(hipGetLastError(), "k_conv_wave(folded, persistent)");
+    }
+    if (knob(kKnobWaveDbg) == 64) {                  // experiment: one wave per workgroup
+        hipLaunchKernelGGL((k_conv_wave<NBW, 32, 0x6, 0, 1, true, false, false, 1>), dim3((unsigned)units, a.groups), dim3(64), 0, s, a, wp, nbt,
+                           (unsigned)units);
+        return check_hip(hipGetLastError(), "k_conv_wave(folded, one wave per workgroup)");
+    }
     if (NBW == 2 && knob(kKnobWaveDbg) == 32)        // experiment: A fragments a whole stage at a time
         hipLaunchKernelGGL((k_conv_wave<2, 32, 0x6, 0, 1, true, true>), dim3((unsigned)((units + 3) / 4), a.groups), dim3(256), 0, s, a, wp, nbt,
                            (unsigned)units);

@@ -42,6 +42,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // transposed 3x3x3 table [n][32] of fpcc_transpose_table_i32) lets a lane fetch its row's entries as 16-byte pieces of ONE cache line.
 // The offset-major table [27][n] costs 27 requests of 4 bytes per row, each to another line as soon as the rows of a block are not
 // consecutive (neighbour-pattern row order) -- on a loaded chip that prologue took a wave ~70 K cycles (profiles/r04/prologue_epilogue.md).
+// Together with a row order the row-major table is indexed by TILE POSITION: its row p holds the neighbours of output row row_order[p]
+// (the caller gathers the table's rows once per coordinate map), so that the entries of a block of consecutive positions are
+// consecutive in memory and no load of the prologue depends on another.
 __device__ __forceinline__ bool table_is_row_major(const ConvArgs &a) {
     return a.nbr && a.nbr_ks == 1 && (a.nbr_os & 3) == 0 && a.nbr_os >= ((a.n_off + 3) & ~3) && (reinterpret_cast<uintptr_t>(a.nbr) & 15) == 0;
 }
@@ -59,6 +62,11 @@ static __device__ unsigned long long *g_stamp_buf = nullptr;      // one copy pe
 static __device__ long long g_stamp_cap = 0;
 __device__ __forceinline__ void stamp_lds(unsigned long long *slot) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned addr = (unsigned)(uintptr_t)slot;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(t) : "memory");
+}
+__device__ __forceinline__ void stamp_lds_realtime(unsigned long long *slot) {      // the constant 100 MHz counter: clock = d(memtime) / d(realtime)
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
     const unsigned addr = (unsigned)(uintptr_t)slot;
     asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(t) : "memory");
 }

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         __builtin_amdgcn_wave_barrier();
     }
     FPCC_STAMP(0);
+    if (DBG & 32) stamp_lds_realtime(&s_stamp[wv * kStampSlots + 38]);
     int n_computed = 0;
     const unsigned tile = a.row_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= n_tiles) return;
@@ -73,13 +74,18 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         if (p >= a.n_out) return -1;
         return a.row_order ? a.row_order[p] : (int32_t)p;
     };
-    auto nbr_of = [&](int k, int32_t row) -> int32_t { return row >= 0 ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)row * a.nbr_os] : -1; };
+    const bool by_pos = table_is_row_major(a) && a.row_order;  // row-major table beside a row order: indexed by tile position
+    auto nbr_of = [&](int k, int32_t row, int pos) -> int32_t {
+        if (row < 0) return -1;
+        return a.nbr[(int64_t)k * a.nbr_ks + (by_pos ? row0 + pos : (int64_t)row) * a.nbr_os];
+    };
     const int32_t my_row = out_row(32 * r + li);                // output row of lane (i, *)
     unsigned wmask = 0;                                         // offsets present in MY row block
     if (table_is_row_major(a)) {
         // lane (i, h) fetches entries [16 h, 16 h + 16) of row i as four 16-byte pieces of the row's one cache line (conv_common.h)
         const int last_piece = (n_off - 1) >> 2;
-        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + (int64_t)(my_row < 0 ? 0 : my_row) * a.nbr_os);
+        const int64_t trow = my_row < 0 ? 0 : by_pos ? row0 + 32 * r + li : (int64_t)my_row;
+        const i32x4 *rowp = reinterpret_cast<const i32x4 *>(a.nbr + trow * a.nbr_os);
         i32x4 q[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) q[j] = rowp[min(4 * lh + j, last_piece)];
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
             }
     } else {
         for (int k = 0; k < n_off; ++k)
-            if (__ballot(nbr_of(k, my_row) >= 0) != 0ull) wmask |= 1u << k;
+            if (__ballot(nbr_of(k, my_row, 32 * r + li) >= 0) != 0ull) wmask |= 1u << k;
     }
     wmask = __builtin_amdgcn_readfirstlane(wmask);
     if (lane == 0 && c == 0) s_mask[r] = wmask;
@@ -142,19 +148,20 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
         const int64_t ld1 = a.ld1, ld2 = a.ld2;
         const float *a1[2], *a2[2];
         int step[2];
-        int ppiece[2];
+        int ppiece[2], gpos[2];
         int32_t grow[2];                                                     // the output rows whose neighbours this lane gathers
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int prow = 8 * (2 * c + j) + (lane >> 3);
             ppiece[j] = 4 * ((lane & 7) ^ ((prow >> 1) & 7));                // in floats
-            grow[j] = out_row(32 * r + prow);
+            gpos[j] = 32 * r + prow;
+            grow[j] = out_row(gpos[j]);
         }
         const float *const x2 = a.x2 ? a.x2 : zero;
         int32_t idx_n[2];                                                    // neighbour rows for the NEXT offset, requested one offset ahead
         auto load_offset = [&](int k) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) idx_n[j] = nbr_of(k, grow[j]);
+            for (int j = 0; j < 2; ++j) idx_n[j] = nbr_of(k, grow[j], gpos[j]);
         };
         auto set_offset = [&]() {                                            // idx_n -> gather addresses of the current offset
 #pragma unroll
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(128 * R, (LdsCfg<R, NBW>::MIN_WAVES)) void k_conv_l
     }
     if (DBG & 32) {
         FPCC_STAMP(42);
+        stamp_lds_realtime(&s_stamp[wv * kStampSlots + 39]);
         if (lane == 0) {
             s_stamp[wv * kStampSlots + 43] = (unsigned long long)n_computed;
             s_stamp[wv * kStampSlots + 44] = (unsigned long long)n_stages;

@@ -57,7 +57,10 @@ class SparseTensorOperationMode(Enum):
     SHARE_COORDINATE_MANAGER = 1
 
 
-_global_cm: Optional['CoordinateManager'] = None
+# The "global" coordinate manager is global PER THREAD: a serving process keeps several frames in flight, each driven by its own
+# thread with its own model context (fastpcc_amd/serving.py); the single-threaded use the reference knows is unchanged.
+import threading as _threading
+_tls = _threading.local()
 _operation_mode = SparseTensorOperationMode.SEPARATE_COORDINATE_MANAGER
 
 
@@ -67,22 +70,21 @@ def set_sparse_tensor_operation_mode(mode: SparseTensorOperationMode):
 
 
 def set_global_coordinate_manager(cm: 'CoordinateManager'):
-    global _global_cm
-    _global_cm = cm
+    _tls.cm = cm
 
 
 def clear_global_coordinate_manager():
-    """Drops the global manager.  Its maps are released by reference counting right here (the links that would form reference
-    cycles are cut): left to Python's cyclic collector, the previous frame's tables -- gigabytes on a 2 M-voxel frame -- stay
+    """Drops the (calling thread's) global manager.  Its maps are released by reference counting right here (the links that would form
+    reference cycles are cut): left to Python's cyclic collector, the previous frame's tables -- gigabytes on a 2 M-voxel frame -- stay
     allocated while the next frame is coded, the caching allocator has to grow (a hipMalloc costs 10-25 ms) and its reserve creeps up."""
-    global _global_cm
-    if _global_cm is not None:
-        _global_cm._break_cycles()
-    _global_cm = None
+    cm = getattr(_tls, 'cm', None)
+    if cm is not None:
+        cm._break_cycles()
+    _tls.cm = None
 
 
 def global_coordinate_manager() -> Optional['CoordinateManager']:
-    return _global_cm
+    return getattr(_tls, 'cm', None)
 
 
 def _as_stride(s) -> Tuple[int, int, int]:
@@ -135,7 +137,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows')
+                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows', 'nbr27_pos')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -145,6 +147,7 @@ class _Map:
         self.generated = False                            # all 8 children of every parent row, row = 8p + octant
         self.nbr27: Optional[torch.Tensor] = None
         self.nbr27_rows: Optional[torch.Tensor] = None    # the same table row-major [n, 32] (what the MFMA kernels' prologue reads)
+        self.nbr27_pos: Optional[torch.Tensor] = None     # ... with its rows in row_order: row p = the neighbours of output row row_order[p]
         self.mask27: Optional[torch.Tensor] = None        # [n] 27-bit neighbour presence (first layer on a constant input)
         self.row_order = False                            # False: not decided; None: natural order; tensor: permutation
         self.coords: Optional[torch.Tensor] = None
@@ -319,12 +322,18 @@ class CoordinateManager:
             m.nbr27_rows = ops.transpose_table(self._nbr27(m), 32)
         return m.nbr27_rows
 
-    def _k3_table(self, m: _Map, mfma: bool) -> dict:
-        """neighbour-table arguments of a 3x3x3 conv_f32 call on map m"""
+    def _k3_table(self, m: _Map, mfma: bool, row_order: Optional[torch.Tensor] = None) -> dict:
+        """neighbour-table arguments of a 3x3x3 conv_f32 call on map m (beside `row_order`: the row-major table in position order)"""
         rows = self._nbr27_rows(m) if mfma else None
-        if rows is not None:
-            return dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32)
-        return dict(nbr=self._nbr27(m), n_offsets=27, nbr_ks=m.n, nbr_os=1)
+        if rows is None:
+            return dict(nbr=self._nbr27(m), n_offsets=27, nbr_ks=m.n, nbr_os=1)
+        if row_order is not None:
+            if row_order is not m.row_order:
+                raise ValueError('a foreign row order')
+            if m.nbr27_pos is None:
+                m.nbr27_pos = rows.index_select(0, row_order.long())          # 128-byte rows: one gather per map
+            rows = m.nbr27_pos
+        return dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32)
 
     def _mask27(self, m: _Map) -> Optional[torch.Tensor]:
         """int32 [n]: which of the 27 neighbours of every row exist, derived from the parent level without building the row table;
@@ -798,9 +807,10 @@ class _ConvBase(nn.Module):
                                      slope=act.slope, clip=clip)
             elif plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
+                ro = cm._row_order(src) if plan[0] + plan[1] > 16 else None
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
-                                   act=act.kind, slope=act.slope, **cm._k3_table(src, True),
-                                   clip=clip, row_order=cm._row_order(src) if plan[0] + plan[1] > 16 else None, pack=True)[:, :c_out]
+                                   act=act.kind, slope=act.slope, **cm._k3_table(src, True, ro),
+                                   clip=clip, row_order=ro, pack=True)[:, :c_out]
                 if c_out < 8:
                     out = out.contiguous()
             elif x2 is None and x1.shape[1] == 1 and getattr(x, '_fpcc_all_ones', False) and 4 <= c_out <= 32 and c_out % 4 == 0 \
@@ -811,9 +821,9 @@ class _ConvBase(nn.Module):
                 out = ops.conv_ones_k3(cm._mask27(src), w, c_out, bias=kw['bias'], act=act.kind, slope=act.slope, clip=clip)
             else:
                 mfma = ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out) != 0
-                out = ops.conv_f32(x1, w, c_out, src.n, **cm._k3_table(src, mfma and kw.get('pack', False) is True),
-                                   # 16 input channels: one 64-byte gather per neighbour -- Morton locality beats block skipping
-                                   row_order=cm._row_order(src) if mfma and x1.shape[1] + (0 if x2 is None else x2.shape[1]) > 16 else None, **kw)
+                # 16 input channels: one 64-byte gather per neighbour -- Morton locality beats block skipping
+                ro = cm._row_order(src) if mfma and x1.shape[1] + (0 if x2 is None else x2.shape[1]) > 16 else None
+                out = ops.conv_f32(x1, w, c_out, src.n, **cm._k3_table(src, mfma and kw.get('pack', False) is True, ro), row_order=ro, **kw)
         else:   # kernel 2, stride 2
             dst = cm._ensure_parent(src)
             if src.generated:

@@ -130,18 +130,40 @@ def no_gc_pause(fn):
     frame is constant (measured: one 0.7-ms convolution of the cfg#2 step shows as 1.7 ms in every other run).  The coordinate
     manager's tables are freed by reference counting (engine.clear_global_coordinate_manager cuts its cycles), so nothing here
     depends on the collector."""
-    import gc
-
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
-        was = gc.isenabled()
-        gc.disable()
+        _gc_hold()
         try:
             return fn(*args, **kwargs)
         finally:
-            if was:
-                gc.enable()
+            _gc_release()
     return wrapped
+
+
+# nesting count over all threads: with several frames in flight (fastpcc_amd/serving.py) the collector comes back on only when no
+# frame is being coded
+_gc_lock = __import__('threading').Lock()
+_gc_depth = 0
+_gc_was_enabled = False
+
+
+def _gc_hold():
+    import gc
+    global _gc_depth, _gc_was_enabled
+    with _gc_lock:
+        if _gc_depth == 0:
+            _gc_was_enabled = gc.isenabled()
+            gc.disable()
+        _gc_depth += 1
+
+
+def _gc_release():
+    import gc
+    global _gc_depth
+    with _gc_lock:
+        _gc_depth -= 1
+        if _gc_depth == 0 and _gc_was_enabled:
+            gc.enable()
 
 
 def _ok(code: int) -> int:
@@ -389,6 +411,7 @@ def packed_weights(w: torch.Tensor, c1: int, c2: int, c_out: int, n_offsets: int
 KNOB_WAVE_ON, KNOB_WAVE_NBW, KNOB_WAVE_SB, KNOB_WAVE_DBG, KNOB_MFMA_TILE, KNOB_POINTWISE_ROWS = 0, 1, 2, 3, 5, 6
 KNOB_GROUPED_FOLD_ROWS = 4       # rows from which grouped (order 3) layers run folded on one wave per unit; 0 = never
 KNOB_GROUPED_OFF, KNOB_GROUPED_NBW, KNOB_WAVE22_ROWS = 7, 8, 9      # 7: experiments only (FPCC_EXPERIMENT=1), changes the summation order
+KNOB_PERSIST = 12     # workgroups per CU of the persistent grouped / folded kernels (0 = off)
 KNOB_LDS_ROWS, KNOB_LDS_ROW_BLOCKS = 10, 11   # rows from which order-3 layers take both operands through LDS (0 = never); row blocks per workgroup (2 | 3 | 4)
 
 
@@ -430,6 +453,7 @@ def conv_set_tuning(which: int, value: int) -> int:
 # When set to a list, every conv_f32 launch appends (start_event, end_event, info) recorded on the launch stream; used by
 # bench.py to time the dominant kernel inside the timed region (events only, no synchronisation).
 CONV_TRACE = None
+TRACE_LOCK = __import__('threading').RLock()   # start event, launch, end event of a traced launch stay together when several threads enqueue
 CLOCK_HOOK = None        # bench.py: callable(ev0, n_out, n_offsets) run right after a traced launch's start event (fpcc_clock_probe beside it)
 _EVENT_POOL: list = []
 
@@ -487,13 +511,15 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
             _dev(row_order, torch.int32, 'row_order', True),
             None if ws is None else ws.data_ptr(), ws_bytes, _stream())
     trace = CONV_TRACE
-    if trace is not None:
+    if trace is None:
+        _ok(fn(*call))
+        return out
+    with TRACE_LOCK:
         ev0 = _trace_event()
         ev0.record()
         if CLOCK_HOOK is not None:
             CLOCK_HOOK(ev0, n_out, n_offsets)
-    _ok(fn(*call))
-    if trace is not None:
+        _ok(fn(*call))
         ev1 = _trace_event()
         ev1.record()
         trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
@@ -530,11 +556,13 @@ def pointwise_head(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor]
             _dev(b2, torch.float32, 'b2', True), int(act2), _dev(slope2, torch.float32, 'slope2', True),
             float(clip), out.data_ptr(), n, _stream())
     trace = CONV_TRACE
-    if trace is not None:
+    if trace is None:
+        _ok(fn(*call))
+        return out
+    with TRACE_LOCK:
         ev0 = _trace_event()
         ev0.record()
-    _ok(fn(*call))
-    if trace is not None:
+        _ok(fn(*call))
         ev1 = _trace_event()
         ev1.record()
         trace.append((ev0, ev1, {'mfma': False, 'c_in': c0, 'c_out': 1, 'n_out': n, 'groups': 1, 'n_offsets': 1, 'nbr': None,
@@ -600,11 +628,13 @@ def mlp_chain(x: torch.Tensor, layers, y: Optional[torch.Tensor] = None, cat_lay
         raise ValueError('output shape mismatch')
     fn, ref, stream = lib().fpcc_mlp_chain_f32, C.byref(d), _stream()
     trace = CONV_TRACE
-    if trace is not None:
+    if trace is None:
+        _ok(fn(ref, stream))
+        return out
+    with TRACE_LOCK:
         ev0 = _trace_event()
         ev0.record()
-    _ok(fn(ref, stream))
-    if trace is not None:
+        _ok(fn(ref, stream))
         ev1 = _trace_event()
         ev1.record()
         trace.append((ev0, ev1, {'mfma': True, 'chain': True, 'c_in': cx, 'c_out': c_in, 'n_out': n, 'groups': 1, 'n_offsets': 1,

@@ -191,6 +191,10 @@ int64_t fpcc_conv_packed_floats(int c1, int c2, int c_out, int n_offsets, int gr
  *  10  rows from which order-3 layers with 64 or 128 output channels take BOTH MFMA operands through LDS (k_conv_lds, conv_lds.hip:
  *      LDS-DMA staging, 2-4 row blocks of a workgroup in lockstep; FPCC_LDS_MIN_ROWS; 0 = never).  Same order 3, same bits.
  *  11  row blocks per workgroup of that kernel: 2 | 3 | 4 (FPCC_LDS_ROW_BLOCKS, default 2)
+ *  12  persistent form of the grouped / folded kernels: workgroups per CU that walk the units of a launch with a stride and fetch the
+ *      next unit's table rows while computing (row-major tables only; FPCC_CONV_PERSIST; default 0 = one unit per workgroup / wave -- measured no faster,
+ *      profiles/r04/persistent.md;
+ *      values above 16 = that many workgroups in all)
  *   4  rows from which the grouped evaluation runs FOLDED -- one wave per unit adds up the four offset groups itself -- instead of on
  *      four waves per unit (FPCC_GROUPED_FOLD_ROWS, default 102400; 0 = never).  Same order 3, same bits. */
 int fpcc_conv_set_tuning(int which, int value);
@@ -262,7 +266,11 @@ int fpcc_pointwise_head_f32(const float *x, int c0, int ldx, const float *w1, co
  * executed -- never a result.  fpcc_conv_row_keys writes, per row, a sort key (window of 2^window_log2 consecutive rows
  * in the high word, Gray rank of the row's neighbour-presence pattern in the low word); sorting them with
  * fpcc_sort_keys (end_bit 63) yields a row_order with like patterns adjacent: on voxelised surfaces ~15 instead of ~24
- * of the 27 offsets per block.  The reference has no counterpart (MinkowskiEngine scatters per offset). */
+ * of the 27 offsets per block.  The reference has no counterpart (MinkowskiEngine scatters per offset).
+ * Table layout beside a row order: an offset-major table (nbr_ks != 1) is indexed by OUTPUT ROW as always; a ROW-MAJOR table
+ * (nbr_ks == 1, fpcc_transpose_table_i32) is indexed by TILE POSITION -- its row p holds the neighbours of output row row_order[p]
+ * (gather the table's rows by row_order once per coordinate map) -- so that the entries a block of positions needs are consecutive
+ * in memory and no load of a kernel's prologue depends on another. */
 int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n, int window_log2,
                        int64_t *keys_out, uint32_t *masks_out, void *stream);
 /* masks_out (may be NULL): per row, bit k set iff the row has kernel offset k. */

@@ -644,8 +644,12 @@ def test_row_major_neighbour_table_changes_no_result(ops, scene, c1, c2, c_out):
     assert rows.shape == (n, 32) and torch.equal(rows[:, :27].t().contiguous(), nbr) and bool((rows[:, 27:] == -1).all())
     order = ops.conv_row_order(nbr, 27, n, 1, n)
     base = dict(x2=None if x2 is None else _cuda(x2), bias=_cuda(b), act=ops.ACT_RELU, pack=True)
+    rows_pos = rows.index_select(0, order.long())              # beside a row order the row-major table is indexed by position
     layouts = (dict(nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1), dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32))
-    forms = [((ops.KNOB_GROUPED_FOLD_ROWS, 0),), ((ops.KNOB_GROUPED_FOLD_ROWS, 1),)]
+    forms = [((ops.KNOB_GROUPED_FOLD_ROWS, 0), (ops.KNOB_PERSIST, 0)), ((ops.KNOB_GROUPED_FOLD_ROWS, 1), (ops.KNOB_PERSIST, 0)),
+             # persistent forms: 40 / 17 workgroups walk the units with a stride (ragged: the counts do not divide the units)
+             ((ops.KNOB_GROUPED_FOLD_ROWS, 0), (ops.KNOB_PERSIST, 40)), ((ops.KNOB_GROUPED_FOLD_ROWS, 1), (ops.KNOB_PERSIST, 17)),
+             ((ops.KNOB_GROUPED_FOLD_ROWS, 1), (ops.KNOB_PERSIST, 3))]
     if c_out >= 64:
         forms += [((ops.KNOB_LDS_ROWS, 1), (ops.KNOB_LDS_ROW_BLOCKS, 2)), ((ops.KNOB_LDS_ROWS, 1), (ops.KNOB_LDS_ROW_BLOCKS, 4))]
     for form in forms:
@@ -653,6 +657,8 @@ def test_row_major_neighbour_table_changes_no_result(ops, scene, c1, c2, c_out):
         try:
             for lay in layouts:
                 for ro in (None, order):
+                    if ro is not None and lay['nbr_ks'] == 1:
+                        lay = dict(lay, nbr=rows_pos)
                     got = ops.conv_f32(_cuda(x1), _cuda(w), c_out, n, row_order=ro, **lay, **base)
                     assert (_bits(got.cpu().numpy()) == _bits(want)).all(), (form, lay['nbr_ks'], ro is not None)
         finally:

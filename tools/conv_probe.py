@@ -28,9 +28,9 @@ w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
 pairs = int((nbr >= 0).sum().item())
 PACK = bool(int(os.environ.get('PACK', '1')))
 # ROWS=0: offset-major neighbour table [27, n]; default: the row-major copy the engine hands the MFMA kernels
-TABLE = cm._k3_table(m, os.environ.get('ROWS', '1') != '0')
+ROWS = os.environ.get('ROWS', '1') != '0'
 def run(row_order):
-    return ops.conv_f32(f, w, c_out, n, row_order=row_order, pack=PACK, **TABLE)
+    return ops.conv_f32(f, w, c_out, n, row_order=row_order, pack=PACK, **cm._k3_table(m, ROWS, row_order if row_order is order else None))
 def lpt(order, group):
     present = (nbr >= 0)[:, order.long()]
     pad = (-n) % group

@@ -24,8 +24,8 @@ nbr = cm._nbr27(m)
 order = cm._row_order(m)
 torch.manual_seed(0)
 f = torch.randn((n, c_in), device='cuda')
-w = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
-run = lambda: ops.conv_f32(f, w, c_out, n, row_order=order, pack=True, **cm._k3_table(m, os.environ.get('ROWS', '1') != '0'))
+wt = torch.randn((27, c_in, c_out), device='cuda') / (13 * c_in) ** 0.5
+run = lambda: ops.conv_f32(f, wt, c_out, n, row_order=order, pack=True, **cm._k3_table(m, os.environ.get('ROWS', '1') != '0', order))
 ops.conv_set_tuning(ops.KNOB_LDS_ROWS, 1)
 ops.conv_set_tuning(ops.KNOB_LDS_ROW_BLOCKS, rb)
 S = 48
@@ -35,7 +35,7 @@ for dbg in (32, 60):
     ops.conv_set_tuning(ops.KNOB_WAVE_DBG, dbg)
     buf = torch.zeros(n_waves * S, dtype=torch.int64, device='cuda')
     ops.conv_debug_stamps(buf)
-    for _ in range(30):
+    for _ in range(60):
         run()
     buf.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +47,18 @@ for dbg in (32, 60):
     comp, stages = st[:, 43], st[:, 44]
     d = lambda a, b: (st[:, b] - st[:, a]).astype(np.float64)
     life = d(0, 42)
-    print(f'## level {level} rows {n} {c_in}->{c_out} {rb} row blocks per workgroup, dbg {dbg}: launch {e0.elapsed_time(e1) * 1e3:.1f} us; {len(st)} waves')
+    rt = d(38, 39)
+    clk = life[rt > 0] / rt[rt > 0] * 100.0
+    print(f'  shader clock over a wave\'s life (memtime / memrealtime): median {np.median(clk):.0f} MHz  p10 {np.percentile(clk, 10):.0f}  p90 {np.percentile(clk, 90):.0f}')
+    # occupancy over time from the constant 100 MHz counter (chip-wide): waves alive at 24 points of the launch
+    ok = st[:, 39] > st[:, 38]
+    b, e = st[ok, 38], st[ok, 39]
+    t0, t1 = b.min(), e.max()
+    pts = np.linspace(t0, t1, 25)[:-1] + (t1 - t0) / 48
+    alive = [int(((b <= q) & (e > q)).sum()) for q in pts]
+    print(f'  launch span by the 100 MHz counter: {(t1 - t0) / 100:.1f} us; waves alive at 24 points (1024 SIMDs x 3 = 3072): {alive}')
+    first = np.sort(b)[[0, len(b) // 100, len(b) // 10]] - t0
+    print(f'  wave starts: 1 % after {first[1] / 100:.1f} us, 10 % after {first[2] / 100:.1f} us; sum of wave lives {(e - b).sum() / 100 / 3072:.1f} us per wave slot')
     print(f'  wave life: sum {life.sum():.4g} cycles = {life.sum() / 1024 / 2400:.1f} us per SIMD slot-sum (1024 SIMDs, 2.4 GHz); median {np.median(life):.0f} p90 {np.percentile(life, 90):.0f}')
     for name, v in (('entry -> masks known', d(0, 1)), ('-> first DMAs issued', d(1, 2)), ('stage loop', d(2, 40)), ('fold', d(40, 41)), ('stores', d(41, 42))):
         print(f'  {name}: median {np.median(v):.0f}  p90 {np.percentile(v, 90):.0f}  share of wave life {v.sum() / life.sum() * 100:.1f} %')

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r04h; mkdir -p $O
+timeout 900 python3 -m pytest tests/test_gpu_conv.py -x -q -k "row_major or folded or grouped" > $O/pytest.txt 2>&1
+tail -3 $O/pytest.txt
+for p in 0 3 2; do
+for shape in "1 128 128" "2 128 128" "1 64 64"; do
+  echo "FPCC_CONV_PERSIST=$p" >> $O/persist.txt
+  FPCC_CONV_PERSIST=$p ONLY=pattern timeout 300 python3 tools/conv_probe.py $shape 20 >> $O/persist.txt 2>&1
+done
+done
+grep -v amdgpu $O/persist.txt
