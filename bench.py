@@ -36,6 +36,7 @@ def parse():
                                                              'the cfg#5 DDP training step over all N ranks at N > 1')
     ap.add_argument('--frames-in-flight', type=int, default=2, help='frames a rank keeps in flight on its GPU (fastpcc_amd/serving.py): '
                     '1 = one frame at a time, each closed by a device synchronise (the reference\'s timer placement)')
+    ap.add_argument('--own-streams', type=int, default=0, help='1: every frame in flight on a HIP stream of its own (kernels of different frames overlap)')
     ap.add_argument('--ddp-steps', type=int, default=10, help='optimisation steps of the cfg#5 DDP figure (N > 1)')
     ap.add_argument('--ddp-deadline', type=float, default=420.0, help='seconds after which rank 0 prints the headline without the DDP figure')
     ap.add_argument('--dump-trace', default='', help='write the per-launch conv table of the last step to this file')
@@ -328,7 +329,7 @@ def main():
     # level of decompress -- the other frame's launches run.  A context waits for its own work only (events).
     from fastpcc_amd.serving import FramePipeline, wait_for_my_work
     depth = max(1, args.frames_in_flight)
-    pipeline = FramePipeline(model, depth, device)
+    pipeline = FramePipeline(model, depth, device, own_streams=bool(args.own_streams))
 
     def step_of(ctx_model, _):
         data = ctx_model.compress(frame)                 # returns when this frame's bytes are written
@@ -348,6 +349,7 @@ def main():
         return data, rec
 
     if depth > 1:
+        step()                                           # context 0 first: every cache derived from the shared weights exists
         for data, rec in pipeline.map(step_of, range(max(args.warmup, depth))):      # every context warm
             assert n_points - max(16, n_points // 1000) <= rec.shape[0] <= n_points, (rec.shape[0], n_points)
     else:

@@ -277,7 +277,17 @@ class GeoLosslessEntropyModel(nn.Module):
 
         if tm is not None:
             tm['enc_enqueued'] = time.perf_counter()
-        coord_bytes_list = pool.wait()                                   # the only blocking point of the encoder
+        try:
+            coord_bytes_list = pool.wait()                               # the only blocking point of the encoder
+        except RuntimeError as e:
+            # a coder refused its input (a zero probability, a symbol outside its own histogram): say what the streams held
+            st['side'].synchronize()
+            what = [f'occupancy level {i}: {m.size} symbols, prob16 min {int(q.min()) if q.size else -1} zeros {int((q == 0).sum())}'
+                    for i, (m, q) in enumerate(occupancy_h)]
+            if residual_job is not None:
+                sym = residual_job[0]
+                what.append(f'residuals: {sym.size} symbols in [{int(sym.min())}, {int(sym.max())}]')
+            raise RuntimeError(f'{e}; job status words {getattr(pool, "last_failure", None)}; ' + '; '.join(what)) from e
         if pending_occ:                                                  # coded finest first: back to level order (coarse -> fine)
             coord_bytes_list.reverse()
             occupancy_h.reverse()

@@ -100,5 +100,7 @@ class CoderPool:
         rc = host().fpcc_pool_wait(self._h)
         binary, self._binary = self._binary, []
         self._keep = []
+        if rc < 0:                                 # which job: the per-job status words say (negative = that job's error)
+            self.last_failure = [int(length[0]) for _, length in binary]
         host_check(rc)
         return [out[out.size - int(host_check(int(length[0]))):].tobytes() for out, length in binary]

@@ -316,24 +316,25 @@ class CoordinateManager:
         """the 3x3x3 table row-major, [n, 32] int32 (entries 27 .. 31 = -1): a row's 27 entries are one 128-byte line, which the MFMA
         kernels' prologue fetches as 16-byte pieces -- from the offset-major table it is 27 four-byte requests to 27 lines per row
         as soon as a block's rows are not consecutive (neighbour-pattern row order).  Built once per map, shared by its layers."""
-        if not self.NBR_ROWS:
-            return None
+        if not self.NBR_ROWS or not isinstance(m.row_order, torch.Tensor):
+            return None                                  # consecutive rows read the offset-major table coalesced as it is
+        if m.nbr27_pos is not None:
+            return m.nbr27_pos                           # (callers below only test for None)
         if m.nbr27_rows is None:
             m.nbr27_rows = ops.transpose_table(self._nbr27(m), 32)
         return m.nbr27_rows
 
     def _k3_table(self, m: _Map, mfma: bool, row_order: Optional[torch.Tensor] = None) -> dict:
         """neighbour-table arguments of a 3x3x3 conv_f32 call on map m (beside `row_order`: the row-major table in position order)"""
-        rows = self._nbr27_rows(m) if mfma else None
-        if rows is None:
+        rows = self._nbr27_rows(m) if (mfma and row_order is not None) else None
+        if rows is None:                                 # consecutive rows read the offset-major table coalesced as it is
             return dict(nbr=self._nbr27(m), n_offsets=27, nbr_ks=m.n, nbr_os=1)
-        if row_order is not None:
-            if row_order is not m.row_order:
-                raise ValueError('a foreign row order')
-            if m.nbr27_pos is None:
-                m.nbr27_pos = rows.index_select(0, row_order.long())          # 128-byte rows: one gather per map
-            rows = m.nbr27_pos
-        return dict(nbr=rows, n_offsets=27, nbr_ks=1, nbr_os=32)
+        if row_order is not m.row_order:
+            raise ValueError('a foreign row order')
+        if m.nbr27_pos is None:
+            m.nbr27_pos = rows.index_select(0, row_order.long())              # 128-byte rows: one gather per map
+            m.nbr27_rows = None                                              # only the position-ordered copy is read from here on
+        return dict(nbr=m.nbr27_pos, n_offsets=27, nbr_ks=1, nbr_os=32)
 
     def _mask27(self, m: _Map) -> Optional[torch.Tensor]:
         """int32 [n]: which of the 27 neighbours of every row exist, derived from the parent level without building the row table;

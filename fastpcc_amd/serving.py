@@ -60,10 +60,15 @@ class FramePipeline:
     """`depth` codec contexts driven by `depth` worker threads; `map(fn, items)` runs fn(context_model, item) for every item, at
     most `depth` at a time, results in item order.  depth == 1 runs in the calling thread."""
 
-    def __init__(self, model: torch.nn.Module, depth: int = 2, device: Optional[torch.device] = None):
+    def __init__(self, model: torch.nn.Module, depth: int = 2, device: Optional[torch.device] = None, own_streams: bool = False):
+        """own_streams: every context enqueues on a stream of its own instead of the caller's current one -- kernels of different
+        frames then run side by side (the latency-sized launches of the coarse levels beside another frame's large ones: more
+        frames per second, but a launch's duration is no longer its own).  Contexts share weights and the caches derived from
+        them: run one frame on context 0 and synchronise before using the others, so that every cached copy exists."""
         if depth < 1:
             raise ValueError('depth >= 1')
         self.depth = depth
+        self.own_streams = own_streams and depth > 1
         self.device = device if device is not None else next(model.parameters()).device
         self.models: List[torch.nn.Module] = [model] + [clone_context(model) for _ in range(depth - 1)]
         self._jobs: 'queue.Queue' = queue.Queue()
@@ -82,6 +87,8 @@ class FramePipeline:
     def _worker(self, model: torch.nn.Module) -> None:
         if self.device.type == 'cuda':
             torch.cuda.set_device(self.device)
+            if self.own_streams:
+                torch.cuda.set_stream(torch.cuda.Stream(device=self.device))
         while True:
             job = self._jobs.get()
             if job is None:

@@ -2,8 +2,9 @@
 # GPU session 10: frames in flight (threads, one stream): bench with depth 1 / 2 / 3; a quick parity check of the pipelined contexts
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r04l; mkdir -p $O
-for d in 1 2 3; do
+for d in 1 2; do
   timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-baseline 0 --secondary 0 --frames-in-flight $d > $O/d$d.json 2> $O/d$d.err
+  [ $d = 2 ] && timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-baseline 0 --secondary 0 --frames-in-flight 2 --own-streams 1 > $O/d3.json 2> $O/d3.err
 done
 python3 - <<'PY'
 import json
