@@ -225,6 +225,82 @@ __device__ __attribute__((aligned(16))) int8_t g_zero_i8[64];
 
 constexpr int kI8MaxOffsets = 64;       // 4x4x4 kernels of the embedding convolutions
 
+// Bias / PReLU / requantisation / residual epilogue of a wave's 32 x (32 NB) tile, shared by the two convolution kernels.  Every load
+// it needs -- slope, zero point, per-column bias and multiplier, the residual operand of all its elements -- is issued BEFORE the
+// first store: a load placed between two stores makes the wave wait (vmcnt(0)) for every store issued so far, one memory round trip
+// per output element (profiles/r04/prologue_epilogue.md; the residual form used to do exactly that, 16 NB times per wave).
+template <int NB>
+__device__ __forceinline__ void conv_i8_epilogue(const ConvI8Args &p, const i32x16 (&acc)[NB], const int32_t *my_rows, int col0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int32_t slope = p.slope ? p.slope[0] : 0;
+    const int64_t zp = p.zp ? p.zp[0] : 0;
+    const int32_t slope2 = p.res ? p.slope2[0] : 0;
+    int32_t b[NB];
+    uint32_t m[NB];
+    bool live[NB], pad[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + 32 * nb + li;
+        live[nb] = col < p.c_out;
+        pad[nb] = !live[nb] && p.out_bits == 8 && col < p.out_pad;
+        b[nb] = (live[nb] && p.bias) ? p.bias[col] : 0;
+        m[nb] = (live[nb] && p.mul) ? p.mul[col] : 0u;
+    }
+    int64_t orow[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) orow[reg] = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
+    if (p.out_bits != 8 && p.res) {
+        // residual form: all residual operands first (16 NB registers), then the stores
+        int32_t r[NB][16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                r[nb][reg] = (live[nb] && orow[reg] >= 0) ? p.res[orow[reg] * p.ld_res + col0 + 32 * nb + li] : 0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!live[nb]) continue;
+            const int col = col0 + 32 * nb + li;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t o = orow[reg];
+                if (o < 0) continue;
+                int32_t v = acc[nb][reg];
+                if (p.mul) {
+                    int64_t t = (int64_t)acc[nb][reg] + b[nb];
+                    if (p.slope) t = prelu_q625(t, slope);
+                    v = requant(t, m[nb], zp, p.shift, p.out_bits);
+                }
+                static_cast<int32_t *>(p.out)[o * p.ldo + col] = residual_prelu(v, r[nb][reg], slope2);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!live[nb] && !pad[nb]) continue;
+            const int col = col0 + 32 * nb + li;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t o = orow[reg];
+                if (o < 0) continue;
+                int32_t v = 0;
+                if (live[nb]) {
+                    if (p.mul) {
+                        int64_t t = (int64_t)acc[nb][reg] + b[nb];
+                        if (p.slope) t = prelu_q625(t, slope);
+                        v = requant(t, m[nb], zp, p.shift, p.out_bits);
+                    } else {
+                        v = acc[nb][reg];
+                    }
+                }
+                if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
+                else static_cast<int32_t *>(p.out)[o * p.ldo + col] = v;
+            }
+        }
+    }
+    also8_tail<NB>(p, my_rows, col0, lane);
+}
+
 // One wave = 32 output rows x 32*NB output columns; the four waves of a workgroup are independent (no barrier).
 // A stage = (kernel offset present in the wave's rows, k-step of 32 input channels): one 16-byte A load and NB 16-byte
 // W loads per lane, NB MFMAs.  The operands of stage s+1 are requested before the MFMAs of stage s are issued.
@@ -335,35 +411,7 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p, int32_t *acc_out,
         return;
     }
 
-    const int32_t slope = p.slope ? p.slope[0] : 0;
-    const int64_t zp = p.zp ? p.zp[0] : 0;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int col = col0 + 32 * nb + li;
-        const bool live = col < p.c_out;
-        const bool pad = !live && p.out_bits == 8 && col < p.out_pad;
-        if (!live && !pad) continue;
-        const int32_t b = (live && p.bias) ? p.bias[col] : 0;
-        const uint32_t m = (live && p.mul) ? p.mul[col] : 0u;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t o = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
-            if (o < 0) continue;
-            int32_t v = 0;
-            if (live) {
-                if (p.mul) {
-                    int64_t t = (int64_t)acc[nb][reg] + b;
-                    if (p.slope) t = prelu_q625(t, slope);
-                    v = requant(t, m, zp, p.shift, p.out_bits);
-                } else {
-                    v = acc[nb][reg];
-                }
-            }
-            if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
-            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
-        }
-    }
-    also8_tail<NB>(p, my_rows, col0, lane);
+    conv_i8_epilogue<NB>(p, acc, my_rows, col0, lane);
 }
 
 // Workgroup-tiled variant for maps that fill the chip with row tiles: 4 waves = 128 output rows x 32*NB output columns.
@@ -491,36 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
         }
     }
 
-    const int32_t slope = p.slope ? p.slope[0] : 0;
-    const int64_t zp = p.zp ? p.zp[0] : 0;
-    const int32_t *my_rows = s_row + wave * 32;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int col = col0 + 32 * nb + li;
-        const bool live = col < p.c_out;
-        const bool pad = !live && p.out_bits == 8 && col < p.out_pad;
-        if (!live && !pad) continue;
-        const int32_t b = (live && p.bias) ? p.bias[col] : 0;
-        const uint32_t m = (live && p.mul) ? p.mul[col] : 0u;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t o = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
-            if (o < 0) continue;
-            int32_t v = 0;
-            if (live) {
-                if (p.mul) {
-                    int64_t t = (int64_t)acc[nb][reg] + b;
-                    if (p.slope) t = prelu_q625(t, slope);
-                    v = requant(t, m, zp, p.shift, p.out_bits);
-                } else {
-                    v = acc[nb][reg];
-                }
-            }
-            if (p.out_bits == 8) static_cast<int8_t *>(p.out)[o * p.ldo + col] = (int8_t)v;
-            else static_cast<int32_t *>(p.out)[o * p.ldo + col] = p.res ? residual_prelu(v, p.res[o * p.ld_res + col], p.slope2[0]) : v;
-        }
-    }
-    also8_tail<NB>(p, my_rows, col0, lane);
+    conv_i8_epilogue<NB>(p, acc, s_row + wave * 32, col0, lane);
 }
 
 // stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
