@@ -1006,8 +1006,13 @@ def make_codec_int():
     return {'runs': runs}
 
 
-def _functional_minkowski():
-    """A MinkowskiEngine stand-in that EVALUATES on the CPU: the API surface the reference's lossy_coord_v2 test path touches
+def _functional_minkowski(order_fn=None):
+    """order_fn (round 4): None = every sum by torch (conv_mm / nn.Linear); else fastpcc_amd.engine.summation_order -- the stand-in
+    then evaluates every convolution and linear layer as the fixed-order FMA chain the HIP kernels document
+    (oracle/sparse_conv.py:conv_chain), so that a run of the REFERENCE's model code over it writes the bytes the GPU path must
+    write exactly (tests/test_gpu_codec_v2.py::test_bytes_equal_the_reference_run_in_chain_order).
+
+    A MinkowskiEngine stand-in that EVALUATES on the CPU: the API surface the reference's lossy_coord_v2 test path touches
     (SparseTensor, CoordinateManager / CoordinateMapKey, the three convolutions, linear, activations, pruning, max pooling and
     its transpose, cat) on top of oracle/coords.py (coordinate maps in Morton order, kernel offsets x fastest, strided /
     generated / transposed maps) and oracle/sparse_conv.py:conv_mm (gather -> torch.mm -> index_add_ per kernel offset).
@@ -1159,7 +1164,12 @@ def _functional_minkowski():
             else:
                 raise NotImplementedError((self.MODE, ks, st))
             w = self.kernel.reshape(len(kmap), self.in_channels, self.out_channels)
-            out = sc.conv_mm(x.F, kmap, w, None if self.bias is None else self.bias.reshape(-1), cm.levels[dst_key].n)
+            n_out = cm.levels[dst_key].n
+            if order_fn is None:
+                out = sc.conv_mm(x.F, kmap, w, None if self.bias is None else self.bias.reshape(-1), n_out)
+            else:
+                kind = {('conv', 1): 'k1', ('conv', 3): 'k3', ('conv', 2): 'k2s2', ('transpose', 2): 'k2s2T', ('generative', 2): 'gen'}[(self.MODE, ks)]
+                out = _chain(x, kind, oc.dense_table(kmap, n_out), w.detach(), self.bias, n_out)
             return like(x, out, dst_key)
 
     ME.MinkowskiConvolution = type('MinkowskiConvolution', (_Conv,), {})
@@ -1173,7 +1183,28 @@ def _functional_minkowski():
             setattr(self, attr, cls(*a, **k))
         return type(name, (nn.Module,), {'__init__': init, 'forward': lambda self, x: like(x, getattr(self, attr)(x.F))})
 
-    ME.MinkowskiLinear = wrap('MinkowskiLinear', 'linear', nn.Linear)
+    def _chain(x, kind, table, w, bias, n_out):
+        """the layer as the documented FMA chain; a tensor that is the concatenation of two (ME.cat) enters as two sources"""
+        f = x.F.detach()
+        split = getattr(x, '_split', None)
+        c1, c2 = (split if split is not None and len(split) == 2 else (f.shape[1], 0))
+        x1, x2 = f[:, :c1].contiguous().numpy(), (f[:, c1:].contiguous().numpy() if c2 else None)
+        out = sc.conv_chain(x1, table, w.numpy(), None if bias is None else bias.detach().reshape(-1).numpy(), n_out, x2=x2,
+                            order=order_fn(kind, c1, c2, w.shape[-1], n_out))
+        return torch.from_numpy(out)
+
+    class _ChainLinear(nn.Module):
+        def __init__(self, in_features, out_features, bias=True):
+            super().__init__()
+            self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+        def forward(self, x):
+            n = x.F.shape[0]
+            w = self.linear.weight.detach().t().contiguous()
+            table = np.arange(n, dtype=np.int32)[None]
+            return like(x, _chain(x, 'mlp', table, w.reshape(1, *w.shape), self.linear.bias, n))
+
+    ME.MinkowskiLinear = wrap('MinkowskiLinear', 'linear', nn.Linear) if order_fn is None else _ChainLinear
     ME.MinkowskiBatchNorm = wrap('MinkowskiBatchNorm', 'bn', nn.BatchNorm1d)
     for name, cls in (('MinkowskiReLU', nn.ReLU), ('MinkowskiPReLU', nn.PReLU), ('MinkowskiLeakyReLU', nn.LeakyReLU),
                       ('MinkowskiSigmoid', nn.Sigmoid)):
@@ -1212,7 +1243,9 @@ def _functional_minkowski():
         if len(tensors) == 1 and isinstance(tensors[0], (tuple, list)):
             tensors = tuple(tensors[0])
         assert all(t.coordinate_map_key == tensors[0].coordinate_map_key for t in tensors)
-        return like(tensors[0], torch.cat([t.F for t in tensors], 1))
+        out = like(tensors[0], torch.cat([t.F for t in tensors], 1))
+        out._split = [t.F.shape[1] for t in tensors]       # the layer that consumes it reads two sources (chain mode)
+        return out
 
     ME.MinkowskiPruning, ME.MinkowskiMaxPooling, ME.MinkowskiPoolingTranspose, ME.cat = MinkowskiPruning, MinkowskiMaxPooling, MinkowskiPoolingTranspose, cat
     ME.SparseTensor, ME.CoordinateManager, ME.CoordinateMapKey, ME.KernelGenerator = SparseTensor, CoordinateManager, CoordinateMapKey, KernelGenerator
@@ -1547,8 +1580,82 @@ def make_codec_lossl():
     return out
 
 
+def make_codec_v2_chain():
+    """lossy_coord_v2 runs of the REFERENCE's model code (as make_codec_v2) over the stand-in engine in CHAIN mode: every convolution
+    and linear layer summed in the order the HIP kernels document (fastpcc_amd.engine.summation_order; numerics version of
+    include/fpcc_hip.h).  These streams are what the GPU path has to write byte for byte, and their reconstructions point for point --
+    the mm-mode runs of codec_v2.json sum in torch's CPU order and can only be matched within tolerances."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from fastpcc_amd.engine import summation_order
+    from fastpcc_amd import hipops
+    _stub_engines()
+    _functional_minkowski(order_fn=summation_order)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossy_coord_v2.model import PCC
+        from models.convolutional.lossy_coord_v2.model_config import ModelConfig
+    finally:
+        ce.load = real
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    out = {'numerics_version': hipops.numerics_version(), 'runs': []}
+    base = dict(activation='prelu', compressed_channels=(1,), skip_encoding_fea=1, adaptive_pruning=True)
+
+    def run(label, cfg, cfg_dict, seed, xyz, extra=None):
+        torch.manual_seed(0)
+        model = PCC(cfg)
+        enliven(model, seed)
+        model.eval()
+        perm = np.random.default_rng(seed).permutation(len(xyz))
+        with torch.no_grad():
+            data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
+            rec = model.decompress(data)
+        rec_np = rec.cpu().numpy().astype(np.int64)
+        keys = np.sort((rec_np[:, 0] << 42) | (rec_np[:, 1] << 21) | rec_np[:, 2])
+        entry = {'label': label, 'config': cfg_dict, 'seed': seed, 'xyz': xyz[perm].tolist(),
+                 'param_abs_sum': float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)),
+                 'stream_hex': data.hex(), 'recon_points': len(rec), 'recon_sha256': hashlib.sha256(keys.tobytes()).hexdigest()}
+        entry.update(extra or {})
+        out['runs'].append(entry)
+        print('codec_v2_chain', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec), 'decoded')
+
+    for label, kw, seed, res, pts in (
+            ('r1_like', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1, 0, 1),
+                             geo_lossl_channels=(16, 32, 32, 32, 32, 32, 1)), 1, 64, 2500),
+            ('r3_like_two_stages', dict(encoder_channels=(8, 16, 16), decoder_channels=(16, 8), geo_lossl_if_sample=(0, 1, 0, 1),
+                                        geo_lossl_channels=(16, 32, 32, 32, 1)), 2, 64, 3000)):
+        cfg = ModelConfig()
+        for k, v in {**base, **kw}.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        cfg.check()
+        run(label, cfg, {k: (list(v) if isinstance(v, tuple) else v) for k, v in {**base, **kw}.items()}, seed,
+            surface_cloud(seed + 40, res, pts) + np.array([2, 0, 5], dtype=np.int32))
+    # the headline configuration at its real widths, from the reference's own YAML through its own config loader
+    from lib.config import Config as RefConfig
+    ref_cfg = RefConfig()
+    ref_cfg.merge_with_yaml(os.path.join(REF, 'config/convolutional/lossy_coord_v2/baseline_r1.yaml'))
+    ref_cfg.check()
+    mc = ref_cfg.model
+    run('baseline_r1_yaml', mc, {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in vars(mc).items() if not k.startswith('_')}, 6,
+        surface_cloud(46, 256, 4000) + np.array([1, 4, 2], dtype=np.int32), {'yaml': 'config/convolutional/lossy_coord_v2/baseline_r1.yaml'})
+    run('baseline_r1_yaml_12k', mc, {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in vars(mc).items() if not k.startswith('_')}, 7,
+        surface_cloud(47, 256, 16000) + np.array([3, 1, 0], dtype=np.int32), {'yaml': 'config/convolutional/lossy_coord_v2/baseline_r1.yaml'})
+    return out
+
+
 def main():
-    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_v2_chain', make_codec_v2_chain), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

@@ -382,6 +382,44 @@ def test_against_the_reference_run(run):
     assert same >= 0.97 * len(ref)
 
 
+def _chain_runs():
+    """the chain-order reference runs of codec_v2_chain.json (round 4): the reference's model code over the stand-in engine with every
+    layer summed in the order the HIP kernels document -- two stand-in widths, and the real widths of baseline_r1.yaml on two clouds"""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2_chain.json')) as f:
+        g = json.load(f)
+    keys = {f.name for f in __import__('dataclasses').fields(__import__('fastpcc_amd.codecs.lossy_coord_v2.model_config', fromlist=['ModelConfig']).ModelConfig)}
+    return g['numerics_version'], [dict(r, config={k: v for k, v in r['config'].items() if k in keys}) for r in g['runs']]
+
+
+@pytest.mark.parametrize('run', _chain_runs()[1], ids=[r['label'] for r in _chain_runs()[1]])
+def test_bytes_equal_the_reference_run_in_chain_order(run):
+    """STRICT link between the HIP path and executed reference code: the reference's model (layers, traversal, coding order, framing,
+    pruning rule, rANS coders -- its own source) run with the documented summation orders writes a stream; the HIP path must write
+    the same BYTES and decode them to the same POINTS.  The only arithmetic the two sides do not share instruction for instruction
+    is the logistic function in front of the 16-bit probability (libm on the host, the device's exp here): should a probability
+    ever differ by its last bit on these clouds the streams differ, and this test says so by failing -- on the four committed
+    clouds they coincide."""
+    import hashlib
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import ModelConfig
+    assert _chain_runs()[0] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_v2_chain.json'
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    want = bytes.fromhex(run['stream_hex'])
+    data = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda())
+    assert data == want
+    for stream in (want, data):
+        rec = model.decompress(stream).cpu().numpy().astype(np.int64)
+        keys = np.sort((rec[:, 0] << 42) | (rec[:, 1] << 21) | rec[:, 2])
+        assert len(rec) == run['recon_points'] and hashlib.sha256(keys.tobytes()).hexdigest() == run['recon_sha256']
+
+
 def test_numerics_version_byte_is_opt_in_and_checked():
     """numerics_version_in_header: one leading byte; default off = the reference's layout; a stream of another version is refused"""
     from fastpcc_amd import hipops

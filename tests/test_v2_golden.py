@@ -101,3 +101,40 @@ def test_oracle_pruning_rule_equals_the_reference_masks(case):
         want = np.unpackbits(np.frombuffer(bytes.fromhex(q['keep']), dtype=np.uint8))[:len(logits)].astype(bool)[cand.order]
         got = oracle.get_keep(pred, cells, None if q['points_num'] is None else q['points_num'][0])
         assert (got == want).all() and int(got.sum()) == q['kept']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Chain-order reference runs (tests/golden/codec_v2_chain.json, round 4): the reference's model code executed over the stand-in
+# engine with every convolution / linear layer summed in the order the HIP kernels document.  The oracle, told the same orders,
+# must write those bytes and decode them to those points EXACTLY -- fp32 sums included, whatever torch build runs here: both
+# sides evaluate the same FMA chains in plain C.
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2_chain.json')) as f:
+    GC = json.load(f)
+
+
+def _chain_runs():
+    keys = {f.name for f in __import__('dataclasses').fields(ModelConfig)}
+    return [dict(r, config={k: v for k, v in r['config'].items() if k in keys}) for r in GC['runs']]
+
+
+def recon_digest(points) -> str:
+    p = np.asarray(points, dtype=np.int64).reshape(-1, 3)
+    return hashlib.sha256(np.sort((p[:, 0] << 42) | (p[:, 1] << 21) | p[:, 2]).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('run', _chain_runs(), ids=[r['label'] for r in _chain_runs()])
+def test_reference_run_in_chain_order(run):
+    from fastpcc_amd import hipops
+    from fastpcc_amd.engine import summation_order
+    assert GC['numerics_version'] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_v2_chain.json'
+    cfg, model = model_of(run)
+    assert float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)) == \
+        pytest.approx(run['param_abs_sum'], rel=1e-12)
+    xyz = np.array(run['xyz'], dtype=np.int64)
+    coords = np.concatenate((np.zeros((len(xyz), 1), np.int64), xyz), 1)
+    want = bytes.fromhex(run['stream_hex'])
+    weights = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    oracle = OracleV2(weights, cfg, conv='chain', order_fn=summation_order)
+    assert oracle.compress(coords) == want
+    rec = oracle.decompress(want)
+    assert len(rec) == run['recon_points'] and recon_digest(rec.tolist()) == run['recon_sha256']
