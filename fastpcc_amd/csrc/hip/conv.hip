@@ -150,12 +150,14 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(ConvArgs a) {
     for (int r = tid; r < TM; r += C::THREADS)
         s_row[r] = row0 + r < a.n_out ? (a.row_order ? a.row_order[row0 + r] : (int32_t)(row0 + r)) : -1;
     // the tile's neighbour table -> LDS (rows past the end count as absent)
+    const bool by_pos = a.row_order && table_is_row_major(a);
     for (int e = tid; e < n_off * TM; e += C::THREADS) {
         const int k = e / TM, r = e % TM;
         int32_t v = -1;
         if (row0 + r < a.n_out) {
             const int64_t row = a.row_order ? (int64_t)a.row_order[row0 + r] : row0 + r;
-            v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + row * a.nbr_os] : (int32_t)row;
+            // (a row-major table beside a row order holds its rows in position order: conv_common.h)
+            v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (by_pos ? row0 + r : row) * a.nbr_os] : (int32_t)row;
         }
         s_nbr[e] = v;
     }
@@ -768,10 +770,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_wave22(ConvArgs a, const float 
     // (i, h) serves rows i (first block) and 32 + i (second block)
     int32_t my_row = -1;
     if (row0 + lane < a.n_out) my_row = a.row_order ? a.row_order[row0 + lane] : (int32_t)(row0 + lane);
+    // (a row-major table beside a row order holds its rows in position order: conv_common.h)
+    const int64_t table_row = (a.row_order && table_is_row_major(a)) ? row0 + lane : (int64_t)my_row;
     unsigned wmask = 0;
     for (int k = 0; k < a.n_off; ++k) {
         int32_t v = -1;
-        if (my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + (int64_t)my_row * a.nbr_os] : my_row;
+        if (my_row >= 0) v = a.nbr ? a.nbr[(int64_t)k * a.nbr_ks + table_row * a.nbr_os] : my_row;
         s_nbr[k * 64 + lane] = v;
         if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
     }

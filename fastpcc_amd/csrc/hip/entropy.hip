@@ -11,10 +11,34 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// The logistic function, SPECIFIED (numerics version 3): exp(-x) by Cody-Waite reduction and a degree-5 polynomial; every operation is
+// an IEEE-754 binary32 fma / multiplication / addition / round-to-nearest-even / correctly rounded division, written so that no
+// compiler may contract or reorder it.  Any conforming device or host gives the same bits (oracle/sparse_conv.c:sigmoid_spec is the
+// same text), so a stream written here decodes anywhere -- the device's expf and a host's libm differ in the last bit now and then, and
+// one differing 16-bit probability desynchronises a binary rANS stream.  Within 2 ulp of torch.sigmoid (the reference's call).
+__device__ __forceinline__ float sigmoid_spec(float x) {
+    float t = -x;
+    t = fminf(fmaxf(t, -87.0f), 87.0f);
+    const float n = rintf(__fmul_rn(t, 1.44269504088896341f));
+    float r = __fmaf_rn(n, -0.693145751953125f, t);
+    r = __fmaf_rn(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __fmaf_rn(p, r, 1.3981999507e-3f);
+    p = __fmaf_rn(p, r, 8.3334519073e-3f);
+    p = __fmaf_rn(p, r, 4.1665795894e-2f);
+    p = __fmaf_rn(p, r, 1.6666665459e-1f);
+    p = __fmaf_rn(p, r, 5.0000001201e-1f);
+    const float pr = __fmul_rn(p, r);
+    float e = __fmaf_rn(pr, r, r);
+    e = __fadd_rn(e, 1.0f);
+    e = __fmul_rn(e, __uint_as_float((uint32_t)((int32_t)n + 127) << 23));
+    return __fdiv_rn(1.0f, __fadd_rn(1.0f, e));
+}
+
 __global__ void k_logit_to_prob16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ p) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float s = 1.0f / (1.0f + expf(-x[i]));             // fp32 sigmoid, as torch.sigmoid on a float tensor
+    const float s = sigmoid_spec(x[i]);
     double q = rint((double)s * 65536.0);                     // float64 product, round half to even (np.round)
     q = fmin(fmax(q, 1.0), 65535.0);
     p[i] = (uint16_t)q;

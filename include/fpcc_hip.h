@@ -119,7 +119,7 @@ enum { FPCC_ACT_NONE = 0, FPCC_ACT_PRELU = 1, FPCC_ACT_RELU = 2 };
 
 /* Numerics version.  A decoder must recompute the encoder's fp32 activations BIT FOR BIT (they pass through round() and
  * 16-bit probability quantisation before entropy coding), so the summation order of every layer is part of the stream
- * format.  Version 2: the order of a layer is a function of its SHAPE alone (channel counts, kernel offsets, groups) -- plus one
+ * format.  Since version 2 the order of a layer is a function of its SHAPE alone (channel counts, kernel offsets, groups) -- plus one
  * row threshold for the zero-padded shapes -- never of tile shapes, row order, kernel choice or a tuning knob:
  *     order 3 (grouped)                      multi-offset layers (8 <= K <= 27, one group) with C_in, c1 multiples of 32 and C_out
  *                                            in {32,64,128}: the K offsets form four fixed contiguous groups
@@ -131,10 +131,18 @@ enum { FPCC_ACT_NONE = 0, FPCC_ACT_PRELU = 1, FPCC_ACT_RELU = 2 };
  *     zero-padding to an MFMA shape          per-point / 3x3x3 layers on maps of at least FPCC_PAD_MIN_ROWS rows
  *     two-phase conv3 -> 1 channel (order 2) every 3x3x3 layer with one output channel and C_in % 16 == 0: per offset its own
  *                                            chain, offsets' sums added in ascending order
- * (Version 1 evaluated multi-offset maps of <= 8192 rows offset-split = order 2 and larger ones in order 1.)  The codecs' streams
- * carry no version field by default (the reference's layout is kept byte for byte; `numerics_version_in_header` of the model
- * configs prepends it); tests/golden/v2_stream.json holds a stream of this version that every later build must decode. */
-#define FPCC_NUMERICS_VERSION 2
+ *     logistic function (version 3)          the sigmoid in front of every 16-bit occupancy probability (fpcc_logit_to_prob16) is a
+ *                                            SPECIFIED sequence of IEEE-754 binary32 operations (Cody-Waite reduction, degree-5
+ *                                            polynomial, correctly rounded division; entropy.hip:sigmoid_spec), not the device's expf:
+ *                                            any conforming host or device reproduces its bits, so a stream written on one decodes on
+ *                                            the other; within one step of the 16-bit probability torch.sigmoid gives the reference
+ * History: version 1 evaluated multi-offset maps of <= 8192 rows offset-split (order 2) and larger ones in order 1; version 2
+ * introduced order 3 but took its probabilities from the device's expf.  A decoder decodes streams of ITS OWN version only: streams
+ * of other versions are refused where the version byte is present (`numerics_version_in_header` of the model configs, which
+ * fastpcc_amd/run_test.py switches on; the library default keeps the reference's byte layout) and decode to garbage where it is not
+ * ("Stream compatibility").  tests/golden/v2_stream.json holds a stream of this version that every later build must
+ * decode; v2_stream_numerics1.json / v2_stream_numerics2.json hold streams of the earlier versions that it must refuse. */
+#define FPCC_NUMERICS_VERSION 3
 #define FPCC_PAD_MIN_ROWS 8192
 int fpcc_numerics_version(void);
 

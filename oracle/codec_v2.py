@@ -231,10 +231,11 @@ class OracleV2:
         return self.mlp_block(pre + '.decoder.1', x)
 
     # ---- entropy coding helpers ----------------------------------------------------------------------------------
-    @staticmethod
-    def init_prob(logit: torch.Tensor) -> np.ndarray:
-        return np.clip(np.round(torch.sigmoid(logit).numpy().astype(np.float64) * (1 << 16)).astype(np.uint32),
-                       1, (1 << 16) - 1)
+    def init_prob(self, logit: torch.Tensor) -> np.ndarray:
+        """geo_lossl_em.py:96-99.  conv == 'mm' (the reference-shaped evaluation): torch.sigmoid as the reference calls it; 'chain'
+        (the evaluation that models the HIP path bit for bit): the logistic function the HIP path specifies (sparse_conv.sigmoid_spec)"""
+        s = torch.sigmoid(logit).numpy() if getattr(self, 'conv', 'mm') == 'mm' else sc.sigmoid_spec(logit)
+        return np.clip(np.round(s.astype(np.float64) * (1 << 16)).astype(np.uint32), 1, (1 << 16) - 1)
 
     @staticmethod
     def rans_encode_with_cdf(target: np.ndarray, bs: io.BytesIO, offset: Optional[int] = None):

@@ -103,3 +103,36 @@ void orc_gather_conv_f32(const float *x1, int64_t c1, int64_t ld1, const float *
         free(part);
     }
 }
+
+
+/* The logistic function in front of the 16-bit occupancy probability, as the HIP path SPECIFIES it from numerics version 3 on
+ * (include/fpcc_hip.h, fpcc_logit_to_prob16; fastpcc_amd/csrc/hip/entropy.hip:sigmoid_spec): exp(-x) by Cody-Waite reduction and a
+ * degree-5 polynomial, every operation an IEEE-754 binary32 fused multiply-add, multiplication, addition, round-to-nearest-even or
+ * correctly rounded division -- so that ANY conforming host or device produces the same bits and a stream written on one decodes on
+ * the other.  (The reference calls torch.sigmoid, geo_lossl_em.py:96-99, whose last bit depends on the libm / vector library at hand;
+ * this function agrees with it to within 2 ulp, i.e. the 16-bit probability to within one step.) */
+static inline float sigmoid_spec(float x) {
+    float t = -x;
+    t = fminf(fmaxf(t, -87.0f), 87.0f);
+    const float n = rintf(t * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, t);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float pr = p * r;
+    float e = fmaf(pr, r, r);
+    e = e + 1.0f;
+    union { uint32_t u; float f; } scale;
+    scale.u = (uint32_t)((int32_t)n + 127) << 23;
+    e = e * scale.f;
+    const float d = 1.0f + e;
+    return 1.0f / d;
+}
+
+void orc_sigmoid_spec_f32(const float *x, int64_t n, float *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = sigmoid_spec(x[i]);
+}

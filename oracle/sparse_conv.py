@@ -87,3 +87,15 @@ def conv_chain(x: np.ndarray, table: Optional[np.ndarray], w: np.ndarray, bias: 
 
 def conv_chain_kmap(x: np.ndarray, kmap: KernelMap, w, bias, n_out: int, **kw) -> np.ndarray:
     return conv_chain(x, dense_table(kmap, n_out), w, bias, n_out, **kw)
+
+
+def sigmoid_spec(x) -> np.ndarray:
+    """the logistic function as the HIP path specifies it from numerics version 3 on (oracle/sparse_conv.c:sigmoid_spec): bit for bit
+    what fpcc_logit_to_prob16 evaluates on the device"""
+    a = np.ascontiguousarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, dtype=np.float32)
+    out = np.empty_like(a)
+    fn = lib().orc_sigmoid_spec_f32
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    fn(a.ctypes.data_as(C.c_void_p), a.size, out.ctypes.data_as(C.c_void_p))
+    return out

@@ -1611,15 +1611,25 @@ def make_codec_v2_chain():
     out = {'numerics_version': hipops.numerics_version(), 'runs': []}
     base = dict(activation='prelu', compressed_channels=(1,), skip_encoding_fea=1, adaptive_pruning=True)
 
+    from oracle import sparse_conv as sc_
+    real_sigmoid = torch.Tensor.sigmoid
+
     def run(label, cfg, cfg_dict, seed, xyz, extra=None):
         torch.manual_seed(0)
         model = PCC(cfg)
         enliven(model, seed)
         model.eval()
         perm = np.random.default_rng(seed).permutation(len(xyz))
-        with torch.no_grad():
-            data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
-            rec = model.decompress(data)
+        # the logistic function in front of the 16-bit probabilities (GeoLosslessEntropyModel.init_prob calls dist.sigmoid()) is the
+        # one the HIP path specifies from numerics version 3 on -- like the convolution sums, an arithmetic primitive with a documented
+        # rounding, not model logic
+        torch.Tensor.sigmoid = lambda self: torch.from_numpy(sc_.sigmoid_spec(self)).to(self.device)
+        try:
+            with torch.no_grad():
+                data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32))
+                rec = model.decompress(data)
+        finally:
+            torch.Tensor.sigmoid = real_sigmoid
         rec_np = rec.cpu().numpy().astype(np.int64)
         keys = np.sort((rec_np[:, 0] << 42) | (rec_np[:, 1] << 21) | rec_np[:, 2])
         entry = {'label': label, 'config': cfg_dict, 'seed': seed, 'xyz': xyz[perm].tolist(),

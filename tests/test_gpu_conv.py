@@ -664,3 +664,31 @@ def test_row_major_neighbour_table_changes_no_result(ops, scene, c1, c2, c_out):
         finally:
             for k, v in saved:
                 ops.conv_set_tuning(k, v)
+
+
+@pytest.mark.parametrize('pack', [True, False])
+@pytest.mark.parametrize('c1,c2,c_out', [(32, 32, 32), (64, 0, 32), (48, 0, 64), (16, 0, 32), (32, 0, 64), (16, 16, 16), (128, 0, 64)])
+def test_position_ordered_table_on_every_mfma_kernel(ops, scene, c1, c2, c_out, pack):
+    """beside a row order the row-major table holds its rows in POSITION order (include/fpcc_hip.h): every kernel that takes a row
+    order -- the block-tiled one, the 64-row wave units, the grouped / folded ones -- must read it that way, not by row id
+    (round 4: the colour decoder's 34 -> 16 layer ran on a kernel that did not).  Same kernel, same order: same bits as from the
+    offset-major table, which the oracle tests above pin."""
+    if ops.conv_order(c1, c2, c_out) == 0:
+        pytest.skip('not an MFMA shape')
+    rng = np.random.default_rng(c1 + 3 * c2 + c_out)
+    table = scene['k3'].copy()
+    n = table.shape[1]
+    table[:, 7] = -1
+    x1 = _cuda(rng.normal(size=(n, c1)).astype(np.float32))
+    x2 = _cuda(rng.normal(size=(n, c2)).astype(np.float32)) if c2 else None
+    w = _cuda((rng.normal(size=(27, c1 + c2, c_out)) / np.sqrt(13 * (c1 + c2))).astype(np.float32))
+    b = _cuda(rng.normal(size=c_out).astype(np.float32))
+    nbr = _cuda(table)
+    order = ops.conv_row_order(nbr, 27, n, 1, n)
+    rows_pos = ops.transpose_table(nbr, 32).index_select(0, order.long())
+    kw = dict(x2=x2, bias=b, act=ops.ACT_RELU, pack=pack, row_order=order)
+    by_row = ops.conv_f32(x1, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, **kw)
+    by_pos = ops.conv_f32(x1, w, c_out, n, nbr=rows_pos, n_offsets=27, nbr_ks=1, nbr_os=32, **kw)
+    natural = ops.conv_f32(x1, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, **dict(kw, row_order=None))
+    assert torch.equal(by_row, natural)
+    assert torch.equal(by_pos, by_row)

@@ -221,26 +221,30 @@ def test_committed_stream_of_this_numerics_version_still_decodes(v2):
     assert again == data, 'the encoder no longer writes the committed stream for the committed input'
 
 
-def test_stream_of_numerics_version_1_is_refused(v2):
-    """tests/golden/v2_stream_numerics1.json is the stream the round-2 build (numerics version 1: other summation orders for the
-    multi-offset layers) wrote for the same cloud and weights.  With the version byte in use a version-2 build must refuse it; and
-    the bytes themselves differ from what this build writes (the activations differ, so do the coded symbols)."""
+@pytest.mark.parametrize('version', [1, 2])
+def test_streams_of_earlier_numerics_versions_are_refused(v2, version):
+    """tests/golden/v2_stream_numerics{1,2}.json are the streams the round-2 build (version 1: other summation orders for the
+    multi-offset layers) and the round-3 build (version 2: probabilities from the device's expf) wrote for the same cloud and
+    weights.  With the version byte in use a later build must refuse them; the version-1 bytes also differ from what this build writes
+    (the activations differ, so do the coded symbols)."""
     import copy, json, os
     from fastpcc_amd.codecs.lossy_coord_v2 import Model
     cfg, model, _, ops, ME = v2
-    with open(os.path.join(os.path.dirname(__file__), 'golden', 'v2_stream_numerics1.json')) as f:
+    with open(os.path.join(os.path.dirname(__file__), 'golden', f'v2_stream_numerics{version}.json')) as f:
         old = json.load(f)
     with open(os.path.join(os.path.dirname(__file__), 'golden', 'v2_stream.json')) as f:
         cur = json.load(f)
-    assert old['numerics_version'] == 1 and ops.numerics_version() != 1
-    assert old['cloud'] == cur['cloud'] and old['weights'] == cur['weights'] and old['stream_hex'] != cur['stream_hex']
+    assert old['numerics_version'] == version and ops.numerics_version() > version
+    assert old['cloud'] == cur['cloud'] and old['weights'] == cur['weights']
+    if version == 1:
+        assert old['stream_hex'] != cur['stream_hex']
     cfg2 = copy.deepcopy(cfg)
     cfg2.numerics_version_in_header = True
     versioned = Model(cfg2)
     versioned.load_state_dict(model.state_dict())
     versioned = versioned.cuda().eval()
-    with pytest.raises(ValueError, match='numerics version 1'):
-        versioned.decompress(bytes([1]) + bytes.fromhex(old['stream_hex']))
+    with pytest.raises(ValueError, match=f'numerics version {version}'):
+        versioned.decompress(bytes([version]) + bytes.fromhex(old['stream_hex']))
     ME.clear_global_coordinate_manager()
     # and the current stream, carried with its version byte, decodes
     rec = versioned.decompress(bytes([ops.numerics_version()]) + bytes.fromhex(cur['stream_hex']))
