@@ -1664,8 +1664,79 @@ def make_codec_v2_chain():
     return out
 
 
+def make_codec_color_chain():
+    """lossy_coord_lossy_color runs of the REFERENCE's model code (as make_codec_color) over the stand-in engine in CHAIN mode (see
+    make_codec_v2_chain): the streams the GPU path has to write byte for byte and the coloured clouds it has to decode point for point."""
+    import torch
+    import torch.utils.cpp_extension as ce
+    import yaml
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from fastpcc_amd.engine import summation_order
+    from fastpcc_amd import hipops
+    _stub_engines()
+    _functional_minkowski(order_fn=summation_order)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.') or k == 'models' or k.startswith('models.')]:
+        del sys.modules[k]
+    real = ce.load
+    import rans_ext_cpp
+    import simple_rans_ext_cpp
+    built = {'rans_ext_cpp': rans_ext_cpp, 'simple_rans_ext_cpp': simple_rans_ext_cpp}
+    ce.load = lambda *a, **k: built.get(k.get('name', a[0] if a else ''), types.SimpleNamespace())
+    try:
+        from models.convolutional.lossy_coord_lossy_color.model import PCC
+        from models.convolutional.lossy_coord_lossy_color.model_config import ModelConfig
+    finally:
+        ce.load = real
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    from oracle import sparse_conv as sc_
+    real_sigmoid = torch.Tensor.sigmoid
+    out = {'numerics_version': hipops.numerics_version(), 'runs': []}
+    for label, kw, seed, res, pts, gain in (
+            ('two_stages', dict(encoder_channels=(8, 16, 16), decoder_channels=(16, 8), geo_lossl_if_sample=(0, 1, 0, 1),
+                                geo_lossl_channels=(16, 32, 32, 32, 1)), 1, 64, 3000, None),
+            ('one_stage', dict(encoder_channels=(8, 16), decoder_channels=(8,), geo_lossl_if_sample=(0, 1, 0, 1, 0, 1),
+                               geo_lossl_channels=(16, 16, 16, 16, 16, 16, 1)), 2, 64, 2000, None),
+            # the reference's own YAML at its real widths (a larger gain: at the default one every residual of this depth quantises to 0)
+            ('baseline_r1_yaml', {}, 3, 256, 6000, 2.3)):
+        cfg = ModelConfig()
+        with open(os.path.join(REF, 'config/convolutional/lossy_coord_lossy_color/baseline_r1.yaml')) as f:
+            for k, v in yaml.safe_load(f)['model'].items():
+                assert hasattr(cfg, k), k
+                setattr(cfg, k, tuple(v) if isinstance(v, list) else v)
+        for k, v in kw.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        cfg.compressed_channels = (cfg.compressed_channels[0],) if isinstance(cfg.compressed_channels, tuple) else (cfg.compressed_channels,)
+        cfg.check()
+        torch.manual_seed(0)
+        model = PCC(cfg)
+        enliven(model, seed, **({} if gain is None else {'gain': gain}))
+        model.eval()
+        xyz = surface_cloud(seed + 50, res, pts) + np.array([1, 3, 0], dtype=np.int32)
+        rng = np.random.default_rng(seed)
+        perm = rng.permutation(len(xyz))
+        color = np.clip(128 + 60 * np.sin(xyz / 7.0) + rng.normal(0, 12, xyz.shape), 0, 255).round().astype(np.float32)
+        torch.Tensor.sigmoid = lambda self: torch.from_numpy(sc_.sigmoid_spec(self)).to(self.device)      # see make_codec_v2_chain
+        try:
+            with torch.no_grad():
+                data = model.compress(torch.from_numpy(batched(xyz)[perm]).to(torch.int32), torch.from_numpy(color[perm]))
+                rec_xyz, rec_rgb = model.decompress(data)
+        finally:
+            torch.Tensor.sigmoid = real_sigmoid
+        out['runs'].append({'label': label, 'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()
+                                                       if not k.startswith('_')},
+                            'seed': seed, 'gain': gain, 'xyz': xyz[perm].tolist(), 'color': color[perm].astype(int).tolist(),
+                            'param_abs_sum': float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)),
+                            'stream_hex': data.hex(), 'recon_xyz': rec_xyz.tolist(), 'recon_rgb': rec_rgb.to(torch.int32).tolist()})
+        print('codec_color_chain', label, len(xyz), 'points ->', len(data), 'bytes,', len(rec_xyz), 'decoded')
+    return out
+
+
 def main():
-    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_v2_chain', make_codec_v2_chain), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_v2_chain', make_codec_v2_chain), ('codec_color_chain', make_codec_color_chain), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

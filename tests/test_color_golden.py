@@ -50,3 +50,37 @@ def test_reference_run(run):
         assert np.asarray(rec_rgb).astype(int).tolist() == run['recon_rgb']
     else:
         assert abs(len(data) - len(want)) <= 0.02 * len(want) + 4
+
+
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color_chain.json')) as f:
+    GC = json.load(f)
+
+
+def chain_model_of(run):
+    known = {f.name for f in fields(ModelConfig)}
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items() if k in known})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'], **({} if run.get('gain') is None else {'gain': run['gain']}))
+    return cfg, model
+
+
+@pytest.mark.parametrize('run', GC['runs'], ids=[r['label'] for r in GC['runs']])
+def test_reference_run_in_chain_order(run):
+    """codec_color_chain.json: the reference's colour codec run with every layer summed in the order the HIP kernels document
+    (make_golden.py:make_codec_color_chain); the chain-mode oracle writes the same bytes and decodes the same coloured cloud"""
+    from fastpcc_amd import hipops
+    from fastpcc_amd.engine import summation_order
+    assert GC['numerics_version'] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_color_chain.json'
+    cfg, model = chain_model_of(run)
+    assert float(sum(p.detach().double().abs().sum() for n, p in model.named_parameters() if '.prior_' not in n)) == \
+        pytest.approx(run['param_abs_sum'], rel=1e-12)
+    xyz = np.array(run['xyz'], dtype=np.int64)
+    coords = np.concatenate((np.zeros((len(xyz), 1), np.int64), xyz), 1)
+    want = bytes.fromhex(run['stream_hex'])
+    weights = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    oracle = OracleColor(weights, cfg, conv='chain', order_fn=summation_order)
+    assert oracle.compress(coords, np.array(run['color'], dtype=np.uint8)) == want
+    rec_xyz, rec_rgb = oracle.decompress(want)
+    assert rec_xyz.tolist() == run['recon_xyz']
+    assert np.asarray(rec_rgb).astype(int).tolist() == run['recon_rgb']

@@ -86,3 +86,36 @@ def test_against_the_reference_run(run):
     assert len(hits) >= 0.97 * len(ref)
     err = np.array([np.abs(np.array(c) - np.array(ref[p])).max() for p, c in hits])
     assert np.mean(err <= 1) > 0.97                     # colours of the common points agree up to rounding of the last layer
+
+
+def _chain_runs():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color_chain.json')) as f:
+        g = json.load(f)
+    return g['numerics_version'], g['runs']
+
+
+@pytest.mark.parametrize('run', _chain_runs()[1], ids=[r['label'] for r in _chain_runs()[1]])
+def test_bytes_equal_the_reference_run_in_chain_order(run):
+    """STRICT: the reference's colour codec (its own model code and coders) run with the documented summation orders and the
+    specified logistic function (tests/golden/make_golden.py:make_codec_color_chain) -- same bytes, same points, same colours.
+    The third run is the reference's own baseline_r1.yaml at its real widths."""
+    from dataclasses import fields
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+    from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import ModelConfig
+    assert _chain_runs()[0] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_color_chain.json'
+    known = {f.name for f in fields(ModelConfig)}
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items() if k in known})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'], **({} if run.get('gain') is None else {'gain': run['gain']}))
+    model = model.cuda().eval()
+    xyz = np.array(run['xyz'], dtype=np.int32)
+    color = np.array(run['color'], dtype=np.uint8)
+    want = bytes.fromhex(run['stream_hex'])
+    data = model.compress(torch.from_numpy(batched(xyz)).to(torch.int32).cuda(), torch.from_numpy(color).cuda())
+    assert data == want
+    rec_xyz, rec_rgb = model.decompress(want)
+    assert rec_xyz.cpu().numpy().tolist() == run['recon_xyz']
+    assert rec_rgb.cpu().numpy().astype(int).tolist() == run['recon_rgb']

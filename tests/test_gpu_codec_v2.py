@@ -396,10 +396,9 @@ def _chain_runs():
 def test_bytes_equal_the_reference_run_in_chain_order(run):
     """STRICT link between the HIP path and executed reference code: the reference's model (layers, traversal, coding order, framing,
     pruning rule, rANS coders -- its own source) run with the documented summation orders writes a stream; the HIP path must write
-    the same BYTES and decode them to the same POINTS.  The only arithmetic the two sides do not share instruction for instruction
-    is the logistic function in front of the 16-bit probability (libm on the host, the device's exp here): should a probability
-    ever differ by its last bit on these clouds the streams differ, and this test says so by failing -- on the four committed
-    clouds they coincide."""
+    the same BYTES and decode them to the same POINTS.  Since numerics version 3 the logistic function in front of the 16-bit
+    probabilities is specified operation by operation as well (include/fpcc_hip.h), so no arithmetic is left that the two sides do
+    not share instruction for instruction."""
     import hashlib
     from fastpcc_amd import hipops
     from fastpcc_amd.codecs.lossy_coord_v2 import Model
