@@ -123,6 +123,18 @@ __device__ __forceinline__ int32_t requant(int64_t v, uint32_t mul, int64_t zp, 
     return (int32_t)(r < lo ? lo : (r > hi ? hi : r));
 }
 
+// requant(v, ..., 8) of an int32 v with per-tensor parameters: one 32 x 32 -> 64-bit multiply-add and a branch-free rounding where
+// nothing can wrap (multiplier < 2^31, |zp| < 2^61, 1 <= shift <= 60 -- uniform tests), the generic form otherwise; see conv_i8_epilogue
+__device__ __forceinline__ int32_t requant8_i32(int32_t v, uint32_t mul, int64_t zp, int shift) {
+    if ((int32_t)mul >= 0 && shift >= 1 && shift <= 60 && zp < ((int64_t)1 << 61) && zp > -((int64_t)1 << 61)) {
+        const int64_t hm1 = ((int64_t)1 << (shift - 1)) - 1;
+        const int64_t q1 = (int64_t)v * (int64_t)(int32_t)mul + (zp + hm1);
+        const int64_t r = (q1 + (int64_t)(q1 >= hm1)) >> shift;
+        return (int32_t)(r < -128 ? -128 : (r > 127 ? 127 : r));
+    }
+    return requant((int64_t)v, mul, zp, shift, 8);
+}
+
 // Additional int8 copies of an int32 (Q8.23) result, each requantised with the parameters of ONE consumer's RequantFxpToScaledInt8
 // (cuda_ops.py:473-509: per-tensor multiplier, zero point, shift): written by the producer's epilogue, so the consumers'
 // stand-alone requantisation launches -- one read of the [n, C] int32 matrix and one int8 write each -- disappear.
@@ -191,8 +203,8 @@ __device__ __forceinline__ void also8_tail(const ConvI8Args &p, const int32_t *m
             const uint32_t mul = (i == 0 ? e.mul0 : e.mul1)[0];
             const int64_t zp = (i == 0 ? e.zp0 : e.zp1)[0];
             if (col < p.c_out)
-                *reinterpret_cast<int32_t *>(dst + o * ld + col) = pack4_i8(requant(v.x, mul, zp, sh, 8), requant(v.y, mul, zp, sh, 8),
-                                                                            requant(v.z, mul, zp, sh, 8), requant(v.w, mul, zp, sh, 8));
+                *reinterpret_cast<int32_t *>(dst + o * ld + col) = pack4_i8(requant8_i32(v.x, mul, zp, sh), requant8_i32(v.y, mul, zp, sh),
+                                                                            requant8_i32(v.z, mul, zp, sh), requant8_i32(v.w, mul, zp, sh));
             else if (col < pad)
                 *reinterpret_cast<int32_t *>(dst + o * ld + col) = 0;
         }
@@ -729,11 +741,30 @@ __global__ void k_epilogue_i32_v4(const int32_t *__restrict__ in, int ldi, const
         const int32_t xs[4] = {x.x, x.y, x.z, x.w};
         const int64_t pc = (row_group ? (int64_t)row_group[r] * ch : 0) + c;
         const int64_t z = zp ? zp[0] : 0;
+        // the lean form of conv_i8_epilogue where its ranges hold (uniform: shift, zero point; per element: the rest), else the generic one
+        const bool lean = shift >= 1 && shift <= 60 && z < ((int64_t)1 << 61) && z > -((int64_t)1 << 61);
+        EpiFast ef;
+        ef.slope = slope ? slope[0] : (1 << 25);
+        ef.slope2 = 0;
+        ef.c25 = ((int64_t)1 << 24) - (ef.slope > 0);
+        ef.c25_2 = 0;
+        ef.shift = shift;
+        ef.hm1 = lean ? ((int64_t)1 << (shift - 1)) - 1 : 0;
+        ef.c_neg = z + ef.hm1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int64_t t = (int64_t)xs[j] + (bias ? (int64_t)bias[pc + j] : 0);
-            if (slope) t = prelu_q625(t, slope[0]);
-            v[j] = requant(t, mul[(pc + j) * mul_stride], z, shift, out_bits);
+            const int32_t bj = bias ? bias[pc + j] : 0;
+            const uint32_t mj = mul[(pc + j) * mul_stride];
+            uint32_t bad_sign = lean ? mj : 0x80000000u, bad_any = 0u;
+            const int32_t fast = out_bits == 8 ? epi_fast_elem<8>(xs[j], bj, (int32_t)mj, ef, bad_sign, bad_any)
+                                               : epi_fast_elem<32>(xs[j], bj, (int32_t)mj, ef, bad_sign, bad_any);
+            if ((int32_t)bad_sign < 0 || bad_any != 0u) {          // (rare) outside the lean form's ranges: the reference's wrapping arithmetic
+                int64_t t = (int64_t)xs[j] + (int64_t)bj;
+                if (slope) t = prelu_q625(t, slope[0]);
+                v[j] = requant(t, mj, z, shift, out_bits);
+            } else {
+                v[j] = fast;
+            }
         }
     }
     if (out_bits == 8) {
@@ -744,8 +775,12 @@ __global__ void k_epilogue_i32_v4(const int32_t *__restrict__ in, int ldi, const
         const i32x4 q = *reinterpret_cast<const i32x4 *>(res + r * ld_res + c);
         const int32_t qs[4] = {q.x, q.y, q.z, q.w};
         const int32_t s2 = slope2[0];
+        const int64_t c25_2 = ((int64_t)1 << 24) - (s2 > 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = residual_prelu(v[j], qs[j], s2);
+        for (int j = 0; j < 4; ++j) {
+            const int32_t x = (int32_t)((uint32_t)v[j] + (uint32_t)qs[j]);                  // the reference's int32 tensor add wraps
+            v[j] = x < 0 ? sat_i32(prelu_neg(x, s2, c25_2)) : x;                            // = residual_prelu, exact for every int32
+        }
     }
     if (c < ch) {
         const i32x4 o = {v[0], v[1], v[2], v[3]};
@@ -757,8 +792,8 @@ __global__ void k_epilogue_i32_v4(const int32_t *__restrict__ in, int ldi, const
         if (c < ch) {
             const uint32_t m8 = (i == 0 ? also.mul0 : also.mul1)[0];
             const int64_t z8 = (i == 0 ? also.zp0 : also.zp1)[0];
-            *reinterpret_cast<int32_t *>(dst + r * ld + c) = pack4_i8(requant(v[0], m8, z8, sh, 8), requant(v[1], m8, z8, sh, 8),
-                                                                      requant(v[2], m8, z8, sh, 8), requant(v[3], m8, z8, sh, 8));
+            *reinterpret_cast<int32_t *>(dst + r * ld + c) = pack4_i8(requant8_i32(v[0], m8, z8, sh), requant8_i32(v[1], m8, z8, sh),
+                                                                      requant8_i32(v[2], m8, z8, sh), requant8_i32(v[3], m8, z8, sh));
         } else if (c < pad) {
             *reinterpret_cast<int32_t *>(dst + r * ld + c) = 0;
         }
