@@ -386,32 +386,67 @@ def main():
             with torch.cuda.stream(clock_stream):
                 hipops.clock_probe(clock_buf[len(clock_idx)], 100)
             clock_idx.append(len(hipops.CONV_TRACE))
-    # The timed region: EXACTLY args.steps steps.  The first args.steps - trace_steps run through the pipeline (depth frames in
-    # flight); the last trace_steps run one frame at a time with HIP events around every convolution launch -- a second frame's
-    # launches between a traced launch's two events would be timed as part of it -- and each half closed by a device synchronise,
-    # which is also where the per-frame encode / decode times of the record come from.
+    # The timed region: EXACTLY args.steps steps.  With frames in flight all of them run through the pipeline; the last trace_steps
+    # record HIP events around every convolution launch of the thread that runs them (hipops.set_thread_trace; start event, launch
+    # and end event of a traced launch are enqueued under one lock, so no other frame's launch falls between them).  One frame at
+    # a time (--frames-in-flight 1): the serial loop of the earlier rounds, each half closed by a device synchronise.
+    step_traces = []
+
+    step_done = [0.0] * args.steps                       # completion time of every timed step (FPCC_BENCH_STEP_TIMES=1 prints them)
+
+    def timed_step(ctx_model, i):
+        if i < args.steps - trace_steps:
+            try:
+                return step_of(ctx_model, i)
+            finally:
+                step_done[i] = time.perf_counter()
+        mine = []
+        hipops.set_thread_trace(mine)
+        try:
+            return step_of(ctx_model, i)
+        finally:
+            hipops.set_thread_trace(None)
+            step_traces.append((i, mine))
+
     barrier()
     t0 = time.perf_counter()
-    if depth > 1 and args.steps > trace_steps:
-        pipeline.map(step_of, range(args.steps - trace_steps))
-    serial_steps = trace_steps if depth > 1 else args.steps
-    for it in range(serial_steps):
-        if it == serial_steps - trace_steps:
-            hipops.CONV_TRACE = []
-        a = time.perf_counter()
-        data = model.compress(frame)
-        torch.cuda.synchronize()
-        b = time.perf_counter()
-        ME.clear_global_coordinate_manager()
-        rec = model.decompress(data)
-        torch.cuda.synchronize()
-        c = time.perf_counter()
-        ME.clear_global_coordinate_manager()
-        t_enc += b - a
-        t_dec += c - b
+    if depth > 1:
+        pipeline.map(timed_step, range(args.steps))
+    else:
+        for it in range(args.steps):
+            if it == args.steps - trace_steps:
+                hipops.CONV_TRACE = []
+            a = time.perf_counter()
+            data = model.compress(frame)
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            ME.clear_global_coordinate_manager()
+            rec = model.decompress(data)
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            ME.clear_global_coordinate_manager()
+            t_enc += b - a
+            t_dec += c - b
     barrier()
     elapsed = time.perf_counter() - t0
-    t_enc, t_dec = t_enc * args.steps / serial_steps, t_dec * args.steps / serial_steps      # per-frame means of the serial steps
+    if depth > 1 and os.environ.get('FPCC_BENCH_STEP_TIMES') == '1':
+        done = sorted(t for t in step_done if t > 0)
+        print('step completions, ms after the start of the timed region:', ' '.join(f'{(t - t0) * 1e3:.1f}' for t in done), file=sys.stderr)
+    if depth > 1:
+        # per-frame latencies: a few frames alone on the GPU AFTER the timed region, each half closed by a device synchronise
+        for it in range(3):
+            a = time.perf_counter()
+            data = model.compress(frame)
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            ME.clear_global_coordinate_manager()
+            rec = model.decompress(data)
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            ME.clear_global_coordinate_manager()
+            t_enc += (b - a) * args.steps / 3
+            t_dec += (c - b) * args.steps / 3
+        hipops.CONV_TRACE = [e for _, tr in sorted(step_traces, key=lambda x: x[0]) for e in tr]
     pipeline.close()
     del pipeline
     trace, hipops.CONV_TRACE = hipops.CONV_TRACE, None
@@ -494,8 +529,8 @@ def main():
                                       (f', {depth} frames in flight per GPU on one stream (fastpcc_amd/serving.py)' if depth > 1 else ''),
                        'frames_in_flight': depth,
                        'latency_note': 'encode_ms / decode_ms: one frame alone on the GPU, each closed by a device synchronise (the reference\'s '
-                                       'timer placement), mean of the serial steps of the timed region; value = steps x points / elapsed of the '
-                                       'whole timed region',
+                                       'timer placement)' + (', mean of 3 frames coded after the timed region' if depth > 1 else ', mean of the timed steps') +
+                                       '; value = steps x points / elapsed of the whole timed region',
                        'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
                        'bytes': n_bytes, 'bpp': round(8 * n_bytes / n_points, 4),
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
@@ -514,7 +549,7 @@ def main():
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),
                          'other_conv_ms_per_step': round(ms_valu / trace_steps, 3),
-                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region)',
+                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region' + (', traced inside the pipeline: events around every convolution launch of the threads that run them)' if depth > 1 else ')'),
                          'shader_clock_mhz': None if shader_mhz is None else round(shader_mhz),
                          'frac_at_shader_clock': None if shader_mhz is None else
                          round(achieved / (MFMA_PEAK_TFLOPS * shader_mhz / 2400.0), 4),

@@ -456,6 +456,18 @@ CONV_TRACE = None
 TRACE_LOCK = __import__('threading').RLock()   # start event, launch, end event of a traced launch stay together when several threads enqueue
 CLOCK_HOOK = None        # bench.py: callable(ev0, n_out, n_offsets) run right after a traced launch's start event (fpcc_clock_probe beside it)
 _EVENT_POOL: list = []
+_trace_tls = __import__('threading').local()
+
+
+def set_thread_trace(trace) -> None:
+    """a trace list for the launches of the CALLING thread only (None: back to the process-wide CONV_TRACE): with several frames in
+    flight (fastpcc_amd/serving.py) a step is traced by tracing the thread that runs it"""
+    _trace_tls.trace = trace
+
+
+def _current_trace():
+    t = getattr(_trace_tls, 'trace', None)
+    return t if t is not None else CONV_TRACE
 
 
 def reserve_trace_events(n: int) -> None:
@@ -510,7 +522,7 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
             _dev(slope, torch.float32, 'slope', True), float(clip),
             _dev(row_order, torch.int32, 'row_order', True),
             None if ws is None else ws.data_ptr(), ws_bytes, _stream())
-    trace = CONV_TRACE
+    trace = _current_trace()
     if trace is None:
         _ok(fn(*call))
         return out
@@ -555,7 +567,7 @@ def pointwise_head(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor]
             _dev(slope1, torch.float32, 'slope1', True), int(order1), _dev(w2, torch.float32, 'w2'),
             _dev(b2, torch.float32, 'b2', True), int(act2), _dev(slope2, torch.float32, 'slope2', True),
             float(clip), out.data_ptr(), n, _stream())
-    trace = CONV_TRACE
+    trace = _current_trace()
     if trace is None:
         _ok(fn(*call))
         return out
@@ -627,7 +639,7 @@ def mlp_chain(x: torch.Tensor, layers, y: Optional[torch.Tensor] = None, cat_lay
     if co != c_in or out.shape[0] != n:
         raise ValueError('output shape mismatch')
     fn, ref, stream = lib().fpcc_mlp_chain_f32, C.byref(d), _stream()
-    trace = CONV_TRACE
+    trace = _current_trace()
     if trace is None:
         _ok(fn(ref, stream))
         return out
