@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Dispatch-gap timeline of the timed steps from a rocprofv3 --kernel-trace csv of `bench.py`: per step the span from the first to the
-last kernel, the time some kernel was running (union of intervals: with frames in flight two kernels never overlap on one stream, but
-copies and probe kernels may), the idle time, and the longest gaps with the kernels either side of them.
+"""Dispatch-gap statistics of the bench's timed steps from a rocprofv3 --kernel-trace csv of `bench.py`.
 
-    python profiles/step_gaps.py <p_kernel_trace.csv> [n_last_steps=3] [title]
+    python profiles/step_gaps.py <p_kernel_trace.csv> [title] [from=0.35] [to=0.70]
 
-A step boundary is the first launch of the encoder's first kernel (k_keys_from_coords on the input cloud)."""
+Looks at the window [from, to] of the trace's time span (the middle of the timed region for the command lines of tools/r04/final.sh),
+counts the frames in it by the launches of `k_conv_ones_k3` (the encoder's first layer: exactly one per compressed frame) and reports,
+PER FRAME: the time some kernel or copy was running (union of the intervals), the idle time, the gaps by length class, and the
+(kernel before -> kernel after) pairs that hold most of the idle time."""
+import collections
 import csv
 import re
 import sys
@@ -18,49 +20,65 @@ def short(name):
         return m.group(1)
     if 'rocprim' in name:
         return 'rocprim'
+    if 'copyBuffer' in name:
+        return 'copy'
+    if 'fillBuffer' in name:
+        return 'fill'
     m = re.search(r'at::native::([A-Za-z_0-9]+)', name)
     return 'torch::' + m.group(1) if m else name[:40]
 
 
-def main(path, n_last=3, title=''):
+def main(path, title='', lo=0.35, hi=0.70):
     ev = []
     with open(path) as f:
         for r in csv.DictReader(f):
             ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
     ev.sort()
-    # frames: every k_morton / first-kernel occurrence that follows a k_nn_dist2-free stretch; robust choice: the encoder's voxel keys of
-    # the FULL cloud = the largest launches of k_keys_from_coords; simpler and exact for this bench: split at gaps > 1.5 ms after a decode
-    starts = [0]
-    for i in range(1, len(ev)):
-        if ev[i][2] == 'k_keys_from_coords' and ev[i - 1][2] != 'k_keys_from_coords' and ev[i][0] - ev[starts[-1]][0] > 5_000_000:
-            starts.append(i)
-    starts.append(len(ev))
-    frames = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
-    print(f'# {title}' if title else '# step gaps')
-    print()
-    print(f'{len(ev)} kernel dispatches, {len(frames)} segments (a segment starts at the first `k_keys_from_coords` at least 5 ms after the previous segment\'s start)')
-    print()
-    print('| segment | dispatches | span ms | busy ms | idle ms | gaps > 20 us | idle in them ms | longest gaps (us: kernel before -> kernel after) |')
-    print('|---:|---:|---:|---:|---:|---:|---:|---|')
-    for fi, (a, b) in enumerate(frames[-n_last - 1:-1] if len(frames) > n_last + 1 else frames):
-        seg = ev[a:b]
-        span = (max(e[1] for e in seg) - seg[0][0]) / 1e6
-        busy, cur_end, gaps = 0, seg[0][0], []
-        for s, e, nme in seg:
-            if s > cur_end:
+    t0, t1 = ev[0][0], max(e[1] for e in ev)
+    a, b = t0 + lo * (t1 - t0), t0 + hi * (t1 - t0)
+    win = [e for e in ev if e[0] >= a and e[1] <= b]
+    frames = sum(1 for e in win if e[2] == 'k_conv_ones_k3')
+    busy, cur_end, prev = 0, win[0][0], None
+    gaps = []
+    for s, e, nme in win:
+        if s > cur_end:
+            if prev is not None:
                 gaps.append((s - cur_end, prev, nme))
-                busy += e - s
-                cur_end = e
-            else:
-                if e > cur_end:
-                    busy += e - cur_end
-                    cur_end = e
-            prev = nme
-        big = [g for g in gaps if g[0] > 20_000]
-        top = sorted(big, reverse=True)[:6]
-        print(f'| {fi} | {len(seg)} | {span:.2f} | {busy / 1e6:.2f} | {span - busy / 1e6:.2f} | {len(big)} | {sum(g[0] for g in big) / 1e6:.2f} | '
-              + '; '.join(f'{g[0] / 1e3:.0f}: {g[1]} -> {g[2]}' for g in top) + ' |')
+            busy += e - s
+            cur_end = e
+        elif e > cur_end:
+            busy += e - cur_end
+            cur_end = e
+        prev = nme
+    span = cur_end - win[0][0]
+    print(f'## {title}' if title else '## step gaps')
+    print()
+    print(f'window: {span / 1e6:.1f} ms of the trace ({lo:.2f} .. {hi:.2f} of its span), {len(win)} dispatches, **{frames} frames** '
+          f'(launches of `k_conv_ones_k3`)')
+    print()
+    print(f'per frame: **{span / 1e6 / frames:.2f} ms**, of which some kernel or copy runs {busy / 1e6 / frames:.2f} ms and the GPU is idle '
+          f'**{(span - busy) / 1e6 / frames:.2f} ms** ({100 * (span - busy) / span:.1f} %); {len(win) / frames:.0f} dispatches')
+    print()
+    print('| gap length | gaps per frame | idle ms per frame |')
+    print('|---|---:|---:|')
+    for lo_us, hi_us in ((0, 5), (5, 20), (20, 100), (100, 500), (500, 10 ** 9)):
+        g = [x[0] for x in gaps if lo_us * 1e3 <= x[0] < hi_us * 1e3]
+        label = f'{lo_us} - {hi_us} us' if hi_us < 10 ** 9 else f'> {lo_us} us'
+        print(f'| {label} | {len(g) / frames:.1f} | {sum(g) / 1e6 / frames:.3f} |')
+    pairs = collections.defaultdict(lambda: [0, 0])
+    for g, p, n in gaps:
+        if g >= 20_000:
+            pairs[(p, n)][0] += 1
+            pairs[(p, n)][1] += g
+    print()
+    print('| gaps >= 20 us: kernel before -> kernel after | per frame | idle ms per frame | longest us |')
+    print('|---|---:|---:|---:|')
+    for (p, n), (cnt, tot) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:12]:
+        longest = max(g for g, pp, nn in gaps if pp == p and nn == n)
+        print(f'| `{p}` -> `{n}` | {cnt / frames:.1f} | {tot / 1e6 / frames:.3f} | {longest / 1e3:.0f} |')
+    print()
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3, sys.argv[3] if len(sys.argv) > 3 else '')
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else '', float(sys.argv[3]) if len(sys.argv) > 3 else 0.35,
+         float(sys.argv[4]) if len(sys.argv) > 4 else 0.70)

@@ -15,11 +15,11 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $CMD > $O/write.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/busy -o p --output-format csv -- $CMD > $O/busy.log 2>&1
 python3 profiles/mfma_busy.py $O/busy > $O/mfma_busy.md 2>&1; head -8 $O/mfma_busy.md
-timeout 300 rocprofv3 --kernel-trace -d $O/gap1 -o p --output-format csv -- python3 bench.py --steps 6 --warmup 2 --cpu-baseline 0 --secondary 0 --frames-in-flight 1 > $O/gap1.log 2>&1
-timeout 300 rocprofv3 --kernel-trace -d $O/gap2 -o p --output-format csv -- python3 bench.py --steps 10 --warmup 2 --cpu-baseline 0 --secondary 0 --frames-in-flight 2 > $O/gap2.log 2>&1
-python3 profiles/step_gaps.py $(find $O/gap1 -name p_kernel_trace.csv | head -1) 3 "one frame at a time (bench.py --frames-in-flight 1)" > $O/step_gaps_1.md
-python3 profiles/step_gaps.py $(find $O/gap2 -name p_kernel_trace.csv | head -1) 3 "two frames in flight (default)" > $O/step_gaps_2.md
-cat $O/step_gaps_1.md | tail -5
+timeout 300 rocprofv3 --kernel-trace -d $O/gap1 -o p --output-format csv -- python3 bench.py --steps 12 --warmup 2 --cpu-baseline 0 --secondary 0 --frames-in-flight 1 > $O/gap1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $O/gap2 -o p --output-format csv -- python3 bench.py --steps 20 --warmup 2 --cpu-baseline 0 --secondary 0 --frames-in-flight 2 > $O/gap2.log 2>&1
+python3 profiles/step_gaps.py $(find $O/gap1 -name p_kernel_trace.csv | head -1) "one frame at a time (bench.py --steps 12 --warmup 2 --frames-in-flight 1)" > $O/step_gaps_1.md
+python3 profiles/step_gaps.py $(find $O/gap2 -name p_kernel_trace.csv | head -1) "two frames in flight (bench.py --steps 20 --warmup 2, the default depth)" > $O/step_gaps_2.md
+head -8 $O/step_gaps_1.md; head -8 $O/step_gaps_2.md
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/int -o s --output-format csv -- python3 tools/timeline_int.py > $O/int.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/color -o s --output-format csv -- python3 tools/timeline_color.py > $O/color.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/train -o s --output-format csv -- python3 bench_train.py --steps 4 --warmup 1 > $O/train.log 2>&1
