@@ -104,6 +104,10 @@ def cpu_baseline_worker(resolution, budget_s, out_path):
     import statistics
     threads = min(os.cpu_count() or 1, CPU_THREADS_CAP)
     os.environ['OMP_NUM_THREADS'] = str(threads)
+    # the parent starts this process before it initialises the GPU and releases it AFTER its GPU legs are done: 32 busy host threads
+    # right before the timed region cost the frame pipeline 15-20 % (two host threads pace two frames; profiles/r04/README.md)
+    if not sys.stdin.readline():
+        return
     import numpy as np
     import torch
     import oracle
@@ -158,19 +162,32 @@ def cpu_baseline_worker(resolution, budget_s, out_path):
 
 
 class CpuBaseline:
-    """the worker above as a child process with a hard time limit; started before the GPU is initialised, collected after"""
+    """the worker above as a child process with a hard time limit; created before the GPU is initialised (no fork of a process that
+    holds a GPU context), idle until start(), which the bench calls after its GPU legs; collected by result()"""
 
     def __init__(self, resolution, limit_s=150.0):
         import subprocess
         import tempfile
         self.limit_s = limit_s
         self.path = os.path.join(tempfile.gettempdir(), f'fpcc_cpu_baseline_{os.getpid()}.json')
-        self.t0 = time.perf_counter()
+        self.t0 = None
         self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', self.path,
-                                      '--cpu-resolution', str(resolution)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                      '--cpu-resolution', str(resolution)], stdin=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                                     stderr=subprocess.DEVNULL)
+
+    def start(self):
+        if self.t0 is None:
+            self.t0 = time.perf_counter()
+            try:
+                self.proc.stdin.write(b'go\n')
+                self.proc.stdin.flush()
+                self.proc.stdin.close()
+            except OSError:
+                pass
 
     def wait(self):
         import subprocess
+        self.start()
         try:
             self.proc.wait(timeout=max(1.0, self.limit_s - (time.perf_counter() - self.t0)))
         except subprocess.TimeoutExpired:
@@ -283,11 +300,10 @@ def main():
     rank, world, local = replicas.env_rank()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    # the CPU baseline runs in a child process, started and finished before this process initialises the GPU (it would
-    # otherwise compete with the coder pool's host threads inside the timed region)
+    # the CPU baseline runs in a child process that is CREATED here, before this process initialises the GPU, and stays idle until
+    # the GPU legs are done (cpu_job.result() at the end releases it): its 32 threads must not run beside or right before the timed
+    # region, whose two frames in flight are paced by two host threads
     cpu_job = CpuBaseline(args.cpu_resolution) if (args.cpu_baseline and world == 1 and rank == 0) else None
-    if cpu_job is not None:
-        cpu_job.wait()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -332,11 +348,13 @@ def main():
     pipeline = FramePipeline(model, depth, device, own_streams=bool(args.own_streams))
 
     def step_of(ctx_model, _):
-        data = ctx_model.compress(frame)                 # returns when this frame's bytes are written
-        ME.clear_global_coordinate_manager()
-        rec = ctx_model.decompress(data)
-        wait_for_my_work(device)                         # this frame's last kernel, not the other frame's queue
-        ME.clear_global_coordinate_manager()
+        with pipeline.stage('compress'):                 # one frame encodes while the other decodes (serving.py: FramePipeline.stage)
+            data = ctx_model.compress(frame)             # returns when this frame's bytes are written
+            ME.clear_global_coordinate_manager()
+        with pipeline.stage('decompress'):
+            rec = ctx_model.decompress(data)
+            wait_for_my_work(device)                     # this frame's last kernel, not the other frame's queue
+            ME.clear_global_coordinate_manager()
         return data, rec
 
     def step():                                          # one frame at a time, each half closed by a device synchronise

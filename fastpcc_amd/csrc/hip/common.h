@@ -39,4 +39,24 @@ inline unsigned blocks_for(int64_t n, int threads) { return static_cast<unsigned
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// fpcc_time_next_launch: the calling thread's next convolution-family entry point records ev0 on its stream before its first launch
+// and ev1 after its last one, inside the one C call (see include/fpcc_hip.h)
+struct PendingEvents { void *ev0 = nullptr, *ev1 = nullptr; };
+PendingEvents &pending_events();
+struct LaunchBracket {
+    hipStream_t s;
+    void *ev1;
+    explicit LaunchBracket(void *stream) : s(as_stream(stream)), ev1(nullptr) {
+        PendingEvents &p = pending_events();
+        if (p.ev0) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p.ev0), s);
+        ev1 = p.ev1;
+        p.ev0 = p.ev1 = nullptr;
+    }
+    ~LaunchBracket() {
+        if (ev1) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev1), s);
+    }
+    LaunchBracket(const LaunchBracket &) = delete;
+    LaunchBracket &operator=(const LaunchBracket &) = delete;
+};
+
 }  // namespace fpcc

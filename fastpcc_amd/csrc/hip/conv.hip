@@ -1425,11 +1425,26 @@ extern "C" int fpcc_conv_f32(const float *x1, int c1, int ld1, const float *x2, 
                             om_os, om_gs, out, ldo, n_out, act, slope, clip, row_order, ws, ws_bytes, stream);
 }
 
+namespace fpcc {
+PendingEvents &pending_events() {
+    static thread_local PendingEvents p;
+    return p;
+}
+}  // namespace fpcc
+
+extern "C" int fpcc_time_next_launch(void *start_event, void *end_event) {
+    PendingEvents &p = pending_events();
+    p.ev0 = start_event;
+    p.ev1 = end_event;
+    return FPCC_OK;
+}
+
 extern "C" int fpcc_conv_f32_pk(const float *x1, int c1, int ld1, const float *x2, int c2, int ld2, const int32_t *nbr,
                                 int n_offsets, int64_t nbr_ks, int64_t nbr_os, const float *w, const float *w_packed,
                                 const float *bias, int c_out, int groups, const int32_t *out_map, int64_t om_os,
                                 int64_t om_gs, float *out, int ldo, int64_t n_out, int act, const float *slope, float clip,
                                 const int32_t *row_order, void *ws, int64_t ws_bytes, void *stream) {
+    LaunchBracket timed(stream);
     if (n_out < 0 || c1 < 1 || c2 < 0 || c_out < 1 || groups < 1 || n_offsets < 1 || n_offsets > 32)
         return fail_arg("conv_f32: sizes out of range (n_offsets must be 1..32)");
     if (n_out == 0) return FPCC_OK;

@@ -483,6 +483,7 @@ extern "C" int fpcc_mlp_chain_set_form(int form) {
 }
 
 extern "C" int fpcc_mlp_chain_f32(const fpcc_mlp_chain *d, void *stream) {
+    LaunchBracket timed(stream);
     if (!d) return fail_arg("mlp_chain: null descriptor");
     if (d->n < 0 || d->n_layers < 1 || d->n_layers > kMaxLayers) return fail_arg("mlp_chain: 1..4 layers");
     if (d->n == 0) return FPCC_OK;
@@ -559,6 +560,7 @@ extern "C" int fpcc_mlp_chain_f32(const fpcc_mlp_chain *d, void *stream) {
 extern "C" int fpcc_pointwise_head_f32(const float *x, int c0, int ldx, const float *w1, const float *b1, int c1, int act1,
                                        const float *slope1, int order1, const float *w2, const float *b2, int act2,
                                        const float *slope2, float clip, float *out, int64_t n, void *stream) {
+    LaunchBracket timed(stream);
     if (n < 0 || ldx < c0 || ldx % 4) return fail_arg("pointwise_head: bad sizes");
     if (!((c0 == 16 && c1 == 8) || (c0 == 8 && c1 == 4))) return fail_arg("pointwise_head: shapes 16->8->1 and 8->4->1");
     if (order1 != 0 && order1 != 1) return fail_arg("pointwise_head: hidden-layer order must be 0 (natural) or 1 (MFMA chain)");

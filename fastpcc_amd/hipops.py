@@ -38,6 +38,7 @@ _SIGS = {
                                 _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
     'fpcc_conv_debug_stamps': (_i32, [_vp, _i64]),
+    'fpcc_time_next_launch': (_i32, [_vp, _vp]),
     'fpcc_transpose_table_i32': (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
     'fpcc_numerics_version': (_i32, []),
     'fpcc_conv_packed_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -462,7 +463,23 @@ _trace_tls = __import__('threading').local()
 def set_thread_trace(trace) -> None:
     """a trace list for the launches of the CALLING thread only (None: back to the process-wide CONV_TRACE): with several frames in
     flight (fastpcc_amd/serving.py) a step is traced by tracing the thread that runs it"""
+    global _n_thread_traces
+    had = getattr(_trace_tls, 'trace', None) is not None
     _trace_tls.trace = trace
+    with TRACE_LOCK:
+        _n_thread_traces += (trace is not None) - had
+
+
+_n_thread_traces = 0
+
+
+def _untraced_launch(fn, call) -> None:
+    """a launch of a thread that is not tracing: behind the lock while another thread is (its launch must not fall into a bracket)"""
+    if _n_thread_traces:
+        with TRACE_LOCK:
+            _ok(fn(*call))
+    else:
+        _ok(fn(*call))
 
 
 def _current_trace():
@@ -474,11 +491,35 @@ def reserve_trace_events(n: int) -> None:
     """create n timing events ahead of a traced step, so that the step itself records into existing events (creating an event
     per launch slows the host enough that the GPU waits for it, and those waits end up inside the measured intervals)"""
     while len(_EVENT_POOL) < n:
-        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                               # creates the hipEvent_t behind it (see _trace_event)
+        _EVENT_POOL.append(ev)
 
 
 def _trace_event():
-    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    if _EVENT_POOL:
+        return _EVENT_POOL.pop()
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()                                   # creates the hipEvent_t behind it (lazy in torch): fpcc_time_next_launch takes the handle
+    return ev
+
+
+def _traced_launch(trace: list, fn, call, info) -> None:
+    """one launch with HIP events around it.  The events are recorded INSIDE the C call (fpcc_time_next_launch): recorded from here,
+    whatever the interpreter does between the start event and the launch -- with several frames in flight, run another thread for a
+    switch interval -- is timed as part of the kernel.  The lock keeps another thread's launch out of the bracket (ctypes calls run
+    without the GIL).  With a clock hook (bench.py's extra step, one thread) the start event is recorded here, the hook needs it."""
+    with TRACE_LOCK:
+        ev0, ev1 = _trace_event(), _trace_event()
+        if CLOCK_HOOK is not None:
+            ev0.record()
+            CLOCK_HOOK(ev0, info.get('n_out', 0), info.get('n_offsets', 1))
+            _ok(fn(*call))
+            ev1.record()
+        else:
+            _ok(lib().fpcc_time_next_launch(ev0.cuda_event, ev1.cuda_event))
+            _ok(fn(*call))
+        trace.append((ev0, ev1, info))
 
 
 def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: Optional[torch.Tensor] = None,
@@ -524,19 +565,11 @@ def conv_f32(x1: torch.Tensor, w: torch.Tensor, c_out: int, n_out: int, *, x2: O
             None if ws is None else ws.data_ptr(), ws_bytes, _stream())
     trace = _current_trace()
     if trace is None:
-        _ok(fn(*call))
+        _untraced_launch(fn, call)
         return out
-    with TRACE_LOCK:
-        ev0 = _trace_event()
-        ev0.record()
-        if CLOCK_HOOK is not None:
-            CLOCK_HOOK(ev0, n_out, n_offsets)
-        _ok(fn(*call))
-        ev1 = _trace_event()
-        ev1.record()
-        trace.append((ev0, ev1, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
-                                 'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
-                                 'nbr_ks': nbr_ks, 'nbr_os': nbr_os}))
+    _traced_launch(trace, fn, call, {'mfma': bool(conv_order(c1, c2, c_out, n_offsets, groups, n_out)), 'c_in': c1 + c2, 'c_out': c_out,
+                                     'n_out': n_out, 'groups': groups, 'n_offsets': n_offsets, 'nbr': nbr,
+                                     'nbr_ks': nbr_ks, 'nbr_os': nbr_os})
     return out
 
 
@@ -569,16 +602,10 @@ def pointwise_head(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor]
             float(clip), out.data_ptr(), n, _stream())
     trace = _current_trace()
     if trace is None:
-        _ok(fn(*call))
+        _untraced_launch(fn, call)
         return out
-    with TRACE_LOCK:
-        ev0 = _trace_event()
-        ev0.record()
-        _ok(fn(*call))
-        ev1 = _trace_event()
-        ev1.record()
-        trace.append((ev0, ev1, {'mfma': False, 'c_in': c0, 'c_out': 1, 'n_out': n, 'groups': 1, 'n_offsets': 1, 'nbr': None,
-                                 'nbr_ks': 0, 'nbr_os': 1}))
+    _traced_launch(trace, fn, call, {'mfma': False, 'c_in': c0, 'c_out': 1, 'n_out': n, 'groups': 1, 'n_offsets': 1, 'nbr': None,
+                                     'nbr_ks': 0, 'nbr_os': 1})
     return out
 
 
@@ -641,18 +668,12 @@ def mlp_chain(x: torch.Tensor, layers, y: Optional[torch.Tensor] = None, cat_lay
     fn, ref, stream = lib().fpcc_mlp_chain_f32, C.byref(d), _stream()
     trace = _current_trace()
     if trace is None:
-        _ok(fn(ref, stream))
+        _untraced_launch(fn, (ref, stream))
         return out
-    with TRACE_LOCK:
-        ev0 = _trace_event()
-        ev0.record()
-        _ok(fn(ref, stream))
-        ev1 = _trace_event()
-        ev1.record()
-        trace.append((ev0, ev1, {'mfma': True, 'chain': True, 'c_in': cx, 'c_out': c_in, 'n_out': n, 'groups': 1, 'n_offsets': 1,
-                                 'nbr': None, 'nbr_ks': 0, 'nbr_os': 1, 'flops': float(flops),
-                                 'bytes': 4.0 * n * (cx + (d.cy if y is not None else 0) + c_in) + 4.0 * sum(w.numel() for w, *_ in layers),
-                                 'layers': [tuple(w.shape) for w, *_ in layers]}))
+    _traced_launch(trace, fn, (ref, stream), {'mfma': True, 'chain': True, 'c_in': cx, 'c_out': c_in, 'n_out': n, 'groups': 1, 'n_offsets': 1,
+                                              'nbr': None, 'nbr_ks': 0, 'nbr_os': 1, 'flops': float(flops),
+                                              'bytes': 4.0 * n * (cx + (d.cy if y is not None else 0) + c_in) + 4.0 * sum(w.numel() for w, *_ in layers),
+                                              'layers': [tuple(w.shape) for w, *_ in layers]})
     return out
 
 

@@ -17,6 +17,7 @@ and every idle stretch also drops the shader clock, which then takes millisecond
 Nothing here changes a byte of a stream: a context runs exactly the single-frame code.  The reference has no counterpart (its test
 loop codes one frame at a time, test.py); this is what "whole-job throughput" means for a stream of frames on one MI355X.
 """
+import contextlib
 import copy
 import queue
 import sys
@@ -74,6 +75,8 @@ class FramePipeline:
         self._jobs: 'queue.Queue' = queue.Queue()
         self._threads: List[threading.Thread] = []
         self._closed = False
+        self._stages: dict = {}
+        self._stages_guard = threading.Lock()
         if depth > 1:
             # the host-side chains of two frames interleave at the interpreter's switch interval: keep it short, a frame's
             # latency-critical stretches (decode of an occupancy level) are tens of microseconds of Python between two waits
@@ -101,6 +104,20 @@ class FramePipeline:
             finally:
                 ME.clear_global_coordinate_manager()
                 done.release()
+
+    def stage(self, name: str):
+        """`with pipe.stage('compress'): ...` -- stages of the same name exclude each other across the contexts.  Two frames that
+        run the SAME stage at the same time want the same resource at the same time: two decodes both wait for the host while the
+        GPU idles, two encodes queue their launches alternately and reach their host tails together (measured: frames in lock-step
+        take 24 ms each, frames in opposite phase 19 ms; which of the two a free-running pipeline falls into is chance).  With the
+        stages named, a host-paced stage of one frame always runs beside a GPU-heavy stage of the other.  depth 1: no-op."""
+        if self.depth == 1:
+            return contextlib.nullcontext()
+        with self._stages_guard:
+            lock = self._stages.get(name)
+            if lock is None:
+                lock = self._stages[name] = threading.Lock()
+        return lock
 
     def map(self, fn: Callable, items: Sequence) -> list:
         items = list(items)

@@ -211,6 +211,11 @@ int fpcc_conv_set_tuning(int which, int value);
  * first operands were requested [2], at the top of stage s [3 + min(s, 36)], after the last stage [40], after the partial-sum
  * exchange [41], after the stores [42]; [44] stages, [45] workgroup << 8 | wave, [46] HW_ID, [47] XCC_ID.  Results stay exact. */
 int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64);
+/* Timing a launch from a process whose launches are paced by several host threads: the NEXT call of fpcc_conv_f32 / fpcc_conv_f32_pk /
+ * fpcc_mlp_chain_f32 / fpcc_pointwise_head_f32 by the calling thread records `start_event` (a hipEvent_t) on its stream before its
+ * first launch and `end_event` after its last one, inside that one call -- recorded from the host language around the call, anything the
+ * host does between the record and the launch (an interpreter switching threads) is timed as part of the kernel.  NULL, NULL cancels. */
+int fpcc_time_next_launch(void *start_event, void *end_event);
 /* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
  * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks
  * (fpcc_mask27_from_parent / fpcc_conv_row_keys) -- the chain of fpcc_conv_f32 with x = 1, bit for bit, without the 27-entry

@@ -66,3 +66,28 @@ def test_pipeline_order_exceptions_and_thread_local_manager():
     ME.clear_global_coordinate_manager()
     with pytest.raises(ValueError):
         FramePipeline(m, depth=0)
+
+
+def test_named_stages_exclude_each_other_across_contexts():
+    m = _Model().eval()
+    inside = {'a': 0, 'b': 0}
+    worst = {'a': 0, 'b': 0}
+    guard = threading.Lock()
+
+    def visit(pipe, name):
+        with pipe.stage(name):
+            with guard:
+                inside[name] += 1
+                worst[name] = max(worst[name], inside[name])
+            time.sleep(0.003)
+            with guard:
+                inside[name] -= 1
+
+    with FramePipeline(m, depth=2, device=torch.device('cpu')) as pipe:
+        pipe.map(lambda ctx, it: (visit(pipe, 'a'), visit(pipe, 'b')), range(12))
+        assert pipe.stage('a') is pipe.stage('a') and pipe.stage('a') is not pipe.stage('b')
+    assert worst == {'a': 1, 'b': 1}                              # never two contexts in the same stage
+    with FramePipeline(m, depth=1, device=torch.device('cpu')) as pipe:
+        with pipe.stage('a'):                                     # one context: nothing to exclude
+            with pipe.stage('a'):
+                pass
