@@ -31,7 +31,7 @@ from . import engine as ME
 
 def clone_context(model: torch.nn.Module) -> torch.nn.Module:
     """a second context of the same codec: every module copied (so that per-module caches, coder pools and staging buffers are
-    separate) and every parameter / buffer of the copy re-pointed at the original's storage (one set of weights in HBM)"""
+    separate) over the original's parameter and buffer objects (one set of weights in HBM)"""
     # per-device overlap state (coder pool threads, side stream, pinned flags) is created lazily by every context for itself
     stash = [(m, m._overlap) for m in model.modules() if hasattr(m, '_overlap')]
     for m, _ in stash:
@@ -41,12 +41,16 @@ def clone_context(model: torch.nn.Module) -> torch.nn.Module:
     finally:
         for m, st in stash:
             m._overlap = st
-    src = dict(model.named_parameters())
-    src.update(dict(model.named_buffers()))
-    with torch.no_grad():
-        for name, t in list(twin.named_parameters()) + list(twin.named_buffers()):
-            if name in src and isinstance(t, torch.Tensor) and t.shape == src[name].shape:
-                t.data = src[name].data
+    # the copy's modules hold the ORIGINAL's parameter and buffer objects (weight tying, not just shared storage): one tensor object
+    # means one version counter, so caches keyed on (storage, version) -- hipops.packed_weights -- serve both contexts from one entry
+    # instead of re-packing a layer whenever the contexts alternate
+    for m_src, m_dst in zip(model.modules(), twin.modules()):
+        for name, p in m_src._parameters.items():
+            if p is not None and name in m_dst._parameters:
+                m_dst._parameters[name] = p
+        for name, b in m_src._buffers.items():
+            if b is not None and name in m_dst._buffers:
+                m_dst._buffers[name] = b
     return twin.eval() if not model.training else twin
 
 

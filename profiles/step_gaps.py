@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Dispatch-gap statistics of the bench's timed steps from a rocprofv3 --kernel-trace csv of `bench.py`.
 
-    python profiles/step_gaps.py <p_kernel_trace.csv> [title] [from=0.35] [to=0.70]
+    python profiles/step_gaps.py <p_kernel_trace.csv> [title] [from=0.40] [to=0.75]
 
-Looks at the window [from, to] of the trace's time span (the middle of the timed region for the command lines of tools/r04/final.sh),
-counts the frames in it by the launches of `k_conv_ones_k3` (the encoder's first layer: exactly one per compressed frame) and reports,
-PER FRAME: the time some kernel or copy was running (union of the intervals), the idle time, the gaps by length class, and the
+Frames are counted by the launches of `k_conv_ones_k3` (the encoder's first layer: exactly one per compressed frame).  The window
+runs from the start of frame number from x N to the start of frame number to x N of the N frames in the trace (the middle of the timed
+region for the command lines of tools/r04/final.sh) and the tool reports, PER FRAME: the time some kernel or copy was running (union of the intervals), the idle time, the gaps by length class, and the
 (kernel before -> kernel after) pairs that hold most of the idle time."""
 import collections
 import csv
@@ -28,16 +28,19 @@ def short(name):
     return 'torch::' + m.group(1) if m else name[:40]
 
 
-def main(path, title='', lo=0.35, hi=0.70):
+def main(path, title='', lo=0.40, hi=0.75):
     ev = []
     with open(path) as f:
         for r in csv.DictReader(f):
             ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
     ev.sort()
-    t0, t1 = ev[0][0], max(e[1] for e in ev)
-    a, b = t0 + lo * (t1 - t0), t0 + hi * (t1 - t0)
-    win = [e for e in ev if e[0] >= a and e[1] <= b]
-    frames = sum(1 for e in win if e[2] == 'k_conv_ones_k3')
+    marks = [e[0] for e in ev if e[2] == 'k_conv_ones_k3']
+    if len(marks) < 4:
+        raise SystemExit(f'only {len(marks)} frames in the trace')
+    fa, fb = int(lo * len(marks)), max(int(hi * len(marks)), int(lo * len(marks)) + 1)
+    a, b = marks[fa], marks[fb]
+    win = [e for e in ev if e[0] >= a and e[0] < b]
+    frames = fb - fa
     busy, cur_end, prev = 0, win[0][0], None
     gaps = []
     for s, e, nme in win:
@@ -53,8 +56,8 @@ def main(path, title='', lo=0.35, hi=0.70):
     span = cur_end - win[0][0]
     print(f'## {title}' if title else '## step gaps')
     print()
-    print(f'window: {span / 1e6:.1f} ms of the trace ({lo:.2f} .. {hi:.2f} of its span), {len(win)} dispatches, **{frames} frames** '
-          f'(launches of `k_conv_ones_k3`)')
+    print(f'window: {span / 1e6:.1f} ms, from the start of frame {fa} to the start of frame {fb} of the {len(marks)} in the trace: {len(win)} dispatches, '
+          f'**{frames} frames**')
     print()
     print(f'per frame: **{span / 1e6 / frames:.2f} ms**, of which some kernel or copy runs {busy / 1e6 / frames:.2f} ms and the GPU is idle '
           f'**{(span - busy) / 1e6 / frames:.2f} ms** ({100 * (span - busy) / span:.1f} %); {len(win) / frames:.0f} dispatches')
@@ -80,5 +83,5 @@ def main(path, title='', lo=0.35, hi=0.70):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else '', float(sys.argv[3]) if len(sys.argv) > 3 else 0.35,
-         float(sys.argv[4]) if len(sys.argv) > 4 else 0.70)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else '', float(sys.argv[3]) if len(sys.argv) > 3 else 0.40,
+         float(sys.argv[4]) if len(sys.argv) > 4 else 0.75)
