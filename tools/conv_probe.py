@@ -57,9 +57,16 @@ if os.environ.get('GROUPED'):    # GROUPED=1 (needs FPCC_EXPERIMENT=1): order 1 
     variants = [(-1, 1), (-3, 1), (-4, 1)]
 if os.environ.get('LDS'):        # LDS=0,2,3,4: the default kernels (0) against k_conv_lds with 2 | 3 | 4 row blocks per workgroup
     variants = [(-100 - int(v), 1) for v in os.environ['LDS'].split(',')]
+if os.environ.get('FORMS'):      # FORMS=1: the three forms of the order-3 evaluation -- four waves x 32 columns, four waves x 64 columns, folded
+    variants = [(-201, 1), (-202, 1), (-203, 1)]
 for dbg, (nbw, sb) in [(a, c) for a in DBG for c in variants]:
   ops.conv_set_tuning(3, dbg)
   tag = ''
+  if nbw is not None and nbw <= -201:
+      ops.conv_set_tuning(ops.KNOB_GROUPED_FOLD_ROWS, 1 if nbw == -203 else 0)
+      ops.conv_set_tuning(ops.KNOB_GROUPED_NBW, {-201: 1, -202: 2, -203: 0}[nbw])
+      tag = {-201: ' [grouped, 32 columns per workgroup]', -202: ' [grouped, 64 columns per workgroup]', -203: ' [folded]'}[nbw]
+      nbw = None
   if nbw is not None and nbw <= -100:
       rb = -100 - nbw
       ops.conv_set_tuning(ops.KNOB_LDS_ROWS, 1 if rb else 0)
