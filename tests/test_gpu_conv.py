@@ -692,3 +692,32 @@ def test_position_ordered_table_on_every_mfma_kernel(ops, scene, c1, c2, c_out, 
     natural = ops.conv_f32(x1, w, c_out, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, **dict(kw, row_order=None))
     assert torch.equal(by_row, natural)
     assert torch.equal(by_pos, by_row)
+
+
+def test_launch_events_recorded_inside_the_call(ops, scene):
+    """fpcc_time_next_launch (hipops.set_thread_trace): the traced launch carries two events recorded inside the C call; their distance
+    is the kernel's duration -- positive, and far below the time the host spends between two launches when it sleeps in between"""
+    import time
+    rng = np.random.default_rng(11)
+    table = scene['k3']
+    n = table.shape[1]
+    x = _cuda(rng.normal(size=(n, 64)).astype(np.float32))
+    w = _cuda((rng.normal(size=(27, 64, 64)) / 30).astype(np.float32))
+    nbr = _cuda(table)
+    want = ops.conv_f32(x, w, 64, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, pack=True)
+    trace = []
+    ops.reserve_trace_events(8)
+    ops.set_thread_trace(trace)
+    try:
+        for _ in range(3):
+            got = ops.conv_f32(x, w, 64, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, pack=True)
+            time.sleep(0.02)                       # host time between launches must not show up in the events
+    finally:
+        ops.set_thread_trace(None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and len(trace) == 3
+    for ev0, ev1, info in trace:
+        ms = ev0.elapsed_time(ev1)
+        assert 0.0 < ms < 5.0 and info['n_out'] == n and info['n_offsets'] == 27
+    untraced = ops.conv_f32(x, w, 64, n, nbr=nbr, n_offsets=27, nbr_ks=n, nbr_os=1, pack=True)      # the bracket does not linger
+    assert torch.equal(untraced, want) and len(trace) == 3
