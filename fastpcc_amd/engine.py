@@ -351,7 +351,7 @@ class CoordinateManager:
 
     # maps with more rows than this run their 3x3x3 convolutions in neighbour-pattern order (fpcc_conv_row_keys)
     ROW_ORDER_MIN_ROWS = int(os.environ.get('FPCC_ROW_ORDER_MIN_ROWS', '8192'))
-    ROW_ORDER_WINDOW_LOG2 = int(os.environ.get('FPCC_ROW_WINDOW_LOG2', '17'))
+    ROW_ORDER_WINDOW_LOG2 = int(os.environ.get('FPCC_ROW_WINDOW_LOG2', '19'))
 
     ROW_ORDER_MIN_ROWS_TRAINING = 512         # the weight gradient skips absent (row block, offset) pairs on any map
 
