@@ -19,6 +19,7 @@ loop codes one frame at a time, test.py); this is what "whole-job throughput" me
 """
 import contextlib
 import copy
+import os
 import queue
 import sys
 import threading
@@ -85,7 +86,7 @@ class FramePipeline:
             # the host-side chains of two frames interleave at the interpreter's switch interval: keep it short, a frame's
             # latency-critical stretches (decode of an occupancy level) are tens of microseconds of Python between two waits
             self._old_switch = sys.getswitchinterval()
-            sys.setswitchinterval(min(self._old_switch, 2e-4))
+            sys.setswitchinterval(min(self._old_switch, float(os.environ.get('FPCC_SWITCH_INTERVAL', '2e-4'))))
             for i in range(depth):
                 t = threading.Thread(target=self._worker, args=(self.models[i],), name=f'fpcc-frame-{i}', daemon=True)
                 t.start()
