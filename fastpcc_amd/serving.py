@@ -83,10 +83,14 @@ class FramePipeline:
         self._stages: dict = {}
         self._stages_guard = threading.Lock()
         if depth > 1:
-            # the host-side chains of two frames interleave at the interpreter's switch interval: keep it short, a frame's
-            # latency-critical stretches (decode of an occupancy level) are tens of microseconds of Python between two waits
+            # the host-side chains of two frames interleave at the interpreter's switch interval: a thread that returns from a blocking
+            # wait (an event, the coder pool) gets the interpreter back only after that interval when the other thread is busy
+            # enqueueing -- CPython hands the lock over on request only, a thread that releases it around a C call usually has it
+            # back before the waiter wakes.  A frame has ~30 such returns on its critical path (every occupancy level of the decoder):
+            # at the default 5 ms the pipeline would crawl, at 0.2 ms it was 44 Mpoints/s on a slower host, at 0.1 ms 49.5 (as at
+            # 0.05 ms; 0.02 ms costs more in switches than it buys: tools/r04/s47.sh, s49.sh).  FPCC_SWITCH_INTERVAL overrides.
             self._old_switch = sys.getswitchinterval()
-            sys.setswitchinterval(min(self._old_switch, float(os.environ.get('FPCC_SWITCH_INTERVAL', '2e-4'))))
+            sys.setswitchinterval(min(self._old_switch, float(os.environ.get('FPCC_SWITCH_INTERVAL', '1e-4'))))
             for i in range(depth):
                 t = threading.Thread(target=self._worker, args=(self.models[i],), name=f'fpcc-frame-{i}', daemon=True)
                 t.start()
