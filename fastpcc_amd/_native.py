@@ -17,11 +17,11 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
-def _load(path, what):
+def _load(path, what, keep_gil=False):
     if not os.path.exists(path):
         raise NativeLibraryMissing(
             f'{what} not built ({path}); run `python -c "import __graft_entry__ as g; g.build()"` at the repo root')
-    return C.CDLL(path)
+    return C.PyDLL(path) if keep_gil else C.CDLL(path)
 
 
 def host():
@@ -90,5 +90,9 @@ def hip():
     """libfpcc_hip.so (kernels for gfx950).  Signatures are attached in fastpcc_amd/hipops.py."""
     global _hip
     if _hip is None:
-        _hip = _load(_build.HIP_LIB, 'libfpcc_hip.so')
+        # Every entry point of libfpcc_hip only ENQUEUES work (microseconds), so its calls keep the interpreter lock (PyDLL): released
+        # around each of a frame's ~800 launches (CDLL), two frame threads (fastpcc_amd/serving.py) hand the lock back and forth at
+        # every launch and each pays a wake-up to get it back.  libfpcc_host's calls block (coder pool waits, rANS passes) and release it.
+        # FPCC_HIP_RELEASE_GIL=1 restores the ctypes default (A/B: tools/r04/s51.sh).
+        _hip = _load(_build.HIP_LIB, 'libfpcc_hip.so', keep_gil=os.environ.get('FPCC_HIP_RELEASE_GIL', '0') != '1')
     return _hip
