@@ -1145,10 +1145,8 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
     const unsigned idx_bytes = (unsigned)n_offsets * 128u * 4u;             // the tiled kernel's slice of the kernel map in LDS
     if (width > 64 && tiled && n_out >= 2048 && tiled_dbg) {
         const dim3 grid(gx, (width + 127) / 128);
+        // the ablations profiles/r04/int8_conv.md cites: 1 no MFMA, 7 no MFMA / gather / W fetch, 8 no epilogue, 15 all of them
         if (tiled_dbg == 1) hipLaunchKernelGGL((k_conv_i8_tiled<4, 1>), grid, dim3(256), idx_bytes, s, p);
-        else if (tiled_dbg == 2) hipLaunchKernelGGL((k_conv_i8_tiled<4, 2>), grid, dim3(256), idx_bytes, s, p);
-        else if (tiled_dbg == 4) hipLaunchKernelGGL((k_conv_i8_tiled<4, 4>), grid, dim3(256), idx_bytes, s, p);
-        else if (tiled_dbg == 6) hipLaunchKernelGGL((k_conv_i8_tiled<4, 6>), grid, dim3(256), idx_bytes, s, p);
         else if (tiled_dbg == 8) hipLaunchKernelGGL((k_conv_i8_tiled<4, 8>), grid, dim3(256), idx_bytes, s, p);
         else if (tiled_dbg == 15) hipLaunchKernelGGL((k_conv_i8_tiled<4, 15>), grid, dim3(256), idx_bytes, s, p);
         else hipLaunchKernelGGL((k_conv_i8_tiled<4, 7>), grid, dim3(256), idx_bytes, s, p);
