@@ -23,6 +23,24 @@ def test_logit_to_prob16(ops):
     assert got.min() >= 1 and got.max() <= 65535
 
 
+def test_logit_to_prob16_is_the_specified_logistic_function_bit_for_bit(ops):
+    """numerics version 3: the device kernel and oracle/sparse_conv.c evaluate the SAME sequence of fp32 operations (Cody-Waite
+    reduction, degree-5 polynomial, explicit fused multiply-adds), so the 16-bit probabilities agree exactly -- on random logits, on a
+    dense sweep across every binade the clamp leaves, and on the special values"""
+    from oracle import sparse_conv as sc
+    rng = np.random.default_rng(5)
+    sweep = np.concatenate([s * np.ldexp(rng.uniform(1, 2, 4000), e) for e in range(-30, 8) for s in (-1.0, 1.0)])
+    special = [0.0, -0.0, 87.0, -87.0, 87.5, -87.5, 88.8, -88.8, 1e30, -1e30, np.inf, -np.inf, 1e-45, -1e-45, 1.17549435e-38,
+               0.5 * np.log(2), -0.5 * np.log(2), 11.0903, -11.0903, 16.6355, -16.6355]
+    x = np.concatenate((rng.normal(0, 6, 1_000_000), rng.uniform(-90, 90, 200_000), sweep, special)).astype(np.float32)
+    got = ops.logit_to_prob16(torch.from_numpy(x).cuda()).cpu().numpy().view(np.uint16).astype(np.int64)
+    s = sc.sigmoid_spec(torch.from_numpy(x))
+    want = np.clip(np.round(np.asarray(s, dtype=np.float64) * 65536), 1, 65535).astype(np.int64)
+    assert (got == want).all(), int((got != want).sum())
+    ref = torch.sigmoid(torch.from_numpy(x).double()).numpy()               # and it IS the logistic function: within 2 fp32 ulp
+    assert np.abs(np.asarray(s, dtype=np.float64) - ref).max() <= 2.5e-7
+
+
 def test_quantize_symbols(ops):
     rng = np.random.default_rng(1)
     x = np.concatenate((rng.uniform(-20, 20, 100000), [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 20, -20])).astype(np.float32)
