@@ -60,6 +60,10 @@ class GeoLosslessEntropyModel(nn.Module):
         self.evaluate_unused_tail = False
         # compress(): feature chain first, occupancy predictors afterwards finest first (same bytes); FPCC_DEFER_OCCUPANCY=0: chain order
         self.defer_occupancy = os.environ.get('FPCC_DEFER_OCCUPANCY', '1') != '0'
+        # experiment (FPCC_OCCUPANCY_STREAM=1, overrides defer_occupancy): every occupancy predictor is enqueued on a second stream the
+        # moment its input exists and runs BESIDE the feature chain -- the predictors are leaves, nothing on the device reads their
+        # result.  Same launches, same bytes (tests/test_gpu_codec_v2.py runs both); measured in profiles/r04/frames_in_flight.md
+        self.occupancy_stream = os.environ.get('FPCC_OCCUPANCY_STREAM', '0') == '1'
         self._overlap = {}
         # True: occupancy levels are decoded by the device-side binary rANS decoder (fpcc_rans_binary_decode_dev) -- nothing
         # but the 4-byte count of occupied children leaves the GPU per level.  Same result; slower than the host path on the
@@ -246,7 +250,18 @@ class GeoLosslessEntropyModel(nn.Module):
             if cm._map(lower.coordinate_map_key) is not target_map:
                 if target_map.parent is not cm._map(lower.coordinate_map_key):
                     raise RuntimeError('pyramid levels are not parent and child')
-                if self.defer_occupancy:
+                if self.occupancy_stream:
+                    # what the predictor shares with the feature chain exists before the fork (built lazily, it would be built on
+                    # whichever stream asks first): the 3x3x3 table of the level's map, parent of the generated map's table
+                    cm._nbr27(cm._map(lower.coordinate_map_key))
+                    fork = torch.cuda.Event()
+                    fork.record()
+                    occ = st.setdefault('occ', torch.cuda.Stream(device=bottom_f.device))
+                    with torch.cuda.stream(occ):
+                        occ.wait_event(fork)
+                        code_occupancy(idx, lower, target_map)
+                    lower.F.record_stream(occ)
+                elif self.defer_occupancy:
                     pending_occ.append((idx, lower, target_map))
                 else:
                     code_occupancy(idx, lower, target_map)
@@ -293,6 +308,8 @@ class GeoLosslessEntropyModel(nn.Module):
             occupancy_h.reverse()
             pending_occ.clear()
         st['side'].synchronize()
+        if 'occ' in st:
+            st['occ'].synchronize()
         if tm is not None:
             tm['enc_synced'] = tm['enc_occupancy_coded'] = time.perf_counter()
         sym_h, job = residual_job

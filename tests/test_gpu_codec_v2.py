@@ -213,6 +213,13 @@ def test_deferred_occupancy_predictors_do_not_change_the_bytes(setup):
     finally:
         em.defer_occupancy = True
     assert deferred == in_order
+    # the same predictors enqueued on a second stream the moment their input exists (experiment of round 4, off by default: no faster)
+    em.occupancy_stream = True
+    try:
+        for _ in range(3):                           # more than once: a race between the two streams would not show every time
+            assert model.compress(dev) == deferred
+    finally:
+        em.occupancy_stream = False
     assert sym_deferred['sizes'] == sym_in_order['sizes'] and len(sym_deferred['sizes']) >= 2
     assert (sym_deferred['occupancy'] == sym_in_order['occupancy']).all() and (sym_deferred['prob'] == sym_in_order['prob']).all()
     assert model.decompress(deferred).shape[0] == len(xyz)
