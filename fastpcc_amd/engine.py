@@ -453,7 +453,10 @@ class SparseTensor:
                  quantization_mode: SparseTensorQuantizationMode = SparseTensorQuantizationMode.RANDOM_SUBSAMPLE,
                  **_):
         if coordinate_manager is None:
-            coordinate_manager = _global_cm
+            # the reference's implicit-manager idiom (ME.SparseTensor(feats, coordinates=...) with no manager): the calling thread's
+            # global manager when the operation mode shares one, a fresh manager otherwise (MinkowskiEngine's two operation modes)
+            coordinate_manager = global_coordinate_manager() \
+                if _operation_mode == SparseTensorOperationMode.SHARE_COORDINATE_MANAGER else None
             if coordinate_manager is None:
                 coordinate_manager = CoordinateManager()
                 if _operation_mode == SparseTensorOperationMode.SHARE_COORDINATE_MANAGER:
