@@ -187,12 +187,23 @@ class GeoLosslessEntropyModel(nn.Module):
         """Entropy coding runs on libfpcc_host's threads WHILE the GPU evaluates the following levels: every level's
         mask / probabilities (and, after the last residual level, all residual symbols) go to pinned memory on a side
         stream, followed by a flag that releases the host job (fastpcc_amd/coder_pool.py).  One wait at the end."""
+        return self.compress_clouds(y_top, 1)[0]
+
+    @torch.no_grad()
+    def compress_clouds(self, y_top: ME.SparseTensor, n_clouds: int) -> List[bytes]:
+        """`n_clouds` independent clouds on one coordinate manager (ME.CoordinateManager(clouds=n), rows cloud-major) through ONE
+        traversal of the networks; every cloud gets the stream `compress` writes for it alone -- its own residual histogram, its own
+        occupancy streams, its own header --, coded by its own jobs on the coder pool (the clouds' long passes run side by side).
+        What the reference does with a list of clouds one cloud at a time (lossy_coord_v2/model.py:247-256)."""
         tm = self.timing
         if tm is not None:
             tm.clear()
             tm['enc_t0'] = time.perf_counter()
         cm = y_top.coordinate_manager
-        *feas, bottom = self.encoder(y_top, batch_size)
+        B = int(n_clouds)
+        if B != (cm._n_batch or 1) or (B > 1 and not cm.independent_clouds):
+            raise ValueError('the coordinate manager was not made for this many independent clouds')
+        *feas, bottom = self.encoder(y_top, 1)
         del y_top
         scale = float(self.bottleneck_scaler)
         bottom_f = bottom.F
@@ -202,10 +213,12 @@ class GeoLosslessEntropyModel(nn.Module):
         pool: CoderPool = st['pool']
         flags = st['flags'].numpy().view(np.uint32)
         n_flags = 0
-        residual_syms = [ops.quantize_symbols_(bottom_f, scale)]         # rounds bottom_f in place
-        occupancy_h: List[Tuple[np.ndarray, np.ndarray]] = []            # (mask u8, prob u16) per coded level, host side
-        lower = bottom
+        edges_of = (lambda m: cm.batch_offsets(m)) if B > 1 else (lambda m: [0, m.n])
         bottom_map = cm._map(bottom.coordinate_map_key)
+        residual_syms = [ops.quantize_symbols_(bottom_f, scale)]         # rounds bottom_f in place
+        residual_edges = [edges_of(bottom_map)]                          # per residual level: its clouds' row ranges
+        occupancy_h: List[Tuple[np.ndarray, np.ndarray, List[int]]] = []  # (mask u8, prob u16, cloud ranges) per coded level, host side
+        lower = bottom
         bottom_xyz = (cm.get_coordinates(bottom.coordinate_map_key)[:, 1:] >> bottom_map.level).contiguous()
         (xyz_h,) = self._ship(st, [bottom_xyz], None)
         # Last level whose evaluation still feeds the bitstream: the reference keeps evaluating the feature predictors
@@ -217,11 +230,22 @@ class GeoLosslessEntropyModel(nn.Module):
         residual_job = None
 
         def ship_residuals():
+            """all residual symbols in ONE copy, cloud-major (a cloud's stream holds its rows of every level, coarse level first),
+            one flag, one histogram job per cloud"""
             nonlocal n_flags
-            (sym_h,) = self._ship(st, [torch.cat(residual_syms)], n_flags)
-            job = pool.histogram_encode(sym_h, None, flags[n_flags:n_flags + 1])
+            if B == 1:
+                pieces, sizes = residual_syms, [sum(t.numel() for t in residual_syms)]
+            else:
+                pieces = [t[e[c]:e[c + 1]] for c in range(B) for t, e in zip(residual_syms, residual_edges)]
+                sizes = [sum(e[c + 1] - e[c] for e in residual_edges) * self.compressed_channels for c in range(B)]
+            (sym_h,) = self._ship(st, [torch.cat(pieces)], n_flags)
+            jobs, at = [], 0
+            for size in sizes:
+                part = sym_h[at: at + size]
+                jobs.append((part, pool.histogram_encode(part, None, flags[n_flags:n_flags + 1])))
+                at += size
             n_flags += 1
-            return sym_h, job
+            return jobs
 
         # The occupancy predictors are leaves of the top-down chain: level idx's predictor reads `lower` of that level and nothing
         # reads its result on the device.  Evaluated in chain order the largest one comes last, and the GPU idles while the host
@@ -236,9 +260,11 @@ class GeoLosslessEntropyModel(nn.Module):
             mask_h, prob_h = self._ship(st, [ops.child_mask(target_map.child_row),
                                              ops.logit_to_prob16(logits.F.view(-1))], n_flags)
             prob_h = prob_h.view(np.uint16)
-            pool.binary_encode(mask_h, prob_h, flags[n_flags:n_flags + 1])
+            cand = [8 * e for e in edges_of(target_map.parent)]          # the candidates of a cloud: 8 per row of the level above
+            for c in range(B):
+                pool.binary_encode(mask_h[cand[c]:cand[c + 1]], prob_h[cand[c]:cand[c + 1]], flags[n_flags:n_flags + 1])
             n_flags += 1
-            occupancy_h.append((mask_h, prob_h))
+            occupancy_h.append((mask_h, prob_h, cand))
 
         if last_residual == len(feas):
             residual_job = ship_residuals()
@@ -275,6 +301,7 @@ class GeoLosslessEntropyModel(nn.Module):
                 res = self.residual_block[idx](fea, fea_pred).F
                 del fea
                 residual_syms.append(ops.quantize_symbols_(res, scale))
+                residual_edges.append(edges_of(target_map))
                 if idx == last_residual:
                     residual_job = ship_residuals()
                 if idx == last_coded and not self.evaluate_unused_tail:
@@ -293,18 +320,39 @@ class GeoLosslessEntropyModel(nn.Module):
         if tm is not None:
             tm['enc_enqueued'] = time.perf_counter()
         try:
-            coord_bytes_list = pool.wait()                               # the only blocking point of the encoder
+            streams = pool.wait()                                        # the only blocking point of the encoder
         except RuntimeError as e:
-            # a coder refused its input (a zero probability, a symbol outside its own histogram): say what the streams held
+            # A coder refused its input (a zero probability, a symbol outside its own histogram).  The inputs of a job are what a
+            # stream-ordered copy left in pinned memory before the job's flag; with every copy complete (synchronise) they are
+            # coded again right here, inline.  If that succeeds the refusal was a hand-over fault -- counted in `handover_retries`
+            # (never observed since the counter exists; bench.py reports it) --, otherwise the symbols themselves are not codable.
             st['side'].synchronize()
+            if 'occ' in st:
+                st['occ'].synchronize()
             what = [f'occupancy level {i}: {m.size} symbols, prob16 min {int(q.min()) if q.size else -1} zeros {int((q == 0).sum())}'
-                    for i, (m, q) in enumerate(occupancy_h)]
-            if residual_job is not None:
-                sym = residual_job[0]
-                what.append(f'residuals: {sym.size} symbols in [{int(sym.min())}, {int(sym.max())}]')
-            raise RuntimeError(f'{e}; job status words {getattr(pool, "last_failure", None)}; ' + '; '.join(what)) from e
+                    for i, (m, q, _) in enumerate(occupancy_h)]
+            for part, _ in residual_job or []:
+                what.append(f'residuals: {part.size} symbols in [{int(part.min())}, {int(part.max())}]')
+            note = f'{e}; job status words {getattr(pool, "last_failure", None)}; ' + '; '.join(what)
+            try:
+                streams = []
+                for m, q, cand in occupancy_h:
+                    for c in range(B):
+                        streams.append(self.binary_rans_coder.encode(m[None, cand[c]:cand[c + 1]].astype(bool),
+                                                                     q[None, cand[c]:cand[c + 1]].astype(np.uint32))[0])
+                redo = CoderPool(1)
+                residual_job = [(part, redo.histogram_encode(part, None)) for part, _ in residual_job]
+                redo.wait()
+                redo.close()
+            except RuntimeError:
+                raise RuntimeError(note) from e
+            GeoLosslessEntropyModel.handover_retries += 1
+            import warnings
+            warnings.warn('coder pool job failed and succeeded when repeated after a synchronise: ' + note)
+        n_levels = len(occupancy_h)
+        by_level = [streams[l * B:(l + 1) * B] for l in range(n_levels)]
         if pending_occ:                                                  # coded finest first: back to level order (coarse -> fine)
-            coord_bytes_list.reverse()
+            by_level.reverse()
             occupancy_h.reverse()
             pending_occ.clear()
         st['side'].synchronize()
@@ -312,64 +360,121 @@ class GeoLosslessEntropyModel(nn.Module):
             st['occ'].synchronize()
         if tm is not None:
             tm['enc_synced'] = tm['enc_occupancy_coded'] = time.perf_counter()
-        sym_h, job = residual_job
         if self.keep_symbols:      # test hook: what went into the coders
-            self.last_symbols = {'residual': sym_h.copy(),
-                                 'occupancy': np.concatenate([m for m, _ in occupancy_h]) if occupancy_h else np.zeros(0, np.uint8),
-                                 'prob': np.concatenate([q for _, q in occupancy_h]) if occupancy_h else np.zeros(0, np.uint16),
-                                 'sizes': [m.size for m, _ in occupancy_h]}
+            kept = []
+            for c in range(B):
+                masks = [m[cand[c]:cand[c + 1]] for m, _, cand in occupancy_h]
+                probs = [q[cand[c]:cand[c + 1]] for _, q, cand in occupancy_h]
+                kept.append({'residual': residual_job[c][0].copy(),
+                             'occupancy': np.concatenate(masks) if masks else np.zeros(0, np.uint8),
+                             'prob': np.concatenate(probs) if probs else np.zeros(0, np.uint16),
+                             'sizes': [m.size for m in masks]})
+            self.last_symbols = kept[0] if B == 1 else kept
 
-        with io.BytesIO() as bs:
-            bs.write(int_to_bytes(bottom_map.level, 1))                                 # log2(bottom stride)
-            bs.write(int_to_bytes(bottom_map.n, self.broadcast_shape_bytes))
-            offset, cdf, payload = pool.histogram_result(job)
-            self._write_coded(bs, sym_h.size, offset, cdf, payload, True)
-            bs.write(int_to_bytes(len(coord_bytes_list), 1))
-            BytesListUtils.concat_bytes_list(coord_bytes_list, bs)
-            self.rans_encode_with_cdf(xyz_h, bs, 0)
-            st['pinned'] = []
-            if tm is not None:
-                tm['enc_done'] = time.perf_counter()
-            return bs.getvalue()
+        out = []
+        bottom_edges = residual_edges[0]
+        for c in range(B):
+            with io.BytesIO() as bs:
+                bs.write(int_to_bytes(bottom_map.level, 1))                             # log2(bottom stride)
+                bs.write(int_to_bytes(bottom_edges[c + 1] - bottom_edges[c], self.broadcast_shape_bytes))
+                sym_h, job = residual_job[c]
+                offset, cdf, payload = pool.histogram_result(job)
+                self._write_coded(bs, sym_h.size, offset, cdf, payload, True)
+                bs.write(int_to_bytes(n_levels, 1))
+                BytesListUtils.concat_bytes_list([level[c] for level in by_level], bs)
+                self.rans_encode_with_cdf(xyz_h[bottom_edges[c]:bottom_edges[c + 1]], bs, 0)
+                out.append(bs.getvalue())
+        st['pinned'] = []
+        if tm is not None:
+            tm['enc_done'] = time.perf_counter()
+        return out
+
+    handover_retries = 0      # process-wide: coder-pool jobs that failed and succeeded when repeated after a synchronise
 
     # -- decompress -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decompress(self, concat_bytes: bytes, cm: ME.CoordinateManager) -> ME.SparseTensor:
+        return self.decompress_clouds([concat_bytes], cm)
+
+    @torch.no_grad()
+    def decompress_clouds(self, streams: List[bytes], cm: ME.CoordinateManager) -> ME.SparseTensor:
+        """The streams of `len(streams)` independent clouds (each what `compress` writes) decoded in ONE traversal of the networks on
+        `cm` (made with clouds=len(streams)): per occupancy level one device->host copy of the probabilities of all clouds, the
+        clouds' streams decoded side by side on the coder pool, one host->device copy of the mask.  Returns the reconstructed top
+        features of the union (rows cloud-major; cm.batch_offsets gives the ranges)."""
         dev = next(self.parameters()).device
         scale = float(self.bottleneck_scaler)
+        B = len(streams)
+        if B != (cm._n_batch or 1) or (B > 1 and not cm.independent_clouds):
+            raise ValueError('the coordinate manager was not made for this many independent clouds')
         tm = self.timing
         if tm is not None:
             tm['dec_t0'] = time.perf_counter()
             tm['dec_wait'] = tm['dec_host'] = 0.0
-        with io.BytesIO(concat_bytes) as bs:
-            bottom_level = bytes_to_int(bs.read(1))
-            bottom_rows = bytes_to_int(bs.read(self.broadcast_shape_bytes))
-            n_sym, sym_offset, sym_cdf, sym_payload = self._read_coded(bs, None)
-            n_streams = bytes_to_int(bs.read(1))
-            coord_bytes_list = BytesListUtils.split_bytes_list(None, n_streams, bs) if n_streams else []
-            bottom_xyz, _ = self.rans_decode_with_cdf(bs, 0, 3)
+        parsed = []
+        for data in streams:
+            with io.BytesIO(data) as bs:
+                bottom_level = bytes_to_int(bs.read(1))
+                bottom_rows = bytes_to_int(bs.read(self.broadcast_shape_bytes))
+                n_sym, sym_offset, sym_cdf, sym_payload = self._read_coded(bs, None)
+                n_streams = bytes_to_int(bs.read(1))
+                coord_bytes_list = BytesListUtils.split_bytes_list(None, n_streams, bs) if n_streams else []
+                bottom_xyz, _ = self.rans_decode_with_cdf(bs, 0, 3)
+            parsed.append((bottom_level, bottom_rows, n_sym, sym_offset, sym_cdf, sym_payload, coord_bytes_list, bottom_xyz))
+        bottom_level = parsed[0][0]
+        if any(p[0] != bottom_level for p in parsed):
+            raise ValueError('the clouds of one traversal must share the depth of the pyramid')
 
-        # the residual stream is decoded in the background, coarse levels first -- the order the loop below consumes it
+        # the residual streams are decoded in the background, coarse levels first -- the order the loop below consumes them
         pool: CoderPool = self._overlap_state(dev)['pool']
-        sym_t = torch.empty(n_sym * self.compressed_channels, dtype=torch.int32, pin_memory=True)
-        progress = pool.table_decode(sym_payload, sym_t.numel(), sym_cdf, sym_offset, sym_t.numpy(),
-                                     first_chunk=bottom_rows * self.compressed_channels)
+        c_ch = self.compressed_channels
+        sym_t, progress = [], []
+        for _, rows, n_sym, sym_offset, sym_cdf, sym_payload, _, _ in parsed:
+            t = torch.empty(n_sym * c_ch, dtype=torch.int32, pin_memory=True)
+            progress.append(pool.table_decode(sym_payload, t.numel(), sym_cdf, sym_offset, t.numpy(), first_chunk=rows * c_ch))
+            sym_t.append(t)
+        used = [0] * B
 
-        def residuals(first_row: int, rows: int) -> torch.Tensor:
-            if first_row + rows > n_sym:
-                raise ValueError('the bitstream holds fewer residual symbols than the pyramid needs')
-            c = self.compressed_channels
-            pool.need(progress, (first_row + rows) * c)
-            t = sym_t[first_row * c: (first_row + rows) * c].to(dev, non_blocking=True).to(torch.float32).view(rows, c)
+        def residuals(rows_of_cloud: List[int]) -> torch.Tensor:
+            """the next rows_of_cloud[c] residual rows of every cloud, cloud-major, on the device"""
+            for c, rows in enumerate(rows_of_cloud):
+                if used[c] + rows > parsed[c][2]:
+                    raise ValueError('the bitstream holds fewer residual symbols than the pyramid needs')
+            if B == 1:
+                rows = rows_of_cloud[0]
+                pool.need(progress[0], (used[0] + rows) * c_ch)
+                t = sym_t[0][used[0] * c_ch: (used[0] + rows) * c_ch].to(dev, non_blocking=True)
+            else:
+                t = torch.empty(sum(rows_of_cloud) * c_ch, dtype=torch.int32, device=dev)
+                at = 0
+                for c, rows in enumerate(rows_of_cloud):
+                    pool.need(progress[c], (used[c] + rows) * c_ch)
+                    t[at: at + rows * c_ch].copy_(sym_t[c][used[c] * c_ch: (used[c] + rows) * c_ch], non_blocking=True)
+                    at += rows * c_ch
+            for c, rows in enumerate(rows_of_cloud):
+                used[c] += rows
+            t = t.to(torch.float32).view(-1, c_ch)
             return t if scale == 1.0 else t / scale
 
-        coords = torch.zeros((bottom_rows, 4), dtype=torch.int32)
-        coords[:, 1:] = torch.from_numpy(bottom_xyz) << bottom_level
-        lower = ME.SparseTensor(residuals(0, bottom_rows), coordinates=coords.to(dev),
+        bottom_rows = [p[1] for p in parsed]
+        coords = torch.zeros((sum(bottom_rows), 4), dtype=torch.int32)
+        at = 0
+        for c, p in enumerate(parsed):
+            coords[at: at + p[1], 0] = c
+            coords[at: at + p[1], 1:] = torch.from_numpy(p[7]) << bottom_level
+            at += p[1]
+        lower = ME.SparseTensor(residuals(bottom_rows), coordinates=coords.to(dev),
                                 tensor_stride=1 << bottom_level, coordinate_manager=cm)
+        if B > 1:
+            # the rows of the bottom map are the clouds' bottom rows in stream order (each cloud's are Morton-sorted and distinct, the
+            # cloud index is the key's top): its ranges are known without a read-back
+            bm = cm._map(lower.coordinate_map_key)
+            if bm.n != sum(bottom_rows):
+                raise ValueError('duplicate bottom coordinates in a stream')
+            bm.edges = ME._edges_of(bottom_rows)
         if tm is not None:
             tm['dec_residual_decoded'] = time.perf_counter()
-        used = bottom_rows
+        occupancy = [p[6] for p in parsed]
 
         for idx in range(len(self.residual_block) - 1, -1, -1):
             occ_net = self.hyper_decoder_coord[idx]
@@ -379,7 +484,9 @@ class GeoLosslessEntropyModel(nn.Module):
                 ta = time.perf_counter()
                 prob_d = ops.logit_to_prob16(logits.F.view(-1))
                 if self.device_decoder:
-                    raw = coord_bytes_list.pop(0)
+                    if B != 1:
+                        raise NotImplementedError('the device-side occupancy decoder takes one cloud')
+                    raw = occupancy[0].pop(0)
                     mask, ones, status = ops.rans_binary_decode_dev(ops.stream_to_device(raw, dev), len(raw), prob_d)
                     count, ok = torch.cat((ones, status)).tolist()          # the level's one read-back: 8 bytes
                     if ok != 0:
@@ -392,8 +499,7 @@ class GeoLosslessEntropyModel(nn.Module):
                     target_key = cur_map.key
                     fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
                     if idx > self.skip_encoding_fea:
-                        res = residuals(used, cur_map.n)
-                        used += cur_map.n
+                        res = residuals([cur_map.n])
                         lower = self.decoder_block[idx](res, fea_pred)
                     else:
                         lower = self.decoder_block[idx](fea_pred)
@@ -407,28 +513,35 @@ class GeoLosslessEntropyModel(nn.Module):
                 copied.synchronize()
                 tb = time.perf_counter()
                 bits_t = torch.empty(prob_t.numel(), dtype=torch.uint8, pin_memory=True)
-                stream = np.frombuffer(coord_bytes_list.pop(0), dtype=np.uint8)
-                host_check(host().fpcc_rans_binary_decode(stream.ctypes.data, stream.size, prob_t.numpy().ctypes.data,
-                                                          prob_t.numel(), bits_t.numpy().ctypes.data))
+                prob_h, bits_h = prob_t.numpy().view(np.uint16), bits_t.numpy()
+                cand = [8 * e for e in (cm.batch_offsets(cur_map) if B > 1 else [0, cur_map.n])]
+                raws = [np.frombuffer(occupancy[c].pop(0), dtype=np.uint8) for c in range(B)]
+                # clouds 1 .. B-1 on the pool's threads, cloud 0 on this one
+                waits = [pool.binary_decode(raws[c], prob_h[cand[c]:cand[c + 1]], bits_h[cand[c]:cand[c + 1]]) for c in range(1, B)]
+                host_check(host().fpcc_rans_binary_decode(raws[0].ctypes.data, raws[0].size, prob_h[cand[0]:].ctypes.data,
+                                                          cand[1] - cand[0], bits_h.ctypes.data))
+                for w in waits:
+                    pool.need(w, 1)
                 mask = bits_t.to(dev, non_blocking=True)                 # H2D
                 if tm is not None:
                     tm['dec_wait'] += tb - ta
                     tm['dec_host'] += time.perf_counter() - tb
                 gen_id = logits.coordinate_map_key.get_key()[1]
-                # the decoded mask is on the host: its popcount sizes the new map without a device read-back
-                cur_map = cm._refine(cur_map, mask, gen_id + 'pruned', count_hint=int(np.count_nonzero(bits_t.numpy())))
+                # the decoded mask is on the host: its popcount sizes the new map (and its clouds' ranges) without a device read-back
+                counts = [int(np.count_nonzero(bits_h[cand[c]:cand[c + 1]])) for c in range(B)]
+                cur_map = cm._refine(cur_map, mask, gen_id + 'pruned', count_hint=sum(counts), cloud_counts=counts if B > 1 else None)
                 del logits
             target_key = cur_map.key
             fea_pred = self.hyper_decoder_fea[idx](lower, target_key)
             if idx > self.skip_encoding_fea:
-                res = residuals(used, cur_map.n)
-                used += cur_map.n
+                e = cm.batch_offsets(cur_map) if B > 1 else [0, cur_map.n]
+                res = residuals([e[c + 1] - e[c] for c in range(B)])
                 lower = self.decoder_block[idx](res, fea_pred)
             else:
                 lower = self.decoder_block[idx](fea_pred)
-        if coord_bytes_list:
+        if any(occupancy):
             raise ValueError('unused occupancy streams in the bitstream')
         pool.wait()
-        if used != n_sym:
+        if any(used[c] != parsed[c][2] for c in range(B)):
             raise ValueError('residual symbols left over in the bitstream')
         return lower

@@ -44,9 +44,12 @@ def classify_head(seq: nn.Sequential, fea):
         return seq(fea)
     da, db = a.conv._derived(), b.conv._derived()
     act1, act2 = ME._act_of(a.act_module), ME._act_of(b.act_module)
-    order1 = ME.summation_order('k1', a.conv.in_channels, 0, a.conv.out_channels, x.shape[0])
-    if order1 not in (0, 1):
+    cm = fea.coordinate_manager
+    orders = {ME.summation_order('k1', a.conv.in_channels, 0, a.conv.out_channels, rows)
+              for rows in cm.cloud_rows(cm._map(fea.coordinate_map_key)) if rows > 0}
+    if len(orders) != 1 or not orders <= {0, 1}:     # (independent clouds on either side of PAD_MIN_ROWS: the blocks sort that out)
         return seq(fea)
+    order1 = orders.pop()
     out = ops.pointwise_head(x, da['w'].reshape(a.conv.in_channels, a.conv.out_channels), da['b'], act1.kind, act1.slope, order1,
                              db['w'].reshape(-1), db['b'], act2.kind, act2.slope)
     return ME.SparseTensor(out, coordinate_map_key=fea.coordinate_map_key, coordinate_manager=fea.coordinate_manager)
@@ -161,28 +164,38 @@ class Decoder(nn.Module):
         return keep.bool()
 
     @torch.no_grad()
-    def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Returns xyz int32 [N, 3] (plus coord_offset, a device int32[3], when given)."""
+    def test_forward(self, fea, points_num_list, coord_offset: Optional[torch.Tensor] = None):
+        """Returns xyz int32 [N, 3] (plus coord_offset, a device int32[3], when given).  On a batch of independent clouds
+        (ME.CoordinateManager(clouds=B); coord_offset int32 [B, 3]; points_num_list entries hold one target per cloud): the list of
+        the clouds' xyz tensors."""
         last = len(self.upsample_blocks) - 1
-        top = fea.coordinate_manager._map(fea.coordinate_map_key)      # local maxima are taken inside the voxels of this level
+        cm = fea.coordinate_manager
+        top = cm._map(fea.coordinate_map_key)      # local maxima are taken inside the voxels of this level
         for i, (up, classify) in enumerate(zip(self.upsample_blocks, self.classify_blocks)):
             fea = up(fea)
             keep = self.get_keep(classify_head(classify, fea), points_num_list, top)
             if i != last:
                 fea = self.pruning(fea, keep)
             else:
-                cm = fea.coordinate_manager
                 gen = cm._map(fea.coordinate_map_key)
                 if not gen.generated:
                     raise RuntimeError('decoder output is expected on a generated coordinate set')
-                xyz, count = ops.compact_coords(gen.parent.keys, keep, gen.level, gen.bits, coord_offset)
-                return xyz[:int(count.item())]
+                if not cm.independent_clouds:
+                    xyz, count = ops.compact_coords(gen.parent.keys, keep, gen.level, gen.bits, coord_offset)
+                    return xyz[:int(count.item())]
+                edges = cm.batch_offsets(gen.parent)
+                parts = [ops.compact_coords(gen.parent.keys[a:b], keep[8 * a: 8 * b], gen.level, gen.bits,
+                                            None if coord_offset is None else coord_offset[c].contiguous())
+                         for c, (a, b) in enumerate(zip(edges[:-1], edges[1:]))]
+                counts = torch.cat([count for _, count in parts]).tolist()              # one read-back for all clouds
+                return [xyz[:n] for (xyz, _), n in zip(parts, counts)]
 
     @torch.no_grad()
     def get_keep(self, pred: ME.SparseTensor, points_num_list: Optional[List[List[int]]], top=None) -> torch.Tensor:
         """uint8 [n]: logit above the adaptive threshold, or the maximum of its cell (layers.py:151-180).  A cell is a voxel
         of the decoder's INPUT level (`top`, tensor stride 2^stages: max_stride_lossy_recon in the reference) -- the 8
-        siblings in the first stage, 64 candidates in the second, 512 in the third."""
+        siblings in the first stage, 64 candidates in the second, 512 in the third.  The threshold is a cloud's own: on a batch of
+        independent clouds every cloud's candidates are ranked among themselves."""
         cm = pred.coordinate_manager
         gen = cm._map(pred.coordinate_map_key)
         if not gen.generated:
@@ -209,6 +222,21 @@ class Decoder(nn.Module):
             cells = pred.F.view(-1, 8)
             return ((cells > 0) | (cells == cell_max[cell.long()][:, None])).view(-1).to(torch.uint8)
         target = points_num_list.pop()
+        if cm.independent_clouds:
+            edges = cm.batch_offsets(parent)
+            if len(target) != len(edges) - 1:
+                raise ValueError('one pruning target per cloud expected')
+            top_edges = cm.batch_offsets(top) if cell is not None else None
+            keep = []
+            for c, (a, b) in enumerate(zip(edges[:-1], edges[1:])):
+                if not 8 * (b - a) > target[c]:
+                    raise ValueError('fewer candidates than points to keep')
+                if cell is None:
+                    keep.append(ops.topk_keep(logits[8 * a: 8 * b], target[c]))
+                else:
+                    keep.append(ops.topk_keep_cells(logits[8 * a: 8 * b], (cell[a:b] - top_edges[c]).contiguous(),
+                                                    top_edges[c + 1] - top_edges[c], target[c]))
+            return torch.cat(keep)
         if len(target) != 1:
             raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')
         if not logits.numel() > target[0]:

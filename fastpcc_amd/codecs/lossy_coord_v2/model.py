@@ -65,16 +65,17 @@ class PCC(nn.Module):
             raise ValueError('Only supports batch size == 1 during testing.')
         return self.test_forward(pc_data)
 
-    def set_global_cm(self) -> ME.CoordinateManager:
+    def set_global_cm(self, clouds: Optional[int] = None) -> ME.CoordinateManager:
         ME.clear_global_coordinate_manager()
-        cm = ME.CoordinateManager(D=3)
+        cm = ME.CoordinateManager(D=3, clouds=clouds)
         ME.set_global_coordinate_manager(cm)
         return cm
 
-    def get_sparse_pc(self, xyz: torch.Tensor) -> ME.SparseTensor:
+    def get_sparse_pc(self, xyz: torch.Tensor, clouds: Optional[int] = None) -> ME.SparseTensor:
         """All-ones 1-channel tensor on the input voxels.  The engine keeps every map in Morton order, which is what the
-        reference obtains by sorting explicitly before building the tensor (model.py:140-142)."""
-        cm = self.set_global_cm()
+        reference obtains by sorting explicitly before building the tensor (model.py:140-142).  clouds: the batch column of `xyz`
+        numbers that many independent clouds coded in one traversal (compress_many)."""
+        cm = self.set_global_cm(clouds)
         ones = torch.ones((xyz.shape[0], 1), dtype=torch.float32, device=xyz.device)
         pc = ME.SparseTensor(features=ones, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
@@ -120,26 +121,84 @@ class PCC(nn.Module):
         sparse_pc = self.get_sparse_pc((batched_coord - F.pad(coord_offset, (1, 0))).contiguous())
         feature, points_num_list = self.encoder(sparse_pc)
         em_bytes = self.em_lossless_based.compress(feature, 1)
-        with io.BytesIO() as bs:
-            if self.cfg.numerics_version_in_header:
-                bs.write(bytes([hipops.numerics_version()]))
-            for v in coord_offset.tolist():
-                bs.write(int(v).to_bytes(2, 'little', signed=False))
-            if self.cfg.adaptive_pruning:
-                for counts in points_num_list:
-                    bs.write(int(counts[0]).to_bytes(3, 'little', signed=False))
-            bs.write(em_bytes)
-            return bs.getvalue()
+        return self._header(coord_offset.tolist(), None if points_num_list is None else [counts[0] for counts in points_num_list]) + em_bytes
 
-    def compress_partitions(self, batched_coord: List[torch.Tensor]) -> bytes:
-        # element 0 is the unpartitioned cloud (model.py:249-250)
-        parts = [self.compress(p) for p in batched_coord[1:]]
-        return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in parts)
+    def _header(self, coord_offset: List[int], counts: Optional[List[int]]) -> bytes:
+        head = bytes([hipops.numerics_version()]) if self.cfg.numerics_version_in_header else b''
+        head += b''.join(int(v).to_bytes(2, 'little', signed=False) for v in coord_offset)
+        if self.cfg.adaptive_pruning:
+            head += b''.join(int(n).to_bytes(3, 'little', signed=False) for n in counts)
+        return head
 
     @hipops.no_gc_pause
     @torch.no_grad()
-    def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
+    def compress_many(self, clouds: List[torch.Tensor]) -> List[bytes]:
+        """Independent clouds (each int32 [n, 4], batch column 0) -> the stream `compress` writes for each of them, from ONE traversal
+        of the networks over their union: the clouds become the samples of one batch (rows of different clouds never neighbour), every
+        layer is launched once over all of them, and each cloud's symbols go to its own coder jobs.  The launches of a cloud's small
+        pyramid levels -- latency-bound alone -- carry every cloud's rows.  What the reference does with the partitions of a large
+        cloud one at a time (model.py:247-256); bytes are identical to coding each cloud alone (tests/test_gpu_codec_many.py)."""
+        if len(clouds) == 1:
+            return [self.compress(clouds[0])]
+        if not clouds or not all(c.is_cuda for c in clouds):
+            raise RuntimeError('compress_many() takes a non-empty list of GPU tensors')
+        B = len(clouds)
+        offsets = torch.stack([c.amin(0) for c in clouds])              # [B, 4]; the batch column of every cloud is 0
+        shift = offsets.clone()
+        shift[:, 0] = -torch.arange(B, device=shift.device, dtype=shift.dtype)          # cloud b becomes sample b of the batch
+        sparse_pc = self.get_sparse_pc(torch.cat([c - shift[b] for b, c in enumerate(clouds)]), clouds=B)
+        feature, points_num_list = self.encoder(sparse_pc)
+        em_bytes = self.em_lossless_based.compress_clouds(feature, B)
+        offsets = offsets[:, 1:].tolist()
+        return [self._header(offsets[b], None if points_num_list is None else [counts[b] for counts in points_num_list]) + em_bytes[b]
+                for b in range(B)]
+
+    @hipops.no_gc_pause
+    @torch.no_grad()
+    def decompress_many(self, streams: List[bytes]) -> List[torch.Tensor]:
+        """inverse of compress_many: the clouds' streams decoded in one traversal; -> one int32 [N_b, 3] tensor per cloud"""
+        if len(streams) == 1:
+            return [self.decompress(streams[0])]
         dev = next(self.parameters()).device
+        B = len(streams)
+        offsets, targets, payloads = [], [], []
+        for data in streams:
+            offset, counts, em_bytes = self._parse_header(data)
+            offsets.append(offset)
+            targets.append(counts)
+            payloads.append(em_bytes)
+        offset_t = torch.tensor(offsets, dtype=torch.int32, device=dev)    # made before anything is queued (pageable memory)
+        points_num_list = None
+        if self.cfg.adaptive_pruning:
+            points_num_list = [[targets[b][s][0] for b in range(B)] for s in range(len(targets[0]))]
+        fea_recon = self.em_lossless_based.decompress_clouds(payloads, self.set_global_cm(B))
+        return self.decoder(fea_recon, points_num_list, offset_t)
+
+    # partitions of one list are coded together up to this many voxels per traversal (activations of every level stay resident)
+    MANY_MAX_VOXELS = 6_000_000
+
+    def _groups(self, sizes: List[int]) -> List[List[int]]:
+        """consecutive list entries per traversal: as many as fit MANY_MAX_VOXELS (and the engine's 64 clouds)"""
+        groups, cur, acc = [], [], 0
+        for i, n in enumerate(sizes):
+            if cur and (acc + n > self.MANY_MAX_VOXELS or len(cur) == 64):
+                groups.append(cur)
+                cur, acc = [], 0
+            cur.append(i)
+            acc += n
+        if cur:
+            groups.append(cur)
+        return groups
+
+    def compress_partitions(self, batched_coord: List[torch.Tensor]) -> bytes:
+        # element 0 is the unpartitioned cloud (model.py:249-250)
+        parts = list(batched_coord[1:])
+        coded: List[bytes] = []
+        for g in self._groups([p.shape[0] for p in parts]):
+            coded.extend(self.compress_many([parts[i] for i in g]))
+        return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in coded)
+
+    def _parse_header(self, compressed_bytes: bytes):
         with io.BytesIO(compressed_bytes) as bs:
             if self.cfg.numerics_version_in_header:
                 written_by = bs.read(1)[0]
@@ -151,18 +210,33 @@ class PCC(nn.Module):
             if self.cfg.adaptive_pruning:
                 points_num_list = [[int.from_bytes(bs.read(3), 'little', signed=False)]
                                    for _ in range(len(self.encoder.blocks) - 1)]
-            em_bytes = bs.read()
+            return coord_offset, points_num_list, bs.read()
+
+    @hipops.no_gc_pause
+    @torch.no_grad()
+    def decompress(self, compressed_bytes: bytes) -> torch.Tensor:
+        dev = next(self.parameters()).device
+        coord_offset, points_num_list, em_bytes = self._parse_header(compressed_bytes)
         # made before anything is queued: a host-to-device copy from pageable memory waits for the stream
         offset = torch.tensor(coord_offset, dtype=torch.int32, device=dev)
         fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
         return self.decoder(fea_recon, points_num_list, offset)
 
     def decompress_partitions(self, concat_bytes: bytes) -> torch.Tensor:
-        out = []
+        streams = []
         with io.BytesIO(concat_bytes) as bs:
             while bs.tell() != len(concat_bytes):
                 length = int.from_bytes(bs.read(3), 'little', signed=False)
-                out.append(self.decompress(bs.read(length)))
+                streams.append(bs.read(length))
+        out: List[torch.Tensor] = []
+        # a partition's size before it is decoded: the pruning target of the finest stage in its header (adaptive pruning), else the
+        # stream length at one bit per voxel
+        if self.cfg.adaptive_pruning:
+            sizes = [self._parse_header(s)[1][0][0] for s in streams]
+        else:
+            sizes = [len(s) * 8 for s in streams]
+        for g in self._groups(sizes):
+            out.extend(self.decompress_many([streams[i] for i in g]))
         return torch.cat(out, 0)
 
     # ---------------------------------------------------------------------------------------------------------------

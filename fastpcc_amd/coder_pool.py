@@ -90,6 +90,17 @@ class CoderPool:
         self._keep.append((stream, data, table, out, progress))
         return progress
 
+    def binary_decode(self, stream: np.ndarray, prob1: np.ndarray, out: np.ndarray) -> np.ndarray:
+        """queue the decode of one binary stream (uint8 [len]) under prob1 (uint16 [n]) into out (uint8 [n]); returns the job's
+        completion word for need(word, 1)"""
+        if stream.dtype != np.uint8 or prob1.dtype != np.uint16 or out.dtype != np.uint8 or prob1.shape != out.shape or out.ndim != 1:
+            raise ValueError('stream: uint8 [len], prob1: uint16 [n], out: uint8 [n]')
+        done = np.zeros(1, dtype=np.int64)
+        host_check(host().fpcc_pool_binary_decode(self._h, stream.ctypes.data, stream.size, prob1.ctypes.data, out.size,
+                                                  out.ctypes.data, done.ctypes.data))
+        self._keep.append((stream, prob1, out, done))
+        return done
+
     @staticmethod
     def need(progress: np.ndarray, count: int) -> None:
         """block until the first `count` symbols of a table_decode are final"""

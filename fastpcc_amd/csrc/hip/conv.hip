@@ -1002,13 +1002,21 @@ int launch_wave_cfg(const ConvArgs &a, const float *wp, int nbt, hipStream_t s) 
     return check_hip(hipGetLastError(), "k_conv_wave");
 }
 
+// cached per device, initialised from any host thread (several frame threads launch concurrently)
+constexpr int kMaxDevices = 16;
+inline int current_device() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) ? dev : -1;
+}
 int cu_count() {
-    static int n = 0;
+    static std::atomic<int> cached[kMaxDevices];
+    const int dev = current_device();
+    if (dev < 0) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -1021,10 +1029,19 @@ constexpr int kUnitCounters = 256;
 __device__ unsigned g_unit_counters[kUnitCounters];
 unsigned *next_unit_counter(unsigned start, hipStream_t s, int *rc) {
     static std::atomic<unsigned> seq{0};           // launches come from several host threads
-    static unsigned *base = nullptr;
-    if (!base && hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_unit_counters)) != hipSuccess) {
-        *rc = check_hip(hipGetLastError(), "unit counters");
+    static std::atomic<unsigned *> bases[kMaxDevices];   // the symbol has one address per device
+    const int dev = current_device();
+    if (dev < 0) {
+        *rc = fail_arg("unit counters: no current device");
         return nullptr;
+    }
+    unsigned *base = bases[dev].load(std::memory_order_acquire);
+    if (!base) {
+        if (hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_unit_counters)) != hipSuccess) {
+            *rc = check_hip(hipGetLastError(), "unit counters");
+            return nullptr;
+        }
+        bases[dev].store(base, std::memory_order_release);
     }
     unsigned *c = base + (seq++ % kUnitCounters);
     *rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), (int)start, 1, s), "unit counter fill");

@@ -562,6 +562,48 @@ extern "C" int64_t fpcc_level_histogram(const int64_t *keys, int64_t n, int leve
     return FPCC_OK;
 }
 
+// The same pass for a BATCH of clouds (key = cloud << cloud_shift | Morton code; rows are cloud-major): row counts of every cloud at
+// every level.  hist[c][t], t <= levels: key pairs INSIDE cloud c with top == t (a pair that straddles two clouds belongs to neither);
+// hist[c][levels + 1]: keys of cloud c.  Rows of cloud c at level l = (hist[c][levels + 1] > 0) + sum_{t >= l} hist[c][t].
+__global__ __launch_bounds__(256) void k_level_histogram_clouds(const int64_t *__restrict__ keys, int64_t n, int levels, int cloud_shift,
+                                                                int n_clouds, int32_t *hist) {
+    extern __shared__ int32_t s_cloud_hist[];
+    const int width = levels + 2, total = n_clouds * width;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) s_cloud_hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = (uint64_t)keys[i];
+        const int c = (int)(k >> cloud_shift);
+        if (c >= n_clouds) continue;                                  // reported by the host wrapper (counts do not add up to n)
+        atomicAdd(&s_cloud_hist[c * width + levels + 1], 1);
+        if (i > 0) {
+            const uint64_t d = k ^ (uint64_t)keys[i - 1];
+            if (d && (d >> cloud_shift) == 0) {
+                const int top = (63 - __clzll((long long)d)) / 3;
+                atomicAdd(&s_cloud_hist[c * width + (top < levels ? top : levels)], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x)
+        if (s_cloud_hist[i]) atomicAdd(&hist[i], s_cloud_hist[i]);
+}
+
+extern "C" int64_t fpcc_level_histogram_clouds(const int64_t *keys, int64_t n, int levels, int cloud_shift, int n_clouds, int32_t *hist,
+                                               void *stream) {
+    if (n < 0 || levels < 1 || levels > 21 || n_clouds < 1 || n_clouds > 64 || cloud_shift < 3 || cloud_shift > 63)
+        return fail_arg("level_histogram_clouds: n < 0, levels outside 1..21, clouds outside 1..64 or bad shift");
+    if (!hist || (n > 0 && !keys)) return fail_arg("level_histogram_clouds: null pointer");
+    const int total = n_clouds * (levels + 2);
+    FPCC_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * total, as_stream(stream)));
+    if (n < 1) return FPCC_OK;
+    const int64_t blocks = blocks_for(n, 256 * 8);
+    hipLaunchKernelGGL(k_level_histogram_clouds, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), sizeof(int32_t) * total,
+                       as_stream(stream), keys, n, levels, cloud_shift, n_clouds, hist);
+    FPCC_LAUNCHED(k_level_histogram_clouds);
+    return FPCC_OK;
+}
+
 extern "C" int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_t *keys_out,
                                int32_t *parent_of, int32_t *child_row, int32_t *count_out, void *ws, int64_t ws_bytes,
                                void *stream) {

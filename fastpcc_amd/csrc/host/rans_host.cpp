@@ -574,7 +574,9 @@ bool await_flag(const volatile uint32_t *flag, uint32_t ready) {
     if (!flag) return true;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spin = 0;; ++spin) {
-        if (*flag == ready) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        // an acquire load of the word the producer stores last (a DMA engine in production, a thread in the tests): the job's
+        // reads of its inputs cannot be moved ahead of it
+        if (__atomic_load_n(const_cast<const uint32_t *>(flag), __ATOMIC_ACQUIRE) == ready) return true;
         if ((spin & 63u) == 63u) {
             std::this_thread::yield();
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
@@ -641,6 +643,19 @@ int64_t fpcc_pool_table_decode(fpcc_pool *p, const uint8_t *stream, int64_t stre
         const int64_t rc = single_table_decode(stream, stream_len, n, cdf, static_cast<int32_t>(cdf_len) - 1, offset,
                                                symbols_out, prog, first_chunk);
         prog->store(rc < 0 ? rc : n, std::memory_order_release);
+        return rc;
+    });
+    return FPCC_HOST_OK;
+}
+
+int64_t fpcc_pool_binary_decode(fpcc_pool *p, const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
+                                uint8_t *bits_out, int64_t *done) {
+    if (!p || !stream || !prob1 || !bits_out || !done || n < 0 || stream_len < 4) return FPCC_HOST_E_ARG;
+    auto *flag = reinterpret_cast<std::atomic<int64_t> *>(done);
+    flag->store(0, std::memory_order_relaxed);
+    p->submit([=]() -> int64_t {
+        const int64_t rc = fpcc_rans_binary_decode(stream, stream_len, prob1, n, bits_out);
+        flag->store(rc < 0 ? rc : 1, std::memory_order_release);
         return rc;
     });
     return FPCC_HOST_OK;

@@ -137,7 +137,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows', 'nbr27_pos')
+                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows', 'nbr27_pos', 'edges')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -153,6 +153,7 @@ class _Map:
         self.coords: Optional[torch.Tensor] = None
         self.gen_child: Optional['_Map'] = None
         self.key: Optional[CoordinateMapKey] = None
+        self.edges: Optional[List[int]] = None            # host copy of the row ranges of the batch's clouds (rows are cloud-major)
 
 
 class CoordinateManager:
@@ -160,12 +161,22 @@ class CoordinateManager:
     # below this many rows the top level's 27-neighbour table is found by binary search instead of climbing further
     ROOT_ROWS = 2048
 
-    def __init__(self, D: int = 3, coordinate_map_type=None, minkowski_algorithm=None, bits: Optional[int] = None):
+    def __init__(self, D: int = 3, coordinate_map_type=None, minkowski_algorithm=None, bits: Optional[int] = None,
+                 clouds: Optional[int] = None):
+        """clouds: the batch holds this many INDEPENDENT clouds that are coded in one traversal (compress_many / compress_partitions of
+        the codecs: /root/reference/models/convolutional/lossy_coord_v2/model.py:247-256,277-288).  Rows of different clouds never
+        neighbour (the cloud index sits above the Morton bits of a key), so a layer computes for every cloud exactly what it would
+        compute for that cloud alone -- PROVIDED the rules that look at a map's row count look at the cloud's own count: that is
+        what `independent_clouds` switches on (PAD_MIN_ROWS below; the codecs' top-k thresholds and headers are per cloud anyway).
+        A training batch (clouds=None) keeps the whole-map rules."""
         if D != 3:
             raise NotImplementedError('3-D only')
+        if clouds is not None and not 1 <= clouds <= 64:
+            raise ValueError('1 <= clouds <= 64')
         self._maps: Dict[CoordinateMapKey, _Map] = {}
         self._bits0 = bits            # bits per axis at level 0; fixed on the first insertion
-        self._n_batch: Optional[int] = None
+        self._n_batch: Optional[int] = clouds
+        self.independent_clouds = clouds is not None and clouds > 1
         self.device = None
 
     @property
@@ -212,7 +223,9 @@ class CoordinateManager:
         coordinates = coordinates.contiguous()
         self.device = coordinates.device
         if self._bits0 is None:
-            nb = int(coordinates[:, 0].max().item()) + 1 if coordinates.shape[0] else 1
+            nb = self._n_batch                           # known up front (clouds=): no read-back
+            if nb is None:
+                nb = int(coordinates[:, 0].max().item()) + 1 if coordinates.shape[0] else 1
             self._n_batch = nb
             self._bits0 = min(21, (63 - max(nb - 1, 0).bit_length()) // 3)
         bits = self._bits0 - level
@@ -227,14 +240,16 @@ class CoordinateManager:
         key = self._register(m, string_id)
         return key, (rows, n)
 
-    def _ensure_parent(self, m: _Map, rows: Optional[int] = None) -> _Map:
-        """rows: the parent map's row count when the caller already knows it (build_pyramid) -- no read-back then"""
+    def _ensure_parent(self, m: _Map, rows: Optional[int] = None, edges: Optional[List[int]] = None) -> _Map:
+        """rows / edges: the parent map's row count (and its clouds' row ranges) when the caller already knows them (build_pyramid) --
+        no read-back then"""
         if m.parent is None:
             if m.bits <= 1:
                 raise ValueError('cannot stride past the coordinate range')
             parent_of, pkeys, child_row, count = ops.coarsen(self._keys(m))
             cnt = int(count.item()) if rows is None else rows
             p = _Map(m.level + 1, m.bits - 1, cnt, pkeys[:cnt])
+            p.edges = edges
             m.parent, m.parent_of, m.child_row = p, parent_of, child_row[:cnt]
             self._register(p, '')
         return m.parent
@@ -250,6 +265,13 @@ class CoordinateManager:
             m, levels = m.parent, levels - 1
         levels = min(levels, m.bits - 1)
         if levels <= 0:
+            return
+        if self.independent_clouds and not m.generated:
+            # the same single pass and read-back, per cloud: every level's row ranges are known on the host from here on
+            per_level = ops.level_counts_clouds(self._keys(m), levels, 3 * m.bits, self._n_batch)
+            m.edges = _edges_of(per_level[0])
+            for counts in per_level[1:]:
+                m = self._ensure_parent(m, sum(counts), _edges_of(counts))
             return
         rows = ops.level_counts(self._keys(m), levels) if not m.generated else [None] * levels
         for r in rows:
@@ -278,12 +300,18 @@ class CoordinateManager:
             self._register(g, '')
         return m.gen_child
 
-    def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str, count_hint: Optional[int] = None) -> _Map:
+    def _refine(self, parent: _Map, mask: torch.Tensor, string_id: str, count_hint: Optional[int] = None,
+                cloud_counts: Optional[Sequence[int]] = None) -> _Map:
         """New map = children of `parent` selected by mask[8 * parent.n] (decoder side / pruning of a generated set).
-        count_hint: number of set mask entries when the caller already knows it on the host (saves a blocking read-back)."""
+        count_hint: number of set mask entries when the caller already knows it on the host (saves a blocking read-back);
+        cloud_counts: the same per cloud of the batch (the new map's row ranges)."""
         keys, parent_of, child_row, count = ops.refine(parent.keys, mask)
+        if cloud_counts is not None:
+            count_hint = sum(cloud_counts)
         n = int(count.item()) if count_hint is None else int(count_hint)
         t = _Map(parent.level - 1, parent.bits + 1, n, keys[:n])
+        if cloud_counts is not None:
+            t.edges = _edges_of(cloud_counts)
         t.parent, t.parent_of, t.child_row = parent, parent_of[:n], child_row
         self._register(t, string_id)
         return t
@@ -432,15 +460,35 @@ class CoordinateManager:
         return idx
 
     def batch_offsets(self, m: _Map) -> List[int]:
-        """Row ranges of the samples of a batch (rows are batch-major)."""
+        """Row ranges of the samples of a batch (rows are batch-major).  Cached on the map; known without a read-back where the
+        pyramid was built for independent clouds (build_pyramid, _refine with cloud_counts, generated sets)."""
+        if m.edges is not None:
+            return m.edges
         if m.n == 0:
             return [0]
         if self._n_batch == 1:
-            return [0, m.n]
-        b = (self._keys(m) >> (3 * m.bits))
-        nb = int(b[-1].item()) + 1
-        edges = torch.searchsorted(b, torch.arange(nb + 1, device=b.device, dtype=b.dtype))
-        return edges.tolist()
+            m.edges = [0, m.n]
+        elif m.generated and m.parent is not None and m.parent.n * 8 == m.n:
+            m.edges = [8 * e for e in self.batch_offsets(m.parent)]
+        else:
+            b = (self._keys(m) >> (3 * m.bits))
+            nb = self._n_batch if self.independent_clouds else int(b[-1].item()) + 1
+            m.edges = torch.searchsorted(b, torch.arange(nb + 1, device=b.device, dtype=b.dtype)).tolist()
+        return m.edges
+
+    def cloud_rows(self, m: _Map) -> List[int]:
+        """the row counts a size-dependent rule must look at: the map's own, or -- independent clouds -- every cloud's"""
+        if not self.independent_clouds:
+            return [m.n]
+        e = self.batch_offsets(m)
+        return [b - a for a, b in zip(e[:-1], e[1:])]
+
+
+def _edges_of(counts: Sequence[int]) -> List[int]:
+    edges = [0]
+    for c in counts:
+        edges.append(edges[-1] + int(c))
+    return edges
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -755,6 +803,29 @@ class _ConvBase(nn.Module):
         src = cm._map(x.coordinate_map_key)
         if torch.is_grad_enabled() and (self.kernel.requires_grad or any(p.requires_grad for p in x.parts)):
             return self._forward_autograd(x, cm, src, coordinates, act, clip)
+        plan_rows = src.n
+        if cm.independent_clouds and self.ks in (1, 3) and not (self.TRANSPOSED or self.GENERATIVE):
+            # PAD_MIN_ROWS is a rule about ONE cloud's map (it selects the summation order, which is part of the stream format): in a
+            # batch of independent clouds every cloud gets the evaluation it would get alone.  Clouds on either side of the threshold
+            # (a small level of one cloud beside the same level of a larger one): the layer runs in both forms over the union and every
+            # cloud takes its rows from its own -- twice the work on a level that is small by definition.
+            c1, c2 = x.parts[0].shape[1], (x.parts[1].shape[1] if len(x.parts) > 1 else 0)
+            edges = cm.batch_offsets(src)
+            padded = [_pad_plan(c1, c2, self.out_channels, b - a) is not None for a, b in zip(edges[:-1], edges[1:]) if b > a]
+            if any(padded) and not all(padded):
+                big = self._forward_fused(x, cm, src, coordinates, act, clip, PAD_MIN_ROWS).F
+                small = self._forward_fused(x, cm, src, coordinates, act, clip, 0).F
+                out = torch.empty_like(small)
+                for a, b in zip(edges[:-1], edges[1:]):
+                    if b > a:
+                        out[a:b] = (big if _pad_plan(c1, c2, self.out_channels, b - a) is not None else small)[a:b]
+                return SparseTensor(out, coordinate_map_key=src.key, coordinate_manager=cm)
+            plan_rows = PAD_MIN_ROWS if any(padded) else 0
+        return self._forward_fused(x, cm, src, coordinates, act, clip, plan_rows)
+
+    def _forward_fused(self, x: SparseTensor, cm: CoordinateManager, src: _Map, coordinates: Optional[CoordinateMapKey], act: _Act,
+                       clip: float, plan_rows: int) -> SparseTensor:
+        """inference path: one fused launch.  plan_rows: the row count PAD_MIN_ROWS is compared with (the map's, or its clouds')"""
         parts = x.parts
         x1 = parts[0]
         x2 = parts[1] if len(parts) > 1 else None
@@ -792,7 +863,7 @@ class _ConvBase(nn.Module):
                                    out_rows=dst.n, **kw)
         elif self.ks == 1:
             dst = src
-            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
+            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, plan_rows)
             if plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 out = ops.conv_f32(self._pad_cols(x1, plan[0]), wp, plan[2], src.n, x2=self._pad_cols(x2, plan[1]), bias=bp,
@@ -804,7 +875,7 @@ class _ConvBase(nn.Module):
             if coordinates is not None and cm._map(coordinates) is not src:
                 raise NotImplementedError('stride-1 convolution onto a different coordinate map')
             d = self._derived()
-            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, src.n)
+            plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, plan_rows)
             if x2 is None and 'k3_w' in d:
                 y = ops.conv_f32(x1, d['k3_w'], 32, src.n, pack=True)       # per input row: its dot product with every offset's kernel
                 out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,

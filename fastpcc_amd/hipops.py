@@ -27,6 +27,7 @@ _SIGS = {
     'fpcc_unique_keys': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_coarsen': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_level_histogram': (_i64, [_vp, _i64, _i32, _vp, _vp]),
+    'fpcc_level_histogram_clouds': (_i64, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -102,6 +103,7 @@ _SIGS = {
     'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
+_BLOCKING_ENTRY_POINTS = ('fpcc_hilbert3d_encode', 'fpcc_conv_debug_stamps', 'fpcc_int_init')
 
 _lib = None
 
@@ -110,8 +112,14 @@ def lib():
     global _lib
     if _lib is None:
         L = _native.hip()
+        blocking = _native.hip_blocking()
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
+            if name in _BLOCKING_ENTRY_POINTS:
+                # these wait for the device (a table upload followed by a stream synchronise, hipMemcpyToSymbol): bound through the
+                # handle that releases the interpreter lock, so another frame's thread keeps enqueueing meanwhile
+                fn = getattr(blocking, name)
+                setattr(L, name, fn)
             fn.restype = res
             fn.argtypes = args
         L.fpcc_last_error.restype = C.c_char_p
@@ -303,6 +311,26 @@ def level_counts(keys: torch.Tensor, levels: int) -> List[int]:
         acc += h[t]
         out.append(1 + acc)
     return out[::-1]
+
+
+def level_counts_clouds(keys: torch.Tensor, levels: int, cloud_shift: int, n_clouds: int) -> List[List[int]]:
+    """rows of every cloud of a batch (key = cloud << cloud_shift | Morton code, rows cloud-major) on the map itself and on its
+    `levels` next coarser maps: out[l][c], l = 0..levels.  One kernel, one blocking read-back (fpcc_level_histogram_clouds)."""
+    n = keys.shape[0]
+    hist = torch.empty((n_clouds, levels + 2), dtype=torch.int32, device=keys.device)
+    _ok(lib().fpcc_level_histogram_clouds(_dev(keys, torch.int64, 'keys'), n, levels, int(cloud_shift), int(n_clouds),
+                                          hist.data_ptr(), _stream()))
+    h = hist.tolist()
+    if sum(row[levels + 1] for row in h) != n:
+        raise ValueError('a key carries a cloud index outside the batch')
+    out = [[0] * n_clouds for _ in range(levels + 1)]
+    for c, row in enumerate(h):
+        out[0][c] = row[levels + 1]
+        acc = 0
+        for t in range(levels, 0, -1):
+            acc += row[t]
+            out[t][c] = acc + (1 if row[levels + 1] else 0)
+    return out
 
 
 def refine(pkeys: torch.Tensor, mask: torch.Tensor):
@@ -507,8 +535,10 @@ def _trace_event():
 def _traced_launch(trace: list, fn, call, info) -> None:
     """one launch with HIP events around it.  The events are recorded INSIDE the C call (fpcc_time_next_launch): recorded from here,
     whatever the interpreter does between the start event and the launch -- with several frames in flight, run another thread for a
-    switch interval -- is timed as part of the kernel.  The lock keeps another thread's launch out of the bracket (ctypes calls run
-    without the GIL).  With a clock hook (bench.py's extra step, one thread) the start event is recorded here, the hook needs it."""
+    switch interval -- is timed as part of the kernel.  The lock keeps another thread's launch out of the bracket (libfpcc_hip's calls
+    keep the interpreter lock -- _native.hip() -- but a thread may still be switched out between the two C calls below).  With a clock
+    hook (bench.py's extra step, one thread) the start event is recorded here, the hook needs it.  If the launch raises, the pending
+    bracket is withdrawn: it must not close around a later, unrelated launch of this thread."""
     with TRACE_LOCK:
         ev0, ev1 = _trace_event(), _trace_event()
         if CLOCK_HOOK is not None:
@@ -518,7 +548,11 @@ def _traced_launch(trace: list, fn, call, info) -> None:
             ev1.record()
         else:
             _ok(lib().fpcc_time_next_launch(ev0.cuda_event, ev1.cuda_event))
-            _ok(fn(*call))
+            try:
+                _ok(fn(*call))
+            except BaseException:
+                lib().fpcc_time_next_launch(None, None)
+                raise
         trace.append((ev0, ev1, info))
 
 

@@ -91,6 +91,13 @@ int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_of, int64_t
  * whose highest differing bit is in [3 t, 3 t + 3) (t clamped to `levels`); the map `l` levels coarser has
  * 1 + sum_{t >= l} hist[t] rows (n > 0).  No reference counterpart (MinkowskiEngine builds strided maps one at a time). */
 int64_t fpcc_level_histogram(const int64_t *keys, int64_t n, int levels, int32_t *hist, void *stream);
+/* The same pass for a batch of clouds coded in ONE network traversal (the reference's lists of independent clouds:
+ * models/convolutional/lossy_coord_v2/model.py:247-256,277-288 compress_partitions / decompress_partitions): keys carry the cloud
+ * index above bit `cloud_shift`, rows are cloud-major.  hist[c][t] (int32 [n_clouds][levels + 2], zeroed here): for t <= levels the
+ * neighbouring key pairs INSIDE cloud c whose highest differing bit is in [3 t, 3 t + 3) (clamped as above), for t = levels + 1 the
+ * keys of cloud c; cloud c has (hist[c][levels + 1] > 0) + sum_{t >= l} hist[c][t] rows on the map `l` levels coarser. */
+int64_t fpcc_level_histogram_clouds(const int64_t *keys, int64_t n, int levels, int cloud_shift, int n_clouds, int32_t *hist,
+                                    void *stream);
 
 /* Occupancy-driven refinement (decoder side; replaces coords = pred.C[mask]; cm.insert_and_map(...),
  * models/convolutional/lossy_coord_lossy_color/geo_lossl_em.py:278-283, and MinkowskiPruning on a generated set):

@@ -80,6 +80,12 @@ int64_t fpcc_pool_histogram_encode(fpcc_pool *p, const volatile uint32_t *flag, 
 int64_t fpcc_pool_table_decode(fpcc_pool *p, const uint8_t *stream, int64_t stream_len, int64_t n, const uint32_t *cdf,
                                int64_t cdf_len, int32_t offset, int32_t *symbols_out, int64_t first_chunk,
                                int64_t *progress);
+/* fpcc_rans_binary_decode in the background: the occupancy levels of SEVERAL clouds coded in one traversal are decoded side by
+ * side (one job per cloud; the reference decodes the clouds of a list one after the other, lossy_coord_v2/model.py:277-288).
+ * *done becomes 1 when bits_out[0..n) is final, or the job's negative code; wait for it with fpcc_progress_wait(done, 1) -- other
+ * jobs of the pool (a residual stream still being decoded) are not waited for. */
+int64_t fpcc_pool_binary_decode(fpcc_pool *p, const uint8_t *stream, int64_t stream_len, const uint16_t *prob1, int64_t n,
+                                uint8_t *bits_out, int64_t *done);
 int64_t fpcc_progress_wait(const int64_t *progress, int64_t needed);
 int64_t fpcc_pool_wait(fpcc_pool *p);
 
