@@ -5,10 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = compress(frame) + decompress(bytes) of one frame resident in HBM, each closed by a device synchronise, exactly
-how the reference times 'encode time' / 'decode time' (models/convolutional/lossy_coord_v2/model.py:196-205).
-Frames are independent, so N GPUs run N replicas on N different frames (weak scaling, no data-path collective; SURVEY.md
-section 8e).  Weights: seeded random initialisation of the architecture (no checkpoints exist here); data: seeded
+One step = one batch of B frames resident in HBM through compress_many + decompress_many (one network traversal over the batch, B
+independent streams); `value` is the throughput of a stream of such steps.  `value_one_frame` is the metric exactly as the reference
+times it: compress(frame) + decompress(bytes) of ONE frame, each closed by a device synchronise ('encode time' / 'decode time',
+models/convolutional/lossy_coord_v2/model.py:196-205).  Frames are independent, so N GPUs run N replicas on different frames (weak
+scaling, no data-path collective).  Weights: seeded random initialisation of the architecture (no checkpoints exist here); data: seeded
 synthetic voxel surface (fastpcc_amd/synthetic.py).  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -34,8 +35,11 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--secondary', type=int, default=1, help='0 skips the figures reported next to the headline: cfg#3 / #4 / #5 at N = 1, '
                                                              'the cfg#5 DDP training step over all N ranks at N > 1')
-    ap.add_argument('--frames-in-flight', type=int, default=2, help='frames a rank keeps in flight on its GPU (fastpcc_amd/serving.py): '
-                    '1 = one frame at a time, each closed by a device synchronise (the reference\'s timer placement)')
+    ap.add_argument('--batch', type=int, default=4, help='frames per step: B independent ~1M-voxel frames coded in ONE network traversal '
+                    '(compress_many / decompress_many; every stream byte-identical to the frame coded alone)')
+    ap.add_argument('--frames-in-flight', type=int, default=2, help='batches a rank keeps in flight on its GPU (fastpcc_amd/serving.py): '
+                    '1 = one batch at a time')
+    ap.add_argument('--latency-frames', type=int, default=12, help='frames of the one-frame-at-a-time figure `value_one_frame` (median; >= 10)')
     ap.add_argument('--own-streams', type=int, default=0, help='1: every frame in flight on a HIP stream of its own (kernels of different frames overlap)')
     ap.add_argument('--ddp-steps', type=int, default=10, help='optimisation steps of the cfg#5 DDP figure (N > 1)')
     ap.add_argument('--ddp-deadline', type=float, default=420.0, help='seconds after which rank 0 prints the headline without the DDP figure')
@@ -296,6 +300,7 @@ def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_resolution, 25.0, args.cpu_baseline_worker)
+    import statistics
     from fastpcc_amd import replicas
     rank, world, local = replicas.env_rank()
     if world != args.gpus:
@@ -334,48 +339,73 @@ def main():
     weights = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
     model = model.cuda().eval()
 
-    # every rank codes its own frame (different seed), all ~1M voxels
-    xyz = body_cloud(args.resolution, SCALE.get(args.resolution, 1.0), seed=2 + rank)
-    frame = torch.from_numpy(batched(xyz)).cuda()
+    # every rank codes its own frames (different seeds), all ~1M voxels: B = --batch of them per step
+    B = max(1, args.batch)
+    clouds = [body_cloud(args.resolution, SCALE.get(args.resolution, 1.0), seed=2 + rank * B + i) for i in range(B)]
+    frames = [torch.from_numpy(batched(c)).cuda() for c in clouds]
+    frame, xyz = frames[0], clouds[0]
     n_points = frame.shape[0]
+    points_per_step = sum(f.shape[0] for f in frames)
 
-    # One step = one frame through compress + decompress.  With --frames-in-flight D > 1 the rank keeps D frames in flight on its
-    # GPU (fastpcc_amd/serving.py: D codec contexts over one set of weights, all enqueueing on ONE stream, so kernels never overlap):
-    # while one frame waits for the host -- the serial rANS tail of compress, the probability -> mask round trip of every occupancy
-    # level of decompress -- the other frame's launches run.  A context waits for its own work only (events).
+    # One step = one batch of B frames through compress_many + decompress_many: ONE traversal of the networks over the B clouds (the
+    # clouds are the samples of one engine batch; every layer is launched once; B byte-identical independent streams, each coded by its
+    # own jobs on the coder pool -- fastpcc_amd/codecs/lossy_coord_v2/model.py).  With --frames-in-flight D > 1 the rank keeps D such
+    # batches in flight on its GPU (fastpcc_amd/serving.py: D codec contexts over one set of weights, all enqueueing on ONE stream, so
+    # kernels never overlap): while one batch waits for the host -- the serial rANS tail of compress, the probability -> mask round
+    # trip of every occupancy level of decompress -- the other's launches run.  A context waits for its own work only (events).
     from fastpcc_amd.serving import FramePipeline, wait_for_my_work
+    from fastpcc_amd.codecs.geo_lossl_em import GeoLosslessEntropyModel
     depth = max(1, args.frames_in_flight)
     pipeline = FramePipeline(model, depth, device, own_streams=bool(args.own_streams))
 
-    def step_of(ctx_model, _):
-        with pipeline.stage('compress'):                 # one frame encodes while the other decodes (serving.py: FramePipeline.stage)
-            data = ctx_model.compress(frame)             # returns when this frame's bytes are written
-            ME.clear_global_coordinate_manager()
-        with pipeline.stage('decompress'):
-            rec = ctx_model.decompress(data)
-            wait_for_my_work(device)                     # this frame's last kernel, not the other frame's queue
-            ME.clear_global_coordinate_manager()
-        return data, rec
-
-    def step():                                          # one frame at a time, each half closed by a device synchronise
-        data = model.compress(frame)
+    def one_frame(f):                                    # one frame at a time, each half closed by a device synchronise
         torch.cuda.synchronize()
+        a = time.perf_counter()
+        data = model.compress(f)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
         ME.clear_global_coordinate_manager()
         rec = model.decompress(data)
         torch.cuda.synchronize()
+        c = time.perf_counter()
         ME.clear_global_coordinate_manager()
+        return data, rec, b - a, c - b
+
+    # reference results of every frame, coded alone: what every step of the timed region must reproduce byte for byte
+    want_bytes, want_points = [], []
+    for f in frames:
+        data, rec, _, _ = one_frame(f)
+        # the decoder keeps the candidates above the (8M - N)-th smallest logit; logits that tie with that threshold are
+        # dropped, exactly as in the reference (lossy_coord_v2/layers.py:164-180), so the count can fall short by the ties
+        assert f.shape[0] - max(16, f.shape[0] // 1000) <= rec.shape[0] <= f.shape[0], (rec.shape[0], f.shape[0])
+        want_bytes.append(data)
+        want_points.append(rec.shape[0])
+
+    # The metric by its BASELINE definition (the reference's Timer blocks, lossy_coord_v2/model.py:196-205): N0 / (t_enc + t_dec),
+    # one frame at a time, each half closed by a device synchronise -- median over `--latency-frames` frames (>= 10) after 2 warm-ups.
+    for _ in range(2):
+        one_frame(frame)
+    lat = [one_frame(frame)[2:] for _ in range(max(1, args.latency_frames))]
+    enc_ms = statistics.median(t[0] for t in lat) * 1e3
+    dec_ms = statistics.median(t[1] for t in lat) * 1e3
+    one_frame_ms = statistics.median(t[0] + t[1] for t in lat) * 1e3
+    value_one_frame = n_points / one_frame_ms / 1e3
+
+    def step_of(ctx_model, _):
+        with pipeline.stage('compress'):                 # one batch encodes while the other decodes (serving.py: FramePipeline.stage)
+            data = ctx_model.compress_many(frames)       # returns when the bytes of every cloud are written
+            ME.clear_global_coordinate_manager()
+        with pipeline.stage('decompress'):
+            rec = ctx_model.decompress_many(data)
+            wait_for_my_work(device)                     # this batch's last kernel, not the other batch's queue
+            ME.clear_global_coordinate_manager()
+        # every step, inside the timed region: the streams are the single-frame streams, the decoders returned the coded points
+        if data != want_bytes or [r.shape[0] for r in rec] != want_points:
+            raise RuntimeError('a step of the timed region did not reproduce the frames\' own streams / point counts')
         return data, rec
 
-    if depth > 1:
-        step()                                           # context 0 first: every cache derived from the shared weights exists
-        for data, rec in pipeline.map(step_of, range(max(args.warmup, depth))):      # every context warm
-            assert n_points - max(16, n_points // 1000) <= rec.shape[0] <= n_points, (rec.shape[0], n_points)
-    else:
-        for _ in range(args.warmup):
-            data, rec = step()
-    # the decoder keeps the candidates above the (8M - N)-th smallest logit; logits that tie with that threshold are
-    # dropped, exactly as in the reference (lossy_coord_v2/layers.py:164-180), so the count can fall short by the ties
-    assert n_points - max(16, n_points // 1000) <= rec.shape[0] <= n_points, (rec.shape[0], n_points)
+    for data, rec in pipeline.map(step_of, range(max(args.warmup, depth))):      # every context warm
+        pass
 
     def barrier():
         replicas.barrier(device)
@@ -388,12 +418,11 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    t_enc = t_dec = 0.0
     hipops.reserve_trace_events(600 * trace_steps)         # before the timed region: the traced steps only record
     # The shader clock the step actually gets: beside every large 3x3x3 launch of ONE EXTRA step after the timed region a one-wave kernel on a second
     # stream counts shader cycles against the constant 100 MHz counter for 100 us (fpcc_clock_probe).  MI355X's power management
     # starts a burst of matrix work near 2.0 GHz and takes ~30 ms of uninterrupted load to reach the 2.4 GHz the peak is quoted at
-    # (profiles/r03/clock_ramp.md); a 24-ms step with host-paced gaps never gets there.
+    # (profiles/r03/clock_ramp.md); a step with host-paced gaps never gets there.
     clock_stream = torch.cuda.Stream(device=device)
     clock_buf = torch.zeros((64, 2), dtype=torch.int64, device=device)
     clock_idx = []
@@ -404,10 +433,9 @@ def main():
             with torch.cuda.stream(clock_stream):
                 hipops.clock_probe(clock_buf[len(clock_idx)], 100)
             clock_idx.append(len(hipops.CONV_TRACE))
-    # The timed region: EXACTLY args.steps steps.  With frames in flight all of them run through the pipeline; the last trace_steps
+    # The timed region: EXACTLY args.steps steps, all through the pipeline (depth 1: in this thread); the last trace_steps
     # record HIP events around every convolution launch of the thread that runs them (hipops.set_thread_trace; start event, launch
-    # and end event of a traced launch are enqueued under one lock, so no other frame's launch falls between them).  One frame at
-    # a time (--frames-in-flight 1): the serial loop of the earlier rounds, each half closed by a device synchronise.
+    # and end event of a traced launch are enqueued under one lock, so no other batch's launch falls between them).
     step_traces = []
 
     step_done = [0.0] * args.steps                       # completion time of every timed step (FPCC_BENCH_STEP_TIMES=1 prints them)
@@ -428,59 +456,26 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    if depth > 1:
-        pipeline.map(timed_step, range(args.steps))
-    else:
-        for it in range(args.steps):
-            if it == args.steps - trace_steps:
-                hipops.CONV_TRACE = []
-            a = time.perf_counter()
-            data = model.compress(frame)
-            torch.cuda.synchronize()
-            b = time.perf_counter()
-            ME.clear_global_coordinate_manager()
-            rec = model.decompress(data)
-            torch.cuda.synchronize()
-            c = time.perf_counter()
-            ME.clear_global_coordinate_manager()
-            t_enc += b - a
-            t_dec += c - b
+    results = pipeline.map(timed_step, range(args.steps))
     barrier()
     elapsed = time.perf_counter() - t0
-    if depth > 1 and os.environ.get('FPCC_BENCH_STEP_TIMES') == '1':
+    data, rec = results[-1][0][0], results[-1][1][0]
+    del results
+    if os.environ.get('FPCC_BENCH_STEP_TIMES') == '1':
         done = sorted(t for t in step_done if t > 0)
         print('step completions, ms after the start of the timed region:', ' '.join(f'{(t - t0) * 1e3:.1f}' for t in done), file=sys.stderr)
-    if depth > 1:
-        # per-frame latencies: a few frames alone on the GPU AFTER the timed region, each half closed by a device synchronise
-        for it in range(3):
-            a = time.perf_counter()
-            data = model.compress(frame)
-            torch.cuda.synchronize()
-            b = time.perf_counter()
-            ME.clear_global_coordinate_manager()
-            rec = model.decompress(data)
-            torch.cuda.synchronize()
-            c = time.perf_counter()
-            ME.clear_global_coordinate_manager()
-            t_enc += (b - a) * args.steps / 3
-            t_dec += (c - b) * args.steps / 3
-        hipops.CONV_TRACE = [e for _, tr in sorted(step_traces, key=lambda x: x[0]) for e in tr]
+    hipops.CONV_TRACE = [e for _, tr in sorted(step_traces, key=lambda x: x[0]) for e in tr]
     pipeline.close()
     del pipeline
     trace, hipops.CONV_TRACE = hipops.CONV_TRACE, None
-    # one more step, outside the timed region and outside `roofline`'s events, for the clock: the probe kernel beside a launch
+    # one more frame, outside the timed region and outside `roofline`'s events, for the clock: the probe kernel beside a launch
     # disturbs that launch's own timing (+15 % on the traced kernel time when both were taken in the same steps)
     hipops.reserve_trace_events(600)
     hipops.CONV_TRACE, hipops.CLOCK_HOOK = [], clock_hook
-    data = model.compress(frame)
-    torch.cuda.synchronize()
-    ME.clear_global_coordinate_manager()
-    rec = model.decompress(data)
-    torch.cuda.synchronize()
-    ME.clear_global_coordinate_manager()
+    one_frame(frame)
     clock_trace, hipops.CONV_TRACE, hipops.CLOCK_HOOK = hipops.CONV_TRACE, None, None
 
-    elapsed_max, total_points = replicas.aggregate(elapsed, float(n_points) * args.steps, device)
+    elapsed_max, total_points = replicas.aggregate(elapsed, float(points_per_step) * args.steps, device)
 
     # rate / distortion of the frame just coded (outside the timed region): bpp and D1-PSNR as the reference's evaluator
     # reports them, distortion computed on the device (fastpcc_amd/evaluators.py)
@@ -537,22 +532,30 @@ def main():
             'metric': 'encode+decode Mpoints/sec, lossy_coord_v2 baseline_r1',
             'value': round(total_points / elapsed_max / 1e6, 4),
             'unit': 'Mpoints/s',
+            # the same metric by the BASELINE definition: N0 / (t_enc + t_dec), ONE frame at a time, each half closed by a device
+            # synchronise (the reference's Timer blocks) -- the figure to compare with earlier rounds and with the reference's test loop
+            'value_one_frame': round(value_one_frame, 4),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed_max / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'lossy_coord_v2/baseline_r1 inference, {n_points}-voxel {args.resolution}^3 '
-                                   f'body-surface frame per GPU (cfg#2), seeded random-init weights',
+                                   f'body-surface frames (cfg#2), seeded random-init weights; one step = a batch of {B} such frames per GPU '
+                                   f'({points_per_step} voxels) through compress_many + decompress_many = ONE network traversal over the batch, '
+                                   f'{B} independent streams byte-identical to the frames coded alone (checked in every timed step); '
+                                   f'{depth} batch(es) in flight per GPU',
                        'parallelism': (f'replicas x{world} (independent frames)' if world > 1 else 'single GPU') +
-                                      (f', {depth} frames in flight per GPU on one stream (fastpcc_amd/serving.py)' if depth > 1 else ''),
-                       'frames_in_flight': depth,
-                       'latency_note': 'encode_ms / decode_ms: one frame alone on the GPU, each closed by a device synchronise (the reference\'s '
-                                       'timer placement)' + (', mean of 3 frames coded after the timed region' if depth > 1 else ', mean of the timed steps') +
-                                       '; value = steps x points / elapsed of the whole timed region',
-                       'encode_ms': round(t_enc / args.steps * 1e3, 3), 'decode_ms': round(t_dec / args.steps * 1e3, 3),
+                                      (f', {depth} batches in flight per GPU on one stream (fastpcc_amd/serving.py)' if depth > 1 else ''),
+                       'batch_clouds': B, 'frames_in_flight': depth, 'voxels_per_step': points_per_step,
+                       'value_note': 'value = steps x voxels_per_step / elapsed of the whole timed region (throughput of a stream of frames); '
+                                     f'value_one_frame = N0 / median(t_enc + t_dec) over {len(lat)} frames coded one at a time, each half closed '
+                                     'by a device synchronise (the reference\'s timer placement), measured before the timed region; '
+                                     'encode_ms / decode_ms = the medians of those frames',
+                       'encode_ms': round(enc_ms, 3), 'decode_ms': round(dec_ms, 3), 'one_frame_ms': round(one_frame_ms, 3),
                        'bytes': n_bytes, 'bpp': round(8 * n_bytes / n_points, 4),
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
                        'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results',
+                       'coder_handover_retries': GeoLosslessEntropyModel.handover_retries,
                        'host_binding': numa if numa is not None else 'none'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
@@ -567,7 +570,8 @@ def main():
                          'kernel_ms_per_step': round(ms / trace_steps, 3),
                          'algorithmic_gflop_per_step': round(flops / trace_steps / 1e9, 2),
                          'other_conv_ms_per_step': round(ms_valu / trace_steps, 3),
-                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region' + (', traced inside the pipeline: events around every convolution launch of the threads that run them)' if depth > 1 else ')'),
+                         'event_traced_steps': f'{trace_steps} of {args.steps} (the last of the timed region, traced inside the pipeline: events '
+                                               f'around every convolution launch of the threads that run them; a launch covers the {B} frames of its batch)',
                          'shader_clock_mhz': None if shader_mhz is None else round(shader_mhz),
                          'frac_at_shader_clock': None if shader_mhz is None else
                          round(achieved / (MFMA_PEAK_TFLOPS * shader_mhz / 2400.0), 4),
@@ -612,7 +616,7 @@ def main():
             failed = failed or (ddp_record is not None and 'error' in ddp_record)
     if rank == 0:
         if args.secondary and world == 1:
-            del model, frame
+            del model, frame, frames
             out['config']['secondary'] = secondary(device)
         if cpu_job is not None:
             out['cpu_baseline'] = cpu_job.result()

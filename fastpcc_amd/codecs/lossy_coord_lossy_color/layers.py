@@ -10,7 +10,7 @@ from ... import engine as ME
 from ... import hipops as ops
 from ...sparse_conv_layers import ConvBlock, GenConvTransBlock
 from ..lossy_coord_v2.layers import DecoderGeoLossl, EncoderGeoLossl, HyperDecoderGenUpsample, HyperDecoderUpsample, \
-    ResidualGeoLossl  # noqa: F401  (re-exported)
+    ResidualGeoLossl, adaptive_keep  # noqa: F401  (re-exported)
 
 
 class Encoder(nn.Module):
@@ -97,17 +97,15 @@ class Decoder(nn.Module):
             raise NotImplementedError('get_keep expects the candidates of a generative upsampling')
         if points_num_list is None:
             raise NotImplementedError('adaptive_pruning=False is not part of the in-scope configurations')
-        target = points_num_list.pop()
-        if len(target) != 1:
-            raise NotImplementedError('batch size 1 at test time')
         logits = pred.F.reshape(-1).contiguous()
         parent = gen.parent
-        if parent is top:
-            return ops.topk_keep(logits, target[0])
-        # cells are the voxels of `top`: follow the parent links of the candidates' parents up to that level
-        cell, m = parent.parent_of, parent.parent
-        while m is not top:
-            if m is None or m.parent_of is None:
-                raise RuntimeError('candidate set is not below the coarsest decoder level')
-            cell, m = m.parent_of[cell.long()], m.parent
-        return ops.topk_keep_cells(logits, cell.to(torch.int32).contiguous(), top.n, target[0])
+        cell = None
+        if parent is not top:
+            # cells are the voxels of `top`: follow the parent links of the candidates' parents up to that level
+            cell, m = parent.parent_of, parent.parent
+            while m is not top:
+                if m is None or m.parent_of is None:
+                    raise RuntimeError('candidate set is not below the coarsest decoder level')
+                cell, m = m.parent_of[cell.long()], m.parent
+            cell = cell.to(torch.int32).contiguous()
+        return adaptive_keep(cm, parent, top, logits, cell, points_num_list.pop())

@@ -4,7 +4,7 @@
 last stage also predicts the colours, and every level of the lossless coder carries residual features."""
 import io
 import time
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -52,14 +52,14 @@ class PCC(nn.Module):
             raise ValueError('Only supports batch size == 1 during testing.')
         return self.test_forward(pc_data)
 
-    def set_global_cm(self) -> ME.CoordinateManager:
+    def set_global_cm(self, clouds: Optional[int] = None) -> ME.CoordinateManager:
         ME.clear_global_coordinate_manager()
-        cm = ME.CoordinateManager(D=3)
+        cm = ME.CoordinateManager(D=3, clouds=clouds)
         ME.set_global_coordinate_manager(cm)
         return cm
 
-    def get_sparse_pc(self, xyz: torch.Tensor, color: torch.Tensor) -> ME.SparseTensor:
-        cm = self.set_global_cm()
+    def get_sparse_pc(self, xyz: torch.Tensor, color: torch.Tensor, clouds: Optional[int] = None) -> ME.SparseTensor:
+        cm = self.set_global_cm(clouds)
         feats = torch.cat((color.to(torch.float32) / 255, torch.full((color.shape[0], 1), 2.0, device=color.device)), 1)
         pc = ME.SparseTensor(features=feats, coordinates=xyz, tensor_stride=[1] * 3, coordinate_manager=cm,
                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
@@ -75,30 +75,88 @@ class PCC(nn.Module):
         sparse_pc = self.get_sparse_pc((batched_coord - F.pad(coord_offset, (1, 0))).contiguous(), batched_color)
         feature, points_num_list = self.encoder(sparse_pc)
         em_bytes = self.em_lossless_based.compress(feature, 1)
-        with io.BytesIO() as bs:
-            for v in coord_offset.tolist():
-                bs.write(int(v).to_bytes(2, 'little', signed=False))
-            if self.cfg.adaptive_pruning:
-                for counts in points_num_list:
-                    bs.write(int(counts[0]).to_bytes(3, 'little', signed=False))
-            bs.write(em_bytes)
-            return bs.getvalue()
+        return self._header(coord_offset.tolist(), None if points_num_list is None else [counts[0] for counts in points_num_list]) + em_bytes
 
-    def compress_partitions(self, batched_coord: List[torch.Tensor], batched_color: List[torch.Tensor]) -> bytes:
-        parts = [self.compress(c, f) for c, f in zip(batched_coord[1:], batched_color[1:])]
-        return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in parts)
+    def _header(self, coord_offset: List[int], counts: Optional[List[int]]) -> bytes:
+        head = b''.join(int(v).to_bytes(2, 'little', signed=False) for v in coord_offset)
+        if self.cfg.adaptive_pruning:
+            head += b''.join(int(n).to_bytes(3, 'little', signed=False) for n in counts)
+        return head
 
     @hipops.no_gc_pause
     @torch.no_grad()
-    def decompress(self, compressed_bytes: bytes) -> Tuple[torch.Tensor, torch.Tensor]:
+    def compress_many(self, clouds: List[torch.Tensor], colors: List[torch.Tensor]) -> List[bytes]:
+        """Independent coloured clouds -> the stream `compress` writes for each, from ONE traversal of the networks over their union
+        (see lossy_coord_v2.PCC.compress_many; the reference codes the partitions of a large cloud one at a time, model.py:277-288)."""
+        if len(clouds) != len(colors) or not clouds:
+            raise ValueError('one colour tensor per cloud')
+        if len(clouds) == 1:
+            return [self.compress(clouds[0], colors[0])]
+        B = len(clouds)
+        offsets = torch.stack([c.amin(0) for c in clouds])
+        shift = offsets.clone()
+        shift[:, 0] = -torch.arange(B, device=shift.device, dtype=shift.dtype)
+        sparse_pc = self.get_sparse_pc(torch.cat([c - shift[b] for b, c in enumerate(clouds)]), torch.cat(list(colors)), clouds=B)
+        feature, points_num_list = self.encoder(sparse_pc)
+        em_bytes = self.em_lossless_based.compress_clouds(feature, B)
+        offsets = offsets[:, 1:].tolist()
+        return [self._header(offsets[b], None if points_num_list is None else [counts[b] for counts in points_num_list]) + em_bytes[b]
+                for b in range(B)]
+
+    @hipops.no_gc_pause
+    @torch.no_grad()
+    def decompress_many(self, streams: List[bytes]) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        if len(streams) == 1:
+            return [self.decompress(streams[0])]
         dev = next(self.parameters()).device
+        B = len(streams)
+        parsed = [self._parse_header(s) for s in streams]
+        offset = torch.tensor([p[0] for p in parsed], dtype=torch.int32, device=dev)      # before anything is queued
+        points_num_list = None
+        if self.cfg.adaptive_pruning:
+            points_num_list = [[parsed[b][1][s][0] for b in range(B)] for s in range(len(parsed[0][1]))]
+        cm = self.set_global_cm(B)
+        fea_recon = self.em_lossless_based.decompress_clouds([p[2] for p in parsed], cm)
+        out = self.decoder(fea_recon, points_num_list)
+        edges = cm.batch_offsets(cm._map(out.coordinate_map_key))
+        xyz, rgb = out.C[:, 1:], out.F.round_()
+        return [(xyz[a:b] + offset[c], rgb[a:b]) for c, (a, b) in enumerate(zip(edges[:-1], edges[1:]))]
+
+    MANY_MAX_VOXELS = 6_000_000       # partitions of one list coded per traversal (see lossy_coord_v2.PCC)
+
+    def _groups(self, sizes: List[int]) -> List[List[int]]:
+        groups, cur, acc = [], [], 0
+        for i, n in enumerate(sizes):
+            if cur and (acc + n > self.MANY_MAX_VOXELS or len(cur) == 64):
+                groups.append(cur)
+                cur, acc = [], 0
+            cur.append(i)
+            acc += n
+        if cur:
+            groups.append(cur)
+        return groups
+
+    def compress_partitions(self, batched_coord: List[torch.Tensor], batched_color: List[torch.Tensor]) -> bytes:
+        coords, colors = list(batched_coord[1:]), list(batched_color[1:])      # element 0 is the unpartitioned cloud
+        coded: List[bytes] = []
+        for g in self._groups([c.shape[0] for c in coords]):
+            coded.extend(self.compress_many([coords[i] for i in g], [colors[i] for i in g]))
+        return b''.join(len(s).to_bytes(3, 'little', signed=False) + s for s in coded)
+
+    def _parse_header(self, compressed_bytes: bytes):
         with io.BytesIO(compressed_bytes) as bs:
             coord_offset = [int.from_bytes(bs.read(2), 'little', signed=False) for _ in range(3)]
             points_num_list = None
             if self.cfg.adaptive_pruning:
                 points_num_list = [[int.from_bytes(bs.read(3), 'little', signed=False)]
                                    for _ in range(len(self.cfg.decoder_channels))]
-            em_bytes = bs.read()
+            return coord_offset, points_num_list, bs.read()
+
+    @hipops.no_gc_pause
+    @torch.no_grad()
+    def decompress(self, compressed_bytes: bytes) -> Tuple[torch.Tensor, torch.Tensor]:
+        dev = next(self.parameters()).device
+        coord_offset, points_num_list, em_bytes = self._parse_header(compressed_bytes)
         offset = torch.tensor(coord_offset, dtype=torch.int32, device=dev)      # before anything is queued (pageable H2D waits)
         fea_recon = self.em_lossless_based.decompress(em_bytes, self.set_global_cm())
         out = self.decoder(fea_recon, points_num_list)
@@ -106,11 +164,16 @@ class PCC(nn.Module):
         return coord, out.F.round_()
 
     def decompress_partitions(self, concat_bytes: bytes):
-        coords, colors = [], []
+        streams = []
         with io.BytesIO(concat_bytes) as bs:
             while bs.tell() != len(concat_bytes):
                 length = int.from_bytes(bs.read(3), 'little', signed=False)
-                c, f = self.decompress(bs.read(length))
+                streams.append(bs.read(length))
+        # a partition's size before it is decoded: the pruning target of the finest stage in its header
+        sizes = [self._parse_header(s)[1][0][0] if self.cfg.adaptive_pruning else len(s) for s in streams]
+        coords, colors = [], []
+        for g in self._groups(sizes):
+            for c, f in self.decompress_many([streams[i] for i in g]):
                 coords.append(c)
                 colors.append(f)
         return torch.cat(coords, 0), torch.cat(colors, 0)

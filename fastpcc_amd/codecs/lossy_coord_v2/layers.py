@@ -221,29 +221,35 @@ class Decoder(nn.Module):
             cell_max.scatter_reduce_(0, cell.long(), per_group, reduce='amax', include_self=True)
             cells = pred.F.view(-1, 8)
             return ((cells > 0) | (cells == cell_max[cell.long()][:, None])).view(-1).to(torch.uint8)
-        target = points_num_list.pop()
-        if cm.independent_clouds:
-            edges = cm.batch_offsets(parent)
-            if len(target) != len(edges) - 1:
-                raise ValueError('one pruning target per cloud expected')
-            top_edges = cm.batch_offsets(top) if cell is not None else None
-            keep = []
-            for c, (a, b) in enumerate(zip(edges[:-1], edges[1:])):
-                if not 8 * (b - a) > target[c]:
-                    raise ValueError('fewer candidates than points to keep')
-                if cell is None:
-                    keep.append(ops.topk_keep(logits[8 * a: 8 * b], target[c]))
-                else:
-                    keep.append(ops.topk_keep_cells(logits[8 * a: 8 * b], (cell[a:b] - top_edges[c]).contiguous(),
-                                                    top_edges[c + 1] - top_edges[c], target[c]))
-            return torch.cat(keep)
-        if len(target) != 1:
-            raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')
-        if not logits.numel() > target[0]:
-            raise ValueError('fewer candidates than points to keep')
-        if cell is None:
-            return ops.topk_keep(logits, target[0])
-        return ops.topk_keep_cells(logits, cell, top.n, target[0])
+        return adaptive_keep(cm, parent, top, logits, cell, points_num_list.pop())
+
+
+def adaptive_keep(cm, parent, top, logits: torch.Tensor, cell: Optional[torch.Tensor], target: List[int]) -> torch.Tensor:
+    """uint8 [8 * parent.n]: the candidates (8 per row of `parent`) above the threshold that keeps `target` of them, or the maximum of
+    their cell (`cell`: the row of `top` every parent row lies in; None = the 8 siblings).  One target, one ranking per cloud: on a
+    batch of independent clouds (ME.CoordinateManager(clouds=B)) every cloud's candidates are ranked among themselves."""
+    if cm.independent_clouds:
+        edges = cm.batch_offsets(parent)
+        if len(target) != len(edges) - 1:
+            raise ValueError('one pruning target per cloud expected')
+        top_edges = cm.batch_offsets(top) if cell is not None else None
+        keep = []
+        for c, (a, b) in enumerate(zip(edges[:-1], edges[1:])):
+            if not 8 * (b - a) > target[c]:
+                raise ValueError('fewer candidates than points to keep')
+            if cell is None:
+                keep.append(ops.topk_keep(logits[8 * a: 8 * b], target[c]))
+            else:
+                keep.append(ops.topk_keep_cells(logits[8 * a: 8 * b], (cell[a:b] - top_edges[c]).contiguous(),
+                                                top_edges[c + 1] - top_edges[c], target[c]))
+        return torch.cat(keep)
+    if len(target) != 1:
+        raise NotImplementedError('batch size 1 at test time, as in the reference (model.py:121)')
+    if not logits.numel() > target[0]:
+        raise ValueError('fewer candidates than points to keep')
+    if cell is None:
+        return ops.topk_keep(logits, target[0])
+    return ops.topk_keep_cells(logits, cell, top.n, target[0])
 
 
 class HyperDecoderUpsample(nn.Module):

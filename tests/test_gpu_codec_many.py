@@ -127,3 +127,93 @@ def test_batched_streams_equal_the_reference_runs_in_chain_order(run):
         rec = model.decompress_many(streams)[at].cpu().numpy().astype(np.int64)
         keys = np.sort((rec[:, 0] << 42) | (rec[:, 1] << 21) | rec[:, 2])
         assert len(rec) == run['recon_points'] and hashlib.sha256(keys.tobytes()).hexdigest() == run['recon_sha256']
+
+
+# ---- the hand-over fallback of the encoder's coder pool ------------------------------------------------------------------------------
+def test_a_failed_pool_job_is_coded_again_after_a_synchronise(model, clouds, monkeypatch):
+    """a coder job that reports a refusal (what a job that read its inputs before they had landed would do) is repeated inline once
+    every copy is complete: same bytes, a warning, and the process-wide counter bench.py reports"""
+    from fastpcc_amd.coder_pool import CoderPool
+    from fastpcc_amd.codecs.geo_lossl_em import GeoLosslessEntropyModel
+    want = model.compress_many([clouds[0], clouds[3]])
+    real_wait = CoderPool.wait
+    fired = []
+
+    def failing_wait(self):
+        out = real_wait(self)
+        if not fired and out:
+            fired.append(1)
+            raise RuntimeError('libfpcc_host: invalid argument')
+        return out
+    monkeypatch.setattr(CoderPool, 'wait', failing_wait)
+    before = GeoLosslessEntropyModel.handover_retries
+    with pytest.warns(UserWarning, match='succeeded when repeated'):
+        got = model.compress_many([clouds[0], clouds[3]])
+    assert fired and got == want and GeoLosslessEntropyModel.handover_retries == before + 1
+    monkeypatch.setattr(CoderPool, 'wait', real_wait)
+    assert model.compress(clouds[0]) == want[0]
+
+
+# ---- the colour codec ------------------------------------------------------------------------------------------------------------------
+def _colors(xyz, seed):
+    rng = np.random.default_rng(seed)
+    base = 127 + 90 * np.stack((np.sin(xyz[:, 0] / 9.0), np.cos(xyz[:, 1] / 7.0), np.sin((xyz[:, 2] + xyz[:, 0]) / 11.0)), 1)
+    return torch.from_numpy(np.clip(base + rng.normal(0, 8, base.shape), 0, 255).astype(np.uint8)).cuda()
+
+
+def test_colour_streams_are_the_single_cloud_streams():
+    from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+    from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import baseline_r1
+    torch.manual_seed(0)
+    m = Model(baseline_r1())
+    enliven(m, 3, gain=2.3)
+    m = m.cuda().eval()
+    raw = [surface_cloud(7, 64, 16000), surface_cloud(8, 256, 70000), surface_cloud(9, 32, 1500)]
+    xyz = [_dev(r, s) for r, s in zip(raw, ((2, 9, 0), (0, 0, 0), (40, 40, 40)))]
+    rgb = [_colors(r, i) for i, r in enumerate(raw)]
+    alone = [m.compress(c, f) for c, f in zip(xyz, rgb)]
+    recs = [m.decompress(s) for s in alone]
+    for pick in ([0, 1, 2], [2, 0], [1, 2]):
+        many = m.compress_many([xyz[i] for i in pick], [rgb[i] for i in pick])
+        for i, s in zip(pick, many):
+            assert s == alone[i], f'coloured cloud {i} of batch {pick}: stream differs from the one coded alone'
+        for i, (c, f) in zip(pick, m.decompress_many(many)):
+            assert _same_points(c, recs[i][0]) and _same_points(f, recs[i][1]), f'coloured cloud {i} of batch {pick}: decode differs'
+    blob = m.compress_partitions([torch.cat(xyz), *xyz], [torch.cat(rgb), *rgb])
+    assert blob == b''.join(len(s).to_bytes(3, 'little') + s for s in alone)
+    c, f = m.decompress_partitions(blob)
+    assert c.shape[0] == sum(r[0].shape[0] for r in recs) == f.shape[0]
+
+
+def _colour_chain_runs():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color_chain.json')) as f:
+        g = json.load(f)
+    return g['numerics_version'], g['runs']
+
+
+@pytest.mark.parametrize('run', _colour_chain_runs()[1], ids=[r['label'] for r in _colour_chain_runs()[1]])
+def test_batched_colour_streams_equal_the_reference_runs_in_chain_order(run):
+    from dataclasses import fields
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+    from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import ModelConfig
+    assert _colour_chain_runs()[0] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_color_chain.json'
+    known = {f.name for f in fields(ModelConfig)}
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items() if k in known})
+    torch.manual_seed(0)
+    m = Model(cfg)
+    enliven(m, run['seed'], **({} if run.get('gain') is None else {'gain': run['gain']}))
+    m = m.cuda().eval()
+    mine = _dev(np.array(run['xyz'], dtype=np.int32))
+    mine_rgb = torch.from_numpy(np.array(run['color'], dtype=np.uint8)).cuda()
+    other_raw = surface_cloud(11, 128, 40000)
+    other, other_rgb = _dev(other_raw, (3, 1, 2)), _colors(other_raw, 5)
+    want = bytes.fromhex(run['stream_hex'])
+    for batch, colours, at in (([mine, other], [mine_rgb, other_rgb], 0), ([other, mine], [other_rgb, mine_rgb], 1)):
+        streams = m.compress_many(batch, colours)
+        assert streams[at] == want
+        rec_xyz, rec_rgb = m.decompress_many(streams)[at]
+        assert rec_xyz.cpu().numpy().tolist() == run['recon_xyz']
+        assert rec_rgb.cpu().numpy().astype(int).tolist() == run['recon_rgb']
