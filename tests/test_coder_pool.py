@@ -138,3 +138,32 @@ def test_all_zero_histogram_is_an_error_not_undefined_behaviour():
     from fastpcc_amd.rans_coder import batched_pmf_to_quantized_cdf
     with pytest.raises((RuntimeError, ValueError)):
         batched_pmf_to_quantized_cdf(np.zeros((1, 5)), np.zeros(1, np.int32), False)
+
+
+def test_binary_decode_jobs_run_beside_a_long_table_decode():
+    """fpcc_pool_binary_decode: the occupancy streams of several clouds decoded side by side; a job's completion word is waited for
+    on its own -- a residual stream still being decoded on the same pool is not"""
+    rng = np.random.default_rng(9)
+    pool = CoderPool(4)
+    # a long table decode that stays busy while the binary jobs come and go
+    sym = np.clip(np.round(rng.normal(0, 3, 400000)), -15, 15).astype(np.int32)
+    h = pool.histogram_encode(sym, None)
+    pool.wait()
+    offset, cdf, payload = pool.histogram_result(h)
+    out_sym = np.full(sym.size, -99, dtype=np.int32)
+    prog = pool.table_decode(payload, sym.size, cdf, offset, out_sym, first_chunk=64)
+    cases = [_binary_case(rng, n) for n in (5000, 1, 70000)]
+    outs, waits = [], []
+    for bits, p, stream in cases:
+        got = np.full(bits.size, 7, dtype=np.uint8)
+        outs.append(got)
+        waits.append(pool.binary_decode(np.frombuffer(stream, dtype=np.uint8), p, got))
+    for w, got, (bits, _, _) in zip(waits, outs, cases):
+        pool.need(w, 1)
+        assert (got == bits).all()
+    pool.need(prog, sym.size)
+    assert (out_sym == sym).all()
+    pool.wait()
+    with pytest.raises(ValueError):
+        pool.binary_decode(np.zeros(8, np.uint8), np.ones(4, np.uint16), np.zeros(5, np.uint8))       # shapes must agree
+    pool.close()
