@@ -352,7 +352,25 @@ __device__ __forceinline__ int32_t epi_fast_elem(int32_t a, int32_t b, int32_t m
     return OUT_BITS == 8 ? min(max(r32, -128), 127) : r32;
 }
 
-template <int NB>
+// The element WITHOUT its range checks, for the launches in which no value can leave its range (uniform conditions, tested once per
+// wave in conv_i8_epilogue): the accumulator of int8 x int8 products over n_off x c_in terms is bounded, so acc + bias stays an int32
+// when the column's bias leaves that much room; a PReLU slope in (-1, 1] (Q6.25) cannot grow a value, so its result stays an int32;
+// the multiplier is below 2^31.  HI (requantisation shift >= 32): the quotient is the high word of the 64-bit sum shifted by
+// shift - 32 -- an int32 by construction, no 64-bit shift and no saturation.  18 instead of 34 issue slots per element; the epilogue
+// is 41 % of a workgroup's life on the finest LiDAR levels (profiles/r05/int8_stage.md).  Same integers as epi_fast_elem.
+template <int OUT_BITS, bool HI>
+__device__ __forceinline__ int32_t epi_lean_elem(int32_t a, int32_t b, int32_t m, const EpiFast &e) {
+    const int32_t t = a + b;
+    const int32_t y = t < 0 ? (int32_t)prelu_neg(t, e.slope, e.c25) : t;
+    const int64_t q1 = (int64_t)((uint64_t)((int64_t)y * (int64_t)m) + (uint64_t)e.c_neg);
+    const int64_t q2 = q1 + (int64_t)(q1 >= e.hm1);
+    const int32_t r32 = HI ? ((int32_t)(q2 >> 32) >> (e.shift - 32)) : sat_i32(q2 >> e.shift);
+    return OUT_BITS == 8 ? min(max(r32, -128), 127) : r32;
+}
+
+// EDBG (timing experiments of the int8-output form, results wrong): 32 = the values are computed but not stored, 64 = stored without
+// being computed (the accumulator's low byte)
+template <int NB, int EDBG = 0>
 __device__ __forceinline__ void conv_i8_epilogue(const ConvI8Args &p, const i32x16 (&acc)[NB], const int32_t *my_rows, int col0, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int64_t zp = p.zp ? p.zp[0] : 0;
@@ -381,21 +399,52 @@ __device__ __forceinline__ void conv_i8_epilogue(const ConvI8Args &p, const i32x
         int64_t orow[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) orow[reg] = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
+        // (uniform) may the range checks be dropped?  |acc| <= n_off x (32 k_steps) x 127 x 128 when nothing but products went into it
+        const int64_t acc_max = (int64_t)p.n_off * p.k_steps * 32 * (127 * 128);
+        bool cols_fit = !p.zp_comp && acc_max < ((int64_t)1 << 31);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int64_t room = (int64_t)INT32_MAX - acc_max;
+            cols_fit = cols_fit && m[nb] >= 0 && (int64_t)b[nb] <= room && (int64_t)b[nb] >= -room;
+        }
+        const bool lean = __builtin_amdgcn_ballot_w64(!cols_fit) == 0ull && e.slope > -(1 << 25) && e.slope <= (1 << 25);
+        const bool hi = p.shift >= 32;
         if (p.out_bits == 8) {
+            // int8 outputs: a lane owns ONE column of 16 rows per column block -- 64 one-byte stores per lane.  (Setting the tile down in
+            // LDS first and writing whole 16-byte pieces of whole rows -- NB store instructions instead of 16 NB -- was built in round 5,
+            // bit-exact, and not faster: 92.6 against 89.5 us on the 113 K-row level, profiles/r05/int8_stage.md.)
             int8_t *out = static_cast<int8_t *>(p.out) + col0 + li;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int8_t *o = out + orow[reg] * p.ldo;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) o[32 * nb] = (int8_t)epi_fast_elem<8>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any);
+            int32_t sink = 0;
+#define FPCC_I8_PUT(ELEM)                                                                                          \
+            _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) {                                                  \
+                int8_t *o = out + orow[reg] * p.ldo;                                                                \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                 \
+                    if (EDBG & 64) o[32 * nb] = (int8_t)acc[nb][reg];                                               \
+                    else if (EDBG & 32) sink ^= (ELEM);                                                             \
+                    else o[32 * nb] = (int8_t)(ELEM);                                                               \
+                }                                                                                                   \
             }
+            if (lean && hi) { FPCC_I8_PUT((epi_lean_elem<8, true>(acc[nb][reg], b[nb], m[nb], e))) }
+            else if (lean) { FPCC_I8_PUT((epi_lean_elem<8, false>(acc[nb][reg], b[nb], m[nb], e))) }
+            else { FPCC_I8_PUT((epi_fast_elem<8>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any))) }
+#undef FPCC_I8_PUT
+            if ((EDBG & 32) && sink == 0x12345678) out[0] = (int8_t)sink;
         } else if (!p.res) {
             int32_t *out = static_cast<int32_t *>(p.out) + col0 + li;
+            if (lean && !hi) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int32_t *o = out + orow[reg] * p.ldo;
+                for (int reg = 0; reg < 16; ++reg) {
+                    int32_t *o = out + orow[reg] * p.ldo;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) o[32 * nb] = epi_fast_elem<32>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any);
+                    for (int nb = 0; nb < NB; ++nb) o[32 * nb] = epi_lean_elem<32, false>(acc[nb][reg], b[nb], m[nb], e);
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    int32_t *o = out + orow[reg] * p.ldo;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) o[32 * nb] = epi_fast_elem<32>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any);
+                }
             }
         } else {
             // residual form: all residual operands first (a load between two stores waits for every store issued so far), then the stores
@@ -411,7 +460,8 @@ __device__ __forceinline__ void conv_i8_epilogue(const ConvI8Args &p, const i32x
                 int32_t *o = out + orow[reg] * p.ldo;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int32_t v = epi_fast_elem<32>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any);
+                    const int32_t v = (lean && !hi) ? epi_lean_elem<32, false>(acc[nb][reg], b[nb], m[nb], e)
+                                                    : epi_fast_elem<32>(acc[nb][reg], b[nb], m[nb], e, bad_sign, bad_any);
                     const int32_t x = (int32_t)((uint32_t)v + (uint32_t)r[reg][nb]);          // the reference's int32 tensor add wraps
                     o[32 * nb] = x < 0 ? sat_i32(prelu_neg(x, e.slope2, e.c25_2)) : x;        // exact for every int32 x
                 }
@@ -544,54 +594,118 @@ __global__ __launch_bounds__(256) void k_conv_i8(ConvI8Args p, int32_t *acc_out,
 // barrier per stage, 16-byte pieces XOR-swizzled so that the MFMA operand reads are conflict free), every wave gathers
 // its 32 A rows as full 128-byte lines into registers one stage ahead, and issues up to 4*NB MFMAs per stage.  Offsets
 // absent from the whole tile are skipped by the workgroup, offsets absent from a wave's rows by that wave.
-template <int NB, int DBG = 0>          // DBG (timing experiments, results wrong): 1 no MFMA, 2 no gather (A from the zero row), 4 no W fetch
-__global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
+// Diagnostics (profiles/r05/int8_stage.md): s_memtime stamps of wave 0 of every workgroup of k_conv_i8_tiled<4, 16> in LDS slots, copied to
+// the buffer set with fpcc_conv_i8_debug_stamps when the workgroup ends.  A stamp is one LDS store by lane 0 with the exec mask narrowed
+// in place (no branch: a branch in the stage loop makes hipcc drain vmcnt).
+constexpr int kI8StampSlots = 48;
+__device__ unsigned long long *g_i8_stamp_buf = nullptr;
+__device__ long long g_i8_stamp_cap = 0;
+__device__ __forceinline__ void i8_stamp(unsigned long long *slot) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned addr = (unsigned)(uintptr_t)slot;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(t) : "memory");
+}
+
+// NB = 2 (round 5): 64-column tiles.  The 128-column form needs all 256 VGPRs (and spills 14) for its 64 accumulator registers and the
+// 64-element epilogue, which holds a SIMD to two waves; on the levels of a LiDAR sweep where a tile executes 2-8 stages the kernel is a
+// chain of dependent round trips (row order -> kernel map -> operands) with nothing to hide them behind -- 41 % of its wave cycles are
+// parked at a wait (profiles/r05/int8_stage.md).  Half the columns is half the registers: four waves per SIMD, at the price of gathering
+// every A row once more.
+template <int NB, int DBG = 0, int MW = (NB == 4 ? 2 : 4)>   // DBG (timing experiments, results wrong): 1 no MFMA, 2 no gather (A from the zero row), 4 no W fetch
+__global__ __launch_bounds__(256, MW) void k_conv_i8_tiled(ConvI8Args p) {
     constexpr int COLS = 32 * NB;
     constexpr int W_PIECES = COLS * 8 / 256;                     // 16-byte pieces of one W tile per thread
     __shared__ i32x4 sB[2][8 * COLS];
     extern __shared__ int32_t s_idx[];                           // [n_off][128] (dynamic: 13.5 KB for 27 offsets, 32 KB for 64)
     __shared__ int32_t s_row[128];
     __shared__ unsigned long long s_mask[4];
+    __shared__ unsigned long long s_i8_stamp[(DBG & 16) ? kI8StampSlots : 1];
+#define FPCC_I8_STAMP(i) do { if ((DBG & 16) && wave == 0) i8_stamp(&s_i8_stamp[(i)]); } while (0)
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (DBG & 16) {
+        if (tid < kI8StampSlots) s_i8_stamp[tid] = 0;
+        __syncthreads();
+    }
+    FPCC_I8_STAMP(0);
     const int li = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int col0 = blockIdx.y * COLS;
 
-    // The tile's slice of the kernel map -> LDS.  Thread t owns tile row t & 127 and the kernel offsets of parity t >> 7; its loads
-    // are issued back to back, eight at a time, before the first of them is used (one load and its LDS store per loop iteration --
-    // the earlier form -- pays one memory round trip per kernel offset pair: 7-14 us of every workgroup's life,
-    // profiles/r04/int8_conv.md); in the row-major table of the integer operators they fall into the row's one or two cache lines.
+    // The tile's slice of the kernel map -> LDS.  Row-major table (nbr_ks == 1, the layout of the integer operators): thread t owns tile
+    // row t & 127 and every second 16-byte piece of its row, pieces of parity t >> 7 -- a row's n_off entries are n_off / 4 requests of
+    // 16 bytes into its one or two cache lines, all issued before the first is used.  (Until round 5 every ENTRY was a 4-byte request:
+    // 64 lanes x 4 bytes of 64 different rows per load instruction, i.e. 64 line requests for 256 bytes -- 3 584 requests per workgroup
+    // for a 13.8 KB slice, more than its operand gathers and stores together.)  Rows are 4 n_off bytes apart, so the pieces are only
+    // dword-aligned.  Any other layout: one request per entry, eight in flight.
     {
         const int r = tid & 127;
         const int64_t row = row0 + r < p.n_out ? (p.row_order ? (int64_t)p.row_order[row0 + r] : row0 + r) : -1;
         if (tid < 128) s_row[tid] = (int32_t)row;
         const int32_t *src = p.nbr ? p.nbr + (row < 0 ? 0 : row) * p.nbr_os : nullptr;
-        for (int k0 = tid >> 7; k0 < p.n_off; k0 += 16) {
-            int32_t v[8];
+        if (p.nbr && p.nbr_ks == 1 && p.n_off >= 4) {
+            typedef int32_t i32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
+            const int n_pieces = (p.n_off + 3) >> 2;
+            for (int q0 = tid >> 7; q0 < n_pieces; q0 += 8) {
+                i32x4_dw v[4];
+                int first[4];                                            // first entry of the piece; the last piece of a row whose length
+#pragma unroll                                                           // is not a multiple of four starts early instead of reading past the row
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + 2 * u;
+                    first[u] = min(4 * (q < n_pieces ? q : q0), p.n_off - 4);
+                    v[u] = *reinterpret_cast<const i32x4_dw *>(src + first[u]);
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 2 * u;
-                v[u] = (p.nbr && row >= 0 && k < p.n_off) ? src[(int64_t)k * p.nbr_ks] : 0;
+                for (int u = 0; u < 4; ++u) {
+                    if (q0 + 2 * u >= n_pieces) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_idx[(first[u] + e) * 128 + r] = row < 0 ? -1 : v[u][e] - p.nbr_bias;
+                }
             }
+        } else {
+            for (int k0 = tid >> 7; k0 < p.n_off; k0 += 16) {
+                int32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 2 * u;
-                if (k < p.n_off) s_idx[k * 128 + r] = row < 0 ? -1 : (p.nbr ? v[u] - p.nbr_bias : (int32_t)row);
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 2 * u;
+                    v[u] = (p.nbr && row >= 0 && k < p.n_off) ? src[(int64_t)k * p.nbr_ks] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 2 * u;
+                    if (k < p.n_off) s_idx[k * 128 + r] = row < 0 ? -1 : (p.nbr ? v[u] - p.nbr_bias : (int32_t)row);
+                }
             }
         }
     }
     __syncthreads();
+    FPCC_I8_STAMP(1);                                            // the tile's slice of the kernel map is in LDS
     const int32_t *my_idx = s_idx + wave * 32 + li;
+    // which offsets any of this wave's 32 rows has.  Lane half h looks at the offsets of parity h, eight LDS reads in flight at a time
+    // (one read, one ballot per offset in turn -- the earlier form -- was 27 dependent LDS round trips: 4 000 cycles of every
+    // workgroup's life whatever the level, profiles/r05/int8_stage.md)
     unsigned long long wmask = 0ull;
-    for (int k = 0; k < p.n_off; ++k)
-        if (__ballot(my_idx[k * 128] >= 0) != 0ull) wmask |= 1ull << k;
+    for (int k0 = 0; k0 < p.n_off; k0 += 16) {
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 2 * u + lh;
+            v[u] = k < p.n_off ? my_idx[k * 128] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long b = __ballot(v[u] >= 0);
+            if (b & 0xffffffffull) wmask |= 1ull << (k0 + 2 * u);
+            if (b >> 32) wmask |= 1ull << (k0 + 2 * u + 1);
+        }
+    }
     if (lane == 0) s_mask[wave] = wmask;
     __syncthreads();
     const unsigned long long tmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
     const int n_chunks = (p.k_steps + 3) / 4;
     const int n_stages = __popcll(tmask) * n_chunks;
+    FPCC_I8_STAMP(2);                                            // offsets present in the tile known
 
     i32x16 acc[NB];
 #pragma unroll
@@ -636,7 +750,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
         fetch_w(k_cur, 0, rw);
         stash_w(0, rw);
         __syncthreads();
+        FPCC_I8_STAMP(3);                                        // the first W tile is in LDS (one full round trip)
         for (int st = 0; st < n_stages; ++st) {
+            FPCC_I8_STAMP(4 + (st < 32 ? st : 32));
             if (++c_next == n_chunks) {
                 c_next = 0;
                 rest &= rest - 1;
@@ -679,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
         }
     }
 
+    FPCC_I8_STAMP(38);                                           // last stage done
     if (DBG & 8) {                                   // no epilogue
         int32_t x = 0;
 #pragma unroll
@@ -688,7 +805,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_i8_tiled(ConvI8Args p) {
         if (x == 0x12345678) static_cast<int32_t *>(p.out)[lane] = x;
         return;
     }
-    conv_i8_epilogue<NB>(p, acc, s_row + wave * 32, col0, lane);
+    conv_i8_epilogue<NB, (DBG & (32 | 64))>(p, acc, s_row + wave * 32, col0, lane);
+    if (DBG & 16) {
+        __builtin_amdgcn_s_waitcnt(0);                           // this wave's stores have been issued and acknowledged
+        FPCC_I8_STAMP(39);
+        if (wave == 0) {
+            if (lane == 0) {
+                s_i8_stamp[44] = (unsigned long long)n_stages;
+                s_i8_stamp[45] = ((unsigned long long)blockIdx.x << 8) | blockIdx.y;
+                s_i8_stamp[46] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            }
+            __builtin_amdgcn_wave_barrier();
+            const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+            if (g_i8_stamp_buf && (wg + 1) * kI8StampSlots <= g_i8_stamp_cap && lane < kI8StampSlots)
+                g_i8_stamp_buf[wg * kI8StampSlots + lane] = s_i8_stamp[lane];
+        }
+    }
+#undef FPCC_I8_STAMP
 }
 
 // stand-alone epilogue on an int32 matrix: out = clamp(rha((prelu(in + bias)) * mul + zp, shift))
@@ -933,6 +1066,16 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 using namespace fpcc;
 
+static bool g_i8_stamps_on = false;
+extern "C" int fpcc_conv_i8_debug_stamps(unsigned long long *buf, int64_t n_u64) {
+    if (n_u64 < 0 || (n_u64 > 0 && !buf)) return fail_arg("conv_i8_debug_stamps: null buffer");
+    const long long cap = buf ? n_u64 : 0;
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamp_buf), &buf, sizeof(buf)));
+    FPCC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamp_cap), &cap, sizeof(cap)));
+    g_i8_stamps_on = buf != nullptr;
+    return FPCC_OK;
+}
+
 extern "C" int fpcc_int_init(void) {
     static bool done = false;
     if (done) return FPCC_OK;
@@ -1141,7 +1284,8 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
         return FPCC_OK;
     }
     static const int tiled = [] { const char *e = getenv("FPCC_I8_TILED"); return e ? atoi(e) : 1; }();
-    static const int tiled_dbg = [] { const char *e = getenv("FPCC_I8_DBG"); return e ? atoi(e) : 0; }();
+    static const int tiled_dbg_env = [] { const char *e = getenv("FPCC_I8_DBG"); return e ? atoi(e) : 0; }();
+    const int tiled_dbg = g_i8_stamps_on ? 16 : tiled_dbg_env;
     const unsigned idx_bytes = (unsigned)n_offsets * 128u * 4u;             // the tiled kernel's slice of the kernel map in LDS
     if (width > 64 && tiled && n_out >= 2048 && tiled_dbg) {
         const dim3 grid(gx, (width + 127) / 128);
@@ -1149,9 +1293,16 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
         if (tiled_dbg == 1) hipLaunchKernelGGL((k_conv_i8_tiled<4, 1>), grid, dim3(256), idx_bytes, s, p);
         else if (tiled_dbg == 8) hipLaunchKernelGGL((k_conv_i8_tiled<4, 8>), grid, dim3(256), idx_bytes, s, p);
         else if (tiled_dbg == 15) hipLaunchKernelGGL((k_conv_i8_tiled<4, 15>), grid, dim3(256), idx_bytes, s, p);
+        else if (tiled_dbg == 16) hipLaunchKernelGGL((k_conv_i8_tiled<4, 16>), grid, dim3(256), idx_bytes, s, p);   // stamps, results exact
+        else if (tiled_dbg == 32) hipLaunchKernelGGL((k_conv_i8_tiled<4, 32>), grid, dim3(256), idx_bytes, s, p);   // epilogue computes, stores nothing
+        else if (tiled_dbg == 64) hipLaunchKernelGGL((k_conv_i8_tiled<4, 64>), grid, dim3(256), idx_bytes, s, p);   // epilogue stores, computes nothing
         else hipLaunchKernelGGL((k_conv_i8_tiled<4, 7>), grid, dim3(256), idx_bytes, s, p);
     } else if (width > 64 && tiled && n_out >= 2048) {
-        hipLaunchKernelGGL((k_conv_i8_tiled<4>), dim3(gx, (width + 127) / 128), dim3(256), idx_bytes, s, p);
+        static const int tile_nb = [] { const char *e = getenv("FPCC_I8_NB"); return e ? atoi(e) : 4; }();
+        static const int tile_mw = [] { const char *e = getenv("FPCC_I8_MW"); return e ? atoi(e) : 4; }();
+        if (tile_nb == 2 && tile_mw == 3) hipLaunchKernelGGL((k_conv_i8_tiled<2, 0, 3>), dim3(gx, (width + 63) / 64), dim3(256), idx_bytes, s, p);
+        else if (tile_nb == 2) hipLaunchKernelGGL((k_conv_i8_tiled<2>), dim3(gx, (width + 63) / 64), dim3(256), idx_bytes, s, p);
+        else hipLaunchKernelGGL((k_conv_i8_tiled<4>), dim3(gx, (width + 127) / 128), dim3(256), idx_bytes, s, p);
     } else if (width > 64) {
         hipLaunchKernelGGL((k_conv_i8<4, false>), dim3(gx, (width + 127) / 128), dim3(256), 0, s, p, nullptr, 0);
     } else if (width > 32) {

@@ -39,6 +39,7 @@ _SIGS = {
                                 _vp, _i64, _i64, _vp, _i32, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
     'fpcc_conv_set_tuning': (_i32, [_i32, _i32]),
     'fpcc_conv_debug_stamps': (_i32, [_vp, _i64]),
+    'fpcc_conv_i8_debug_stamps': (_i32, [_vp, _i64]),
     'fpcc_time_next_launch': (_i32, [_vp, _vp]),
     'fpcc_transpose_table_i32': (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
     'fpcc_numerics_version': (_i32, []),
@@ -103,7 +104,7 @@ _SIGS = {
     'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
-_BLOCKING_ENTRY_POINTS = ('fpcc_hilbert3d_encode', 'fpcc_conv_debug_stamps', 'fpcc_int_init')
+_BLOCKING_ENTRY_POINTS = ('fpcc_hilbert3d_encode', 'fpcc_conv_debug_stamps', 'fpcc_conv_i8_debug_stamps', 'fpcc_int_init')
 
 _lib = None
 
@@ -470,6 +471,14 @@ def conv_debug_stamps(buf: Optional[torch.Tensor]) -> None:
         _ok(lib().fpcc_conv_debug_stamps(None, 0))
     else:
         _ok(lib().fpcc_conv_debug_stamps(_dev(buf, torch.int64, 'buf'), buf.numel()))
+
+
+def conv_i8_debug_stamps(buf: Optional[torch.Tensor]) -> None:
+    """attach (int64 device tensor) / detach (None) the stamp buffer of the int8 tiled convolution (fpcc_conv_i8_debug_stamps)"""
+    if buf is None:
+        _ok(lib().fpcc_conv_i8_debug_stamps(None, 0))
+    else:
+        _ok(lib().fpcc_conv_i8_debug_stamps(_dev(buf, torch.int64, 'buf'), buf.numel()))
 
 
 def conv_set_tuning(which: int, value: int) -> int:

@@ -223,6 +223,13 @@ int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64);
  * first launch and `end_event` after its last one, inside that one call -- recorded from the host language around the call, anything the
  * host does between the record and the launch (an interpreter switching threads) is timed as part of the kernel.  NULL, NULL cancels. */
 int fpcc_time_next_launch(void *start_event, void *end_event);
+/* The same diagnostics for the int8 tiled convolution (profiles/r05/int8_stage.md): while a buffer is attached, fpcc_conv_i8* launches
+ * of the 128-column tiled kernel run its stamped build (results exact) and wave 0 of every workgroup leaves 48 64-bit words:
+ * s_memtime at entry [0], kernel-map slice in LDS [1], offsets of the tile known [2], first W tile in LDS [3], top of stage s
+ * [4 + min(s, 32)], after the last stage [38], after the epilogue's stores [39]; [44] stages, [45] blockIdx.x << 8 | blockIdx.y,
+ * [46] HW_ID.  NULL / 0 detaches.  Blocks (hipMemcpyToSymbol). */
+int fpcc_conv_i8_debug_stamps(unsigned long long *buf, int64_t n_u64);
+
 /* 3x3x3 convolution of the constant-one one-channel input the codec starts from (model.py:132-136: features = 1 for every voxel):
  * out[o][j] = act(sum over existing neighbours k of w[k][j] + bias[j]), read from the rows' 27-bit presence masks
  * (fpcc_mask27_from_parent / fpcc_conv_row_keys) -- the chain of fpcc_conv_f32 with x = 1, bit for bit, without the 27-entry

@@ -194,3 +194,42 @@ def test_softmax_and_cdf(ops, c):
     hi = np.where(sym == c - 1, 65536, w64[np.arange(len(x)), sym])
     assert (start.cpu().numpy().view(np.uint16) == lo).all()
     assert (fm1.cpu().numpy().view(np.uint16) == hi - lo - 1).all()
+
+
+@pytest.mark.parametrize('shift', [1, 20, 31, 32, 33, 40, 60])
+@pytest.mark.parametrize('case', ['plain', 'slope_one', 'slope_big', 'slope_negative_one', 'bias_huge', 'mul_huge', 'no_prelu'])
+@pytest.mark.parametrize('out_bits', [8, 32])
+def test_tiled_epilogue_forms_bit_exact(ops, cloud, shift, case, out_bits):
+    """the fused epilogue of the tiled int8 convolution picks between a form without range checks (bounded accumulator, bias with room,
+    slope in (-1, 1], multiplier < 2^31; a high-word shortcut for shifts >= 32), the checked form and the generic wrapping form: every
+    combination equals the reference arithmetic (oracle/int_ops.c) exactly"""
+    rng = np.random.default_rng(shift * 31 + len(case) + out_bits)
+    c_in = c_out = 128
+    n = len(cloud)
+    a = rng.integers(-127, 128, (n, c_in)).astype(np.int8)
+    w = rng.integers(-127, 128, (27, c_out, c_in)).astype(np.int8)
+    bias = rng.integers(-20000, 20000, c_out).astype(np.int32)
+    mul = rng.integers(1 << 10, 1 << 18, c_out).astype(np.int64)
+    slope = np.array([int(0.3 * (1 << 25))], dtype=np.int32)
+    if case == 'slope_one':
+        slope[0] = 1 << 25
+    elif case == 'slope_big':
+        slope[0] = 3 << 25                                                  # PReLU may grow a value: checked form
+    elif case == 'slope_negative_one':
+        slope[0] = -(1 << 25)                                               # the excluded end of the slope interval
+    elif case == 'bias_huge':
+        bias[::3] = 2 ** 31 - 5                                             # acc + bias can leave int32: generic form for those waves
+        bias[1::3] = -2 ** 31 + 7
+    elif case == 'mul_huge':
+        mul[::2] = (1 << 31) + 12345                                        # multipliers of 2^31 and more
+    use_slope = case != 'no_prelu'
+    zp = np.array([(12345 << min(shift, 40)) + 77], dtype=np.int64)
+    table = oi.kernel_table(cloud, cloud, (3, 3, 3), (1, 1, 1))
+    acc = oi.conv_i8(a, table, w, None)
+    _, _, t = _table_gpu(ops, cloud, cloud, (3, 3, 3), (1, 1, 1))
+    from fastpcc_amd.int_sparse_conv import _pad_weight
+    got = ops.conv_i8(_cuda(a), _pad_weight(_cuda(w)), c_in, c_out, n, nbr=t, n_offsets=27, nbr_ks=1, nbr_os=27, nbr_bias=1,
+                      bias=_cuda(bias), slope=_cuda(slope) if use_slope else None, requant_mul=_cuda(mul).to(torch.uint32) if case != 'mul_huge' else _cuda(mul),
+                      zero_point=_cuda(zp), shift=shift, out_bits=out_bits)
+    want = oi.epilogue(acc, bias, slope if use_slope else None, mul, int(zp[0]), shift, out_bits)
+    assert (got.cpu().numpy() == (want.astype(np.int8) if out_bits == 8 else want)).all()
