@@ -63,11 +63,14 @@ def conv_flops(info, counts_cache):
     return 2.0 * pairs * info['c_in'] * info['c_out']
 
 
-def pmc_traffic():
-    """HBM bytes per MFMA convolution launch (k_conv_wave / k_conv_mfma) from the newest committed rocprofv3 PMC passes (profiles/r*/..._pmc_traffic.json,
-    made by profiles/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950
-    guide prescribes).  PMC counters cannot be collected from inside this process, so the committed measurement of the
-    same command is reported; None when there is none."""
+def pmc_traffic(batch, launches_per_step):
+    """HBM bytes per MFMA convolution launch (k_conv_wave / k_conv_mfma / ...) from the newest committed rocprofv3 PMC passes
+    (profiles/r*/..._pmc_traffic.json, made by profiles/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled
+    as the gfx950 guide prescribes).  PMC counters cannot be collected from inside this process, so the committed measurement of the
+    same command is reported; None when there is none.  The profiled command codes single frames (reference streams, the
+    one-frame-at-a-time leg) AND batches, so the file carries how many frame-equivalents it covers (`_meta`); the figure returned is
+    family bytes per frame x the frames of a launch of THIS run: bytes / frame_equivalents x batch / launches_per_step -- per launch,
+    like `achieved` and `algorithmic_bytes_per_launch`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_traffic.json')))
     if not files:
@@ -79,7 +82,11 @@ def pmc_traffic():
     total = sum(v['fetch_bytes'] + v['write_bytes'] for v in mfma)
     if not launches:
         return None, None
-    return total / launches, os.path.relpath(files[-1], ROOT)
+    meta = data.get('_meta') or {}
+    src = os.path.relpath(files[-1], ROOT)
+    if meta.get('frame_equivalents') and launches_per_step:
+        return total / meta['frame_equivalents'] * batch / launches_per_step, f"{src} ({meta.get('command', '')}; {meta['frame_equivalents']} frame-equivalents)"
+    return total / launches, src
 
 
 def cpu_model():
@@ -527,7 +534,7 @@ def main():
                     f.write(f"{'mfma' if info['mfma'] else 'valu'} {info['c_in']} {info['c_out']} {info['n_out']} "
                             f"{info['n_offsets']} {info['groups']} {dt:.4f} {fl / 1e9:.3f} {fl / dt / 1e9:.2f} "
                             f"{dense / dt / 1e9:.2f}\n")
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(B, n_launch // trace_steps)
         out = {
             'metric': 'encode+decode Mpoints/sec, lossy_coord_v2 baseline_r1',
             'value': round(total_points / elapsed_max / 1e6, 4),

@@ -131,7 +131,16 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, s: ConvSpec
     elif s.kind == 'k2s2T':
         dw = ops.conv_wgrad(x, dy, s.n_in, groups=8, out_map=s.table, om_os=8, om_gs=1)
     elif s.kind == 'gen':
-        dw = ops.conv_wgrad(x, dy, s.n_in, groups=8)
+        c_in, c_out = w.shape[-2], w.shape[-1]
+        if 8 * c_out <= 128 and c_in % 16 == 0 and (8 * c_out) % 32 == 0:
+            # a generated set's rows are 8 * parent + octant, so dY [8 m, c_out] IS [m, 8 c_out]: the eight octant gradients side by side
+            # are ONE per-point weight gradient X^T [c_in, m] . dY [m, 8 c_out] on the MFMA kernel (the mirror of the packed forward GEMM)
+            # instead of eight 16-column ones on the narrow kernels (64 -> 16 at 125 K rows: 0.70 ms at 0.4 TFLOP/s,
+            # profiles/r05/train_host_ops.md).  Same sums in the same row order per element.
+            wide = ops.conv_wgrad(x, dy.view(s.n_in, 8 * c_out), s.n_in)             # [1, 1, c_in, 8 c_out]
+            dw = wide.view(c_in, 8, c_out).permute(1, 0, 2).contiguous()
+        else:
+            dw = ops.conv_wgrad(x, dy, s.n_in, groups=8)
     elif s.kind == 'tab':
         k = s.table.shape[1]
         dw = torch.cat([ops.conv_wgrad(x, dy, s.n_out, nbr=s.table[:, a: a + _TAB_CHUNK].contiguous(),

@@ -80,7 +80,7 @@ def _check(kind, scene, c_in, c_out, seed):
 
 
 @pytest.mark.parametrize('kind', ['k1', 'k3', 'k2s2', 'k2s2T', 'gen'])
-@pytest.mark.parametrize('c_in,c_out', [(128, 128), (256, 128), (128, 64), (64, 32), (16, 64), (128, 1), (32, 1), (1, 16), (1, 64), (16, 8), (8, 1), (32, 8)])
+@pytest.mark.parametrize('c_in,c_out', [(128, 128), (256, 128), (128, 64), (64, 32), (16, 64), (128, 1), (32, 1), (1, 16), (1, 64), (16, 8), (8, 1), (32, 8), (64, 16)])
 def test_conv_gradients_match_torch_float64(scene, kind, c_in, c_out):
     _check(kind, scene, c_in, c_out, seed=c_in * 7 + c_out)
 

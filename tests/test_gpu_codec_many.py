@@ -217,3 +217,26 @@ def test_batched_colour_streams_equal_the_reference_runs_in_chain_order(run):
         rec_xyz, rec_rgb = m.decompress_many(streams)[at]
         assert rec_xyz.cpu().numpy().tolist() == run['recon_xyz']
         assert rec_rgb.cpu().numpy().astype(int).tolist() == run['recon_rgb']
+
+
+# ---- edges -----------------------------------------------------------------------------------------------------------------------------
+def test_edges_of_the_batch_interface(model, clouds):
+    """empty lists and host tensors are refused; a one-voxel cloud, a batch of many small clouds and repeated clouds code like any other"""
+    with pytest.raises(RuntimeError):
+        model.compress_many([])
+    with pytest.raises(RuntimeError):
+        model.compress_many([clouds[0], clouds[2].cpu()])
+    one = _dev(np.array([[7, 7, 7]]), (5, 6, 7))
+    rng = np.random.default_rng(12)
+    small = [_dev(np.unique(rng.integers(0, 40, (300 + 50 * i, 3)), axis=0), (i, 2 * i, 3 * i)) for i in range(9)]
+    batch = [one, *small, clouds[0], one]
+    many = model.compress_many(batch)
+    assert many[0] == many[-1] == model.compress(one)
+    for c, s in zip(batch, many):
+        assert s == model.compress(c)
+    back = model.decompress_many(many)
+    assert [b.shape[0] for b in back] == [model.decompress(s).shape[0] for s in many]
+    assert back[0].cpu().tolist() == [[12, 13, 14]]                          # the one voxel, offset restored
+    # the streams of a batch decode one at a time, and single-cloud streams decode as a batch
+    assert _same_points(model.decompress(many[3]), back[3])
+    assert _same_points(model.decompress_many([model.compress(c) for c in batch[:3]])[2], back[2])
