@@ -18,9 +18,15 @@
 #include <new>
 #include <thread>
 #include <vector>
-#if defined(__AVX2__)
+#if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -423,6 +429,160 @@ static inline int64_t count_le(const uint16_t *row, int64_t width, uint16_t targ
     return count;
 }
 
+#if defined(__x86_64__)
+// the same count with 32 entries per compare where the CPU has AVX-512BW (the GPU boxes' EPYC 9575F does; selected at run time, the
+// library itself is built for x86-64-v3)
+__attribute__((target("avx512f,avx512bw"))) static int64_t count_le_avx512(const uint16_t *row, int64_t width, uint16_t target) {
+    int64_t j = 0, count = 0;
+    const __m512i t = _mm512_set1_epi16(static_cast<short>(target));
+    for (; j + 32 <= width; j += 32)
+        count += __builtin_popcount(_mm512_cmple_epu16_mask(_mm512_loadu_si512(row + j), t));
+    if (j < width) {
+        const __mmask32 tail = (__mmask32)((1u << (width - j)) - 1u);
+        count += __builtin_popcount(_mm512_mask_cmple_epu16_mask(tail, _mm512_maskz_loadu_epi16(tail, row + j), t));
+    }
+    return count;
+}
+static const bool kHaveAvx512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
+#else
+static const bool kHaveAvx512 = false;
+static int64_t count_le_avx512(const uint16_t *row, int64_t width, uint16_t target) { return count_le(row, width, target); }
+#endif
+
+// ---- row warmers ----------------------------------------------------------------------------------------------------------------
+// The 255-ary decoder meets every CDF row cold: 510 bytes that a DMA engine wrote to pinned memory a moment ago, behind a serial
+// dependency (the row to search is known, the slot inside it only after the previous symbol) -- one core streaming 510 B per symbol
+// from DRAM, 15.5 ns per symbol on the GPU box whatever the search costs.  A few helper threads of this library read the rows of the
+// block AHEAD of the decoder (whole 4-KB pieces, round robin), which pulls them into the cache level the cores share; the decoder's
+// loads then hit there.  Nothing depends on the helpers: a row they have not reached yet comes from DRAM as before.  They are pinned to
+// CPUs that share a last-level cache with the calling thread (sysfs), FPCC_HOST_WARMERS = 0 .. 8 sets their number.
+// Measured (tools/r05/dec_bench.py, profiles/r05/int8_stage.md): on the build container's Xeon one helper halves the time per symbol
+// (62.8 -> 31.2 ns); on the GPU boxes' EPYC 9575F a single core already streams the rows at 42 GB/s and helpers change nothing
+// (12.1 ns without, 11.1-13.3 ns with 1-6) -- hence OFF by default; the AVX-512 search above is what moved that host (15.5 -> 12.1 ns).
+namespace {
+class RowWarmers {
+public:
+    static RowWarmers &get() { static RowWarmers w; return w; }
+    int count() const { return n_; }
+    // start warming [base, base + bytes); returns at once.  One decoder at a time owns the helpers (another thread's decoder that
+    // arrives meanwhile simply runs without them): true = the caller owns them and must call end()
+    bool begin(const void *base, size_t bytes) {
+        if (n_ == 0 || bytes < (size_t)1 << 20) return false;
+        if (busy_.exchange(true, std::memory_order_acquire)) return false;
+        pin_near_caller();
+        std::lock_guard<std::mutex> g(mu_);
+        base_ = static_cast<const char *>(base);
+        bytes_ = bytes;
+        next_.store(0, std::memory_order_relaxed);
+        stop_.store(false, std::memory_order_relaxed);
+        ++generation_;
+        active_ = n_;
+        cv_.notify_all();
+        return true;
+    }
+    // (owner only) stop the helpers and wait until none of them touches the buffer any more: it may be freed afterwards
+    void end() {
+        stop_.store(true, std::memory_order_relaxed);
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            idle_.wait(g, [this] { return active_ == 0; });
+            base_ = nullptr;
+        }
+        busy_.store(false, std::memory_order_release);
+    }
+
+private:
+    RowWarmers() {
+        const char *e = getenv("FPCC_HOST_WARMERS");
+        n_ = e ? atoi(e) : 0;
+        n_ = n_ < 0 ? 0 : (n_ > 8 ? 8 : n_);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)n_ + 1 > hw) n_ = hw > 1 ? (int)hw - 1 : 0;
+        for (int i = 0; i < n_; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~RowWarmers() {
+        { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            const char *base;
+            size_t bytes;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+                base = base_;
+                bytes = bytes_;
+            }
+            constexpr size_t kPiece = 4096;
+            unsigned sink = 0;
+            while (base && !stop_.load(std::memory_order_relaxed)) {
+                const size_t at = next_.fetch_add(kPiece, std::memory_order_relaxed);
+                if (at >= bytes) break;
+                const size_t end = at + kPiece < bytes ? at + kPiece : bytes;
+                for (size_t b = at; b < end; b += 64) __builtin_prefetch(base + b, 0, 2);
+                sink += static_cast<unsigned char>(*reinterpret_cast<const volatile char *>(base + end - 1));   // paces the prefetches
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                sink_ += sink;                     // (keeps the pacing loads alive)
+                --active_;
+            }
+            idle_.notify_all();
+        }
+    }
+    // the helpers onto CPUs that share a last-level cache with the caller (once per caller CPU)
+    void pin_near_caller() {
+#if defined(__linux__)
+        const int cpu = sched_getcpu();
+        if (cpu < 0 || cpu == pinned_for_) return;
+        pinned_for_ = cpu;
+        char path[128];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        FILE *f = fopen(path, "r");
+        if (!f) return;
+        char list[512] = {0};
+        const bool ok = fgets(list, sizeof list, f) != nullptr;
+        fclose(f);
+        if (!ok) return;
+        cpu_set_t allowed, set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+        for (char *p = list; *p;) {                                   // "a-b,c,d-e"
+            char *q;
+            const long lo = strtol(p, &q, 10);
+            if (q == p) break;
+            long hi = lo;
+            if (*q == '-') { p = q + 1; hi = strtol(p, &q, 10); }
+            for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+                if (c != cpu && CPU_ISSET(c, &allowed)) CPU_SET(c, &set);
+            p = (*q == ',') ? q + 1 : q;
+            if (*q != ',') break;
+        }
+        if (CPU_COUNT(&set) == 0) return;
+        for (auto &t : threads_) pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+#endif
+    }
+    int n_ = 0;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, idle_;
+    const char *base_ = nullptr;
+    size_t bytes_ = 0;
+    std::atomic<size_t> next_{0};
+    std::atomic<bool> stop_{false}, busy_{false};
+    uint64_t generation_ = 0;
+    int active_ = 0;
+    bool quit_ = false;
+    int pinned_for_ = -1;
+    unsigned sink_ = 0;
+};
+}  // namespace
+
 fpcc_simple_enc *fpcc_simple_enc_new(int64_t buf_bytes) {
     if (buf_bytes < 16) return nullptr;
     return new (std::nothrow) fpcc_simple_enc(buf_bytes);
@@ -484,6 +644,10 @@ int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_
     if (!d || !rows || !symbols_out || width < 1 || (n_rows != 1 && n_rows != n)) return FPCC_HOST_E_ARG;
     constexpr int64_t kAhead = 6;                       // rows requested ahead of the one being searched
     const int64_t row_bytes = width * 2;
+    const bool wide = kHaveAvx512 && width >= 64;
+    const bool warm = n_rows != 1 && n >= 2048;         // a block of cold rows: helpers read ahead of this thread (RowWarmers)
+    struct WarmEnd { bool on; ~WarmEnd() { if (on) RowWarmers::get().end(); } }
+        warm_end{warm && RowWarmers::get().begin(rows, static_cast<size_t>(n) * static_cast<size_t>(row_bytes))};
     for (int64_t i = 0; i < n; ++i) {
         const uint16_t *row = rows + (n_rows == 1 ? 0 : i * width);
         if (n_rows != 1 && i + kAhead < n) {
@@ -491,8 +655,9 @@ int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_
             for (int64_t b = 0; b < row_bytes; b += 64) __builtin_prefetch(ahead + b, 0, 0);
         }
         const uint32_t target = d->r.peek<kProbBits>();
-        int64_t s = width >= 32 ? count_le(row, width, static_cast<uint16_t>(target))
-                                : std::upper_bound(row, row + width, static_cast<uint16_t>(target)) - row;
+        int64_t s = wide ? count_le_avx512(row, width, static_cast<uint16_t>(target))
+                         : width >= 32 ? count_le(row, width, static_cast<uint16_t>(target))
+                                       : std::upper_bound(row, row + width, static_cast<uint16_t>(target)) - row;
         s = std::min<int64_t>(s, width - 1);
         uint32_t lo, hi;
         edge_range(row, width, static_cast<uint32_t>(s), lo, hi);

@@ -211,3 +211,47 @@ def test_multi_stream_encoder_matches_single():
         want = orc.BinaryRansCoder(1).encode(bits[start[s]:start[s + 1]].astype(bool)[None],
                                              prob[start[s]:start[s + 1]].astype(np.uint32)[None])[0]
         assert out[s, cap - lens[s]:].tobytes() == want
+
+
+def test_wide_row_decoder_with_row_warmers_and_concurrent_decoders():
+    """the 255-ary decoder on blocks of >= 2048 cold rows can start the library's row-warming helpers (FPCC_HOST_WARMERS, read once per
+    process: off by default, so this runs in a child process with two helpers; one decoder at a time owns them, a second decoder running
+    meanwhile goes without); same symbols either way, from several threads at once"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import threading
+import numpy as np
+from fastpcc_amd.rans_coder import RansDecoder, RansEncoder
+rng = np.random.default_rng(21)
+n = 6000
+f = rng.integers(1, 300, (n, 255)).astype(np.int64)
+f = (f * 65000 // f.sum(1, keepdims=True)) + 1
+cdf = np.cumsum(f, 1)
+cdf[:, -1] = 65535
+rows = cdf.astype(np.uint16)
+slot = rng.integers(0, 65535, n).astype(np.uint16)
+sym = (rows <= slot[:, None]).sum(1).clip(0, 254).astype(np.uint16)
+enc = RansEncoder(8 * 1024 * 1024)
+enc.encode(rows, sym)
+data = enc.flush()
+results = [None] * 4
+def work(i):
+    dec = RansDecoder()
+    dec.flush(data)
+    out = np.empty(n, dtype=np.uint16)
+    for a in range(0, n, 3000):                       # two blocks of 3000 rows x 510 bytes: above the warmers' threshold
+        dec.decode(rows[a:a + 3000], out[a:a + 3000])
+    results[i] = out
+threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+for t in threads: t.start()
+for t in threads: t.join()
+assert all((out == sym).all() for out in results)
+print('ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for warmers in ('2', '0'):
+        env = dict(os.environ, FPCC_HOST_WARMERS=warmers, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]

@@ -11,7 +11,7 @@ OUT=profiles/r05/sanitize.log
 SRC=fastpcc_amd/csrc/host/rans_host.cpp
 FR=${1:-800}
 : > $OUT
-for kind in thread address,undefined; do
+for kind in thread address,undefined; do   # (round 5, later: the row warmers of the 255-ary decoder are covered by the Python leg, test_rans_golden.py)
   tag=${kind%%,*}
   echo "== pool_stress under -fsanitize=$kind" | tee -a $OUT
   g++ -O1 -g -fno-omit-frame-pointer -fsanitize=$kind -std=c++17 -pthread -march=x86-64-v3 tools/r05/pool_stress.cpp $SRC -o /tmp/pool_$tag || exit 1
