@@ -479,7 +479,16 @@ def main():
     # disturbs that launch's own timing (+15 % on the traced kernel time when both were taken in the same steps)
     hipops.reserve_trace_events(600)
     hipops.CONV_TRACE, hipops.CLOCK_HOOK = [], clock_hook
-    one_frame(frame)
+    if B > 1:                                            # the clock of the workload the timed region ran: one batch, alone
+        extra = model.compress_many(frames)
+        torch.cuda.synchronize()
+        ME.clear_global_coordinate_manager()
+        model.decompress_many(extra)
+        torch.cuda.synchronize()
+        ME.clear_global_coordinate_manager()
+        del extra
+    else:
+        one_frame(frame)
     clock_trace, hipops.CONV_TRACE, hipops.CLOCK_HOOK = hipops.CONV_TRACE, None, None
 
     elapsed_max, total_points = replicas.aggregate(elapsed, float(points_per_step) * args.steps, device)
@@ -582,7 +591,7 @@ def main():
                          'shader_clock_mhz': None if shader_mhz is None else round(shader_mhz),
                          'frac_at_shader_clock': None if shader_mhz is None else
                          round(achieved / (MFMA_PEAK_TFLOPS * shader_mhz / 2400.0), 4),
-                         'shader_clock_note': 'mean clock measured beside the 3x3x3 launches on maps >= 50 K rows of one extra step after the timed '
+                         'shader_clock_note': 'mean clock measured beside the 3x3x3 launches on maps >= 50 K rows of one extra step (one batch) after the timed '
                                               'region (fpcc_clock_probe; profiles/r03/clock_ramp.md); `peak` and `frac` are quoted at the '
                                               'nominal 2400 MHz'},
         }

@@ -189,8 +189,31 @@ class GeoLosslessEntropyModel(nn.Module):
         stream, followed by a flag that releases the host job (fastpcc_amd/coder_pool.py).  One wait at the end."""
         return self.compress_clouds(y_top, 1)[0]
 
+    def _quiesce_pools(self) -> None:
+        """after an exception inside compress / decompress: no job of the coder pools may outlive the frame (it reads and writes buffers
+        the frame owns).  Copies still in flight are completed, encoder jobs that wait for a flag are released (their results are dropped),
+        running jobs are waited for; errors of those jobs are swallowed -- the caller is already propagating the real one."""
+        for dev, st in self._overlap.items():
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:
+                pass
+            st['flags'].fill_(1)
+            try:
+                st['pool'].wait()
+            except RuntimeError:
+                pass
+            st['pinned'] = []
+
     @torch.no_grad()
     def compress_clouds(self, y_top: ME.SparseTensor, n_clouds: int) -> List[bytes]:
+        try:
+            return self._compress_clouds(y_top, n_clouds)
+        except BaseException:
+            self._quiesce_pools()
+            raise
+
+    def _compress_clouds(self, y_top: ME.SparseTensor, n_clouds: int) -> List[bytes]:
         """`n_clouds` independent clouds on one coordinate manager (ME.CoordinateManager(clouds=n), rows cloud-major) through ONE
         traversal of the networks; every cloud gets the stream `compress` writes for it alone -- its own residual histogram, its own
         occupancy streams, its own header --, coded by its own jobs on the coder pool (the clouds' long passes run side by side).
@@ -398,6 +421,13 @@ class GeoLosslessEntropyModel(nn.Module):
 
     @torch.no_grad()
     def decompress_clouds(self, streams: List[bytes], cm: ME.CoordinateManager) -> ME.SparseTensor:
+        try:
+            return self._decompress_clouds(streams, cm)
+        except BaseException:
+            self._quiesce_pools()          # the background residual decode writes into a buffer this frame owns
+            raise
+
+    def _decompress_clouds(self, streams: List[bytes], cm: ME.CoordinateManager) -> ME.SparseTensor:
         """The streams of `len(streams)` independent clouds (each what `compress` writes) decoded in ONE traversal of the networks on
         `cm` (made with clouds=len(streams)): per occupancy level one device->host copy of the probabilities of all clouds, the
         clouds' streams decoded side by side on the coder pool, one host->device copy of the mask.  Returns the reconstructed top

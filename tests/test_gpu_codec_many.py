@@ -240,3 +240,30 @@ def test_edges_of_the_batch_interface(model, clouds):
     # the streams of a batch decode one at a time, and single-cloud streams decode as a batch
     assert _same_points(model.decompress(many[3]), back[3])
     assert _same_points(model.decompress_many([model.compress(c) for c in batch[:3]])[2], back[2])
+
+
+def test_an_exception_inside_a_frame_leaves_the_coder_pool_idle(model, clouds, monkeypatch):
+    """something raises in the middle of compress / decompress while jobs of the coder pool are queued or running (encoder jobs waiting
+    for their flags, the background residual decode): the frame releases and waits for them before the exception leaves it -- the next
+    frame finds an idle pool and its results are the usual ones"""
+    from fastpcc_amd import hipops
+    batch = [clouds[0], clouds[3]]
+    want = model.compress_many(batch)
+    want_points = [p.shape[0] for p in model.decompress_many(want)]
+    real = hipops.logit_to_prob16
+    for phase in ('compress', 'decompress'):
+        calls = []
+
+        def flaky(x):
+            calls.append(1)
+            if len(calls) == 3:
+                raise RuntimeError('injected')
+            return real(x)
+        monkeypatch.setattr(hipops, 'logit_to_prob16', flaky)
+        with pytest.raises(RuntimeError, match='injected'):
+            model.compress_many(batch) if phase == 'compress' else model.decompress_many(want)
+        monkeypatch.setattr(hipops, 'logit_to_prob16', real)
+        pool = model.em_lossless_based._overlap[torch.device('cuda', torch.cuda.current_device())]['pool']
+        assert pool.wait() == []                                              # nothing pending, no stale error
+        assert model.compress_many(batch) == want
+        assert [p.shape[0] for p in model.decompress_many(want)] == want_points
