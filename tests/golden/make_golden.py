@@ -1007,7 +1007,7 @@ def make_codec_int():
 
 
 def _functional_minkowski(order_fn=None):
-    """order_fn (round 4): None = every sum by torch (conv_mm / nn.Linear); else fastpcc_amd.engine.summation_order -- the stand-in
+    """order_fn (round 4): None = every sum by torch (conv_mm / nn.Linear); else oracle.orders.summation_order -- the stand-in
     then evaluates every convolution and linear layer as the fixed-order FMA chain the HIP kernels document
     (oracle/sparse_conv.py:conv_chain), so that a run of the REFERENCE's model code over it writes the bytes the GPU path must
     write exactly (tests/test_gpu_codec_v2.py::test_bytes_equal_the_reference_run_in_chain_order).
@@ -1582,15 +1582,15 @@ def make_codec_lossl():
 
 def make_codec_v2_chain():
     """lossy_coord_v2 runs of the REFERENCE's model code (as make_codec_v2) over the stand-in engine in CHAIN mode: every convolution
-    and linear layer summed in the order the HIP kernels document (fastpcc_amd.engine.summation_order; numerics version of
+    and linear layer summed in the order the HIP kernels document (oracle/orders.py, the restatement of the numerics version of
     include/fpcc_hip.h).  These streams are what the GPU path has to write byte for byte, and their reconstructions point for point --
     the mm-mode runs of codec_v2.json sum in torch's CPU order and can only be matched within tolerances."""
     import torch
     import torch.utils.cpp_extension as ce
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from fastpcc_amd.engine import summation_order
-    from fastpcc_amd import hipops
+    from oracle.orders import summation_order       # the oracle's restatement of the specification, NOT the product's rule
+    from fastpcc_amd import hipops                   # (tests/test_orders.py holds the product's rule against it)
     _stub_engines()
     _functional_minkowski(order_fn=summation_order)
     if REF not in sys.path:
@@ -1672,8 +1672,8 @@ def make_codec_color_chain():
     import yaml
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from fastpcc_amd.engine import summation_order
-    from fastpcc_amd import hipops
+    from oracle.orders import summation_order       # the oracle's restatement of the specification, NOT the product's rule
+    from fastpcc_amd import hipops                   # (tests/test_orders.py holds the product's rule against it)
     _stub_engines()
     _functional_minkowski(order_fn=summation_order)
     if REF not in sys.path:
