@@ -1580,11 +1580,10 @@ def make_codec_lossl():
     return out
 
 
-def make_codec_v2_chain():
-    """lossy_coord_v2 runs of the REFERENCE's model code (as make_codec_v2) over the stand-in engine in CHAIN mode: every convolution
-    and linear layer summed in the order the HIP kernels document (oracle/orders.py, the restatement of the numerics version of
-    include/fpcc_hip.h).  These streams are what the GPU path has to write byte for byte, and their reconstructions point for point --
-    the mm-mode runs of codec_v2.json sum in torch's CPU order and can only be matched within tolerances."""
+def _chain_env_v2():
+    """imports the reference's lossy_coord_v2 model code over the stand-in engine in CHAIN mode (see make_codec_v2_chain): -> (PCC,
+    ModelConfig, hipops)"""
+
     import torch
     import torch.utils.cpp_extension as ce
     if ROOT not in sys.path:
@@ -1607,6 +1606,16 @@ def make_codec_v2_chain():
         from models.convolutional.lossy_coord_v2.model_config import ModelConfig
     finally:
         ce.load = real
+    return PCC, ModelConfig, hipops
+
+
+def make_codec_v2_chain():
+    """lossy_coord_v2 runs of the REFERENCE's model code (as make_codec_v2) over the stand-in engine in CHAIN mode: every convolution
+    and linear layer summed in the order the HIP kernels document (oracle/orders.py, the restatement of the numerics version of
+    include/fpcc_hip.h).  These streams are what the GPU path has to write byte for byte, and their reconstructions point for point --
+    the mm-mode runs of codec_v2.json sum in torch's CPU order and can only be matched within tolerances."""
+    import torch
+    PCC, ModelConfig, hipops = _chain_env_v2()
     from fastpcc_amd.synthetic import batched, enliven, surface_cloud
     out = {'numerics_version': hipops.numerics_version(), 'runs': []}
     base = dict(activation='prelu', compressed_channels=(1,), skip_encoding_fea=1, adaptive_pruning=True)
@@ -1664,9 +1673,69 @@ def make_codec_v2_chain():
     return out
 
 
-def make_codec_color_chain():
-    """lossy_coord_lossy_color runs of the REFERENCE's model code (as make_codec_color) over the stand-in engine in CHAIN mode (see
-    make_codec_v2_chain): the streams the GPU path has to write byte for byte and the coloured clouds it has to decode point for point."""
+def make_codec_v2_partitions_chain():
+    """The reference's LIST path -- PCC.compress_partitions / decompress_partitions (lossy_coord_v2/model.py:247-256,277-288), which code
+    the clouds of a list one after the other -- executed in chain mode (as make_codec_v2_chain): the bytes and the decoded points that
+    the product's batched traversal (compress_many: ONE network pass over all clouds of the list) must reproduce.  The clouds of a run
+    differ in size by more than an order of magnitude, so that the row-count rule of the narrow layers (PAD_MIN_ROWS) differs between
+    the clouds of one list.  (All at 256^3: the reference's coder asserts on a cloud whose bottom level is a single voxel.)"""
+    import torch
+    PCC, ModelConfig, hipops = _chain_env_v2()
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    from oracle import sparse_conv as sc_
+    from lib.config import Config as RefConfig
+    real_sigmoid = torch.Tensor.sigmoid
+    out = {'numerics_version': hipops.numerics_version(), 'runs': []}
+    ref_cfg = RefConfig()
+    ref_cfg.merge_with_yaml(os.path.join(REF, 'config/convolutional/lossy_coord_v2/baseline_r1.yaml'))
+    ref_cfg.check()
+    mc = ref_cfg.model
+    cfg_dict = {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in vars(mc).items() if not k.startswith('_')}
+    for label, seed, clouds in (
+            ('baseline_r1_yaml_three_clouds', 8, [surface_cloud(60, 256, 9000) + np.array([1, 4, 2], dtype=np.int32),
+                                                  surface_cloud(61, 256, 500) + np.array([100, 3, 50], dtype=np.int32),
+                                                  surface_cloud(62, 256, 3000)]),
+            ('baseline_r1_yaml_two_clouds', 9, [surface_cloud(63, 256, 800), surface_cloud(64, 256, 14000) + np.array([0, 9, 1], dtype=np.int32)])):
+        torch.manual_seed(0)
+        model = PCC(mc)
+        enliven(model, seed)
+        model.eval()
+        rng = np.random.default_rng(seed)
+        parts = [torch.from_numpy(batched(c)[rng.permutation(len(c))]).to(torch.int32) for c in clouds]
+        torch.Tensor.sigmoid = lambda self: torch.from_numpy(sc_.sigmoid_spec(self)).to(self.device)
+        try:
+            with torch.no_grad():
+                blob = model.compress_partitions([torch.cat(parts), *parts])        # element 0: the unpartitioned cloud (model.py:249)
+                rec = model.decompress_partitions(blob)
+        finally:
+            torch.Tensor.sigmoid = real_sigmoid
+        rec_np = rec.cpu().numpy().astype(np.int64)
+        # the clouds' shares of the reconstruction: decompress_partitions concatenates them in list order
+        counts, hashes, at, pos = [], [], 0, 0
+        while pos != len(blob):
+            length = int.from_bytes(blob[pos:pos + 3], 'little')
+            torch.Tensor.sigmoid = lambda self: torch.from_numpy(sc_.sigmoid_spec(self)).to(self.device)
+            try:
+                with torch.no_grad():
+                    n_i = len(model.decompress(blob[pos + 3: pos + 3 + length]))
+            finally:
+                torch.Tensor.sigmoid = real_sigmoid
+            part = rec_np[at: at + n_i]
+            keys = np.sort((part[:, 0] << 42) | (part[:, 1] << 21) | part[:, 2])
+            counts.append(n_i)
+            hashes.append(hashlib.sha256(keys.tobytes()).hexdigest())
+            at, pos = at + n_i, pos + 3 + length
+        assert at == len(rec_np)
+        out['runs'].append({'label': label, 'config': cfg_dict, 'seed': seed, 'parts': [p[:, 1:].tolist() for p in parts],
+                            'yaml': 'config/convolutional/lossy_coord_v2/baseline_r1.yaml', 'blob_hex': blob.hex(),
+                            'recon_points': counts, 'recon_sha256': hashes})
+        print('codec_v2_partitions_chain', label, [len(c) for c in clouds], 'points ->', len(blob), 'bytes,', len(rec_np), 'decoded')
+    return out
+
+
+def _chain_env_color():
+    """imports the reference's lossy_coord_lossy_color model code over the stand-in engine in CHAIN mode: -> (PCC, ModelConfig, hipops)"""
+
     import torch
     import torch.utils.cpp_extension as ce
     import yaml
@@ -1690,6 +1759,64 @@ def make_codec_color_chain():
         from models.convolutional.lossy_coord_lossy_color.model_config import ModelConfig
     finally:
         ce.load = real
+    return PCC, ModelConfig, hipops
+
+
+def make_codec_color_partitions_chain():
+    """the reference's list path of the colour codec (lossy_coord_lossy_color/model.py:262-275,299-314) in chain mode, on a list of
+    coloured clouds of different sizes: see make_codec_v2_partitions_chain"""
+    import torch
+    import yaml
+    PCC, ModelConfig, hipops = _chain_env_color()
+    from fastpcc_amd.synthetic import batched, enliven, surface_cloud
+    from oracle import sparse_conv as sc_
+    real_sigmoid = torch.Tensor.sigmoid
+    out = {'numerics_version': hipops.numerics_version(), 'runs': []}
+    cfg = ModelConfig()
+    with open(os.path.join(REF, 'config/convolutional/lossy_coord_lossy_color/baseline_r1.yaml')) as f:
+        for k, v in yaml.safe_load(f)['model'].items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, tuple(v) if isinstance(v, list) else v)
+    cfg.compressed_channels = (cfg.compressed_channels[0],) if isinstance(cfg.compressed_channels, tuple) else (cfg.compressed_channels,)
+    cfg.check()
+    seed, gain = 4, 2.3
+    torch.manual_seed(0)
+    model = PCC(cfg)
+    enliven(model, seed, gain=gain)
+    model.eval()
+    rng = np.random.default_rng(seed)
+    clouds = [surface_cloud(70, 256, 7000) + np.array([1, 3, 0], dtype=np.int32), surface_cloud(71, 256, 700), surface_cloud(72, 256, 2500)]
+    xyzs, colors = [], []
+    for c in clouds:
+        perm = rng.permutation(len(c))
+        xyzs.append(torch.from_numpy(batched(c)[perm]).to(torch.int32))
+        colors.append(torch.from_numpy(np.clip(128 + 60 * np.sin(c[perm] / 7.0) + rng.normal(0, 12, c.shape), 0, 255).round().astype(np.float32)))
+    torch.Tensor.sigmoid = lambda self: torch.from_numpy(sc_.sigmoid_spec(self)).to(self.device)
+    try:
+        with torch.no_grad():
+            blob = model.compress_partitions([torch.cat(xyzs), *xyzs], [torch.cat(colors), *colors])
+            parts, pos = [], 0
+            while pos != len(blob):
+                length = int.from_bytes(blob[pos:pos + 3], 'little')
+                rec_xyz, rec_rgb = model.decompress(blob[pos + 3: pos + 3 + length])
+                parts.append({'recon_xyz': rec_xyz.tolist(), 'recon_rgb': rec_rgb.to(torch.int32).tolist()})
+                pos += 3 + length
+    finally:
+        torch.Tensor.sigmoid = real_sigmoid
+    out['runs'].append({'label': 'baseline_r1_yaml_three_clouds', 'seed': seed, 'gain': gain,
+                        'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items() if not k.startswith('_')},
+                        'xyz': [x[:, 1:].tolist() for x in xyzs], 'color': [c.to(torch.int32).tolist() for c in colors],
+                        'blob_hex': blob.hex(), 'parts': parts})
+    print('codec_color_partitions_chain', [len(c) for c in clouds], 'points ->', len(blob), 'bytes,', [len(p['recon_xyz']) for p in parts], 'decoded')
+    return out
+
+
+def make_codec_color_chain():
+    """lossy_coord_lossy_color runs of the REFERENCE's model code (as make_codec_color) over the stand-in engine in CHAIN mode (see
+    make_codec_v2_chain): the streams the GPU path has to write byte for byte and the coloured clouds it has to decode point for point."""
+    import torch
+    import yaml
+    PCC, ModelConfig, hipops = _chain_env_color()
     from fastpcc_amd.synthetic import batched, enliven, surface_cloud
     from oracle import sparse_conv as sc_
     real_sigmoid = torch.Tensor.sigmoid
@@ -1736,7 +1863,7 @@ def make_codec_color_chain():
 
 
 def main():
-    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_v2_chain', make_codec_v2_chain), ('codec_color_chain', make_codec_color_chain), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
+    for name, fn in (('get_keep', make_get_keep), ('codec_lossl', make_codec_lossl), ('codec_color', make_codec_color), ('codec_v2', make_codec_v2), ('codec_v2_chain', make_codec_v2_chain), ('codec_v2_partitions_chain', make_codec_v2_partitions_chain), ('codec_color_chain', make_codec_color_chain), ('codec_color_partitions_chain', make_codec_color_partitions_chain), ('codec_int', make_codec_int), ('codec_v3', make_codec_v3), ('hilbert', make_hilbert), ('me_semantics', make_me_semantics), ('entropy_model_hyperprior', make_entropy_model_hyperprior), ('entropy_model_indexed', make_entropy_model_indexed), ('ptq_import', make_ptq_import), ('kdtree', make_kdtree), ('entropy_model', make_entropy_model), ('rans', make_rans), ('morton', make_morton), ('byteslist', make_byteslist), ('explut', make_explut)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         data = fn()

@@ -84,3 +84,28 @@ def test_reference_run_in_chain_order(run):
     rec_xyz, rec_rgb = oracle.decompress(want)
     assert rec_xyz.tolist() == run['recon_xyz']
     assert np.asarray(rec_rgb).astype(int).tolist() == run['recon_rgb']
+
+
+# the reference's LIST path of the colour codec in chain order (codec_color_partitions_chain.json, round 5; see test_v2_golden.py)
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color_partitions_chain.json')) as f:
+    GP = json.load(f)
+
+
+@pytest.mark.parametrize('run', GP['runs'], ids=[r['label'] for r in GP['runs']])
+def test_reference_partition_lists_in_chain_order(run):
+    from oracle.orders import summation_order, NUMERICS_VERSION
+    assert GP['numerics_version'] == NUMERICS_VERSION, 'numerics version bumped: regenerate codec_color_partitions_chain.json'
+    cfg, model = chain_model_of(run)
+    weights = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    oracle = OracleColor(weights, cfg, conv='chain', order_fn=summation_order)
+    blob = bytes.fromhex(run['blob_hex'])
+    pos = 0
+    for xyz, color, part in zip(run['xyz'], run['color'], run['parts']):
+        length = int.from_bytes(blob[pos:pos + 3], 'little')
+        stream = blob[pos + 3: pos + 3 + length]
+        xyz = np.array(xyz, dtype=np.int64)
+        assert oracle.compress(np.concatenate((np.zeros((len(xyz), 1), np.int64), xyz), 1), np.array(color, dtype=np.uint8)) == stream
+        rec_xyz, rec_rgb = oracle.decompress(stream)
+        assert rec_xyz.tolist() == part['recon_xyz'] and np.asarray(rec_rgb).astype(int).tolist() == part['recon_rgb']
+        pos += 3 + length
+    assert pos == len(blob)

@@ -267,3 +267,78 @@ def test_an_exception_inside_a_frame_leaves_the_coder_pool_idle(model, clouds, m
         assert pool.wait() == []                                              # nothing pending, no stale error
         assert model.compress_many(batch) == want
         assert [p.shape[0] for p in model.decompress_many(want)] == want_points
+
+
+def _partition_runs():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2_partitions_chain.json')) as f:
+        g = json.load(f)
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import ModelConfig
+    keys = {f.name for f in __import__('dataclasses').fields(ModelConfig)}
+    return g['numerics_version'], [dict(r, config={k: v for k, v in r['config'].items() if k in keys}) for r in g['runs']]
+
+
+@pytest.mark.parametrize('run', _partition_runs()[1], ids=[r['label'] for r in _partition_runs()[1]])
+def test_partition_lists_equal_the_reference_runs_in_chain_order(run):
+    """STRICT, for the list path itself: the reference's compress_partitions / decompress_partitions (its own model code, clouds coded one
+    after the other, baseline_r1.yaml at its real widths, documented summation orders) wrote `blob`; the product's compress_partitions
+    -- ONE traversal over all clouds of the list -- must write the same bytes and decode them to the same points, cloud by cloud"""
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_v2 import Model
+    from fastpcc_amd.codecs.lossy_coord_v2.model_config import ModelConfig
+    assert _partition_runs()[0] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_v2_partitions_chain.json'
+    cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items()})
+    torch.manual_seed(0)
+    model = Model(cfg)
+    enliven(model, run['seed'])
+    model = model.cuda().eval()
+    parts = [_dev(np.array(p, dtype=np.int32)) for p in run['parts']]
+    want = bytes.fromhex(run['blob_hex'])
+    calls = []
+    real = model.compress_many
+    model.compress_many = lambda clouds: (calls.append(len(clouds)), real(clouds))[1]
+    blob = model.compress_partitions([torch.cat(parts), *parts])
+    assert calls == [len(parts)], 'the list was not coded in one traversal'
+    assert blob == want
+    rec = model.decompress_partitions(want).cpu().numpy().astype(np.int64)
+    at = 0
+    for n_i, sha in zip(run['recon_points'], run['recon_sha256']):
+        part = rec[at: at + n_i]
+        keys = np.sort((part[:, 0] << 42) | (part[:, 1] << 21) | part[:, 2])
+        assert hashlib.sha256(keys.tobytes()).hexdigest() == sha
+        at += n_i
+    assert at == len(rec)
+
+
+def test_colour_partition_lists_equal_the_reference_run_in_chain_order():
+    """the colour codec's list path: the reference's compress_partitions (clouds one after the other) against the product's (one
+    traversal): same bytes, same points and colours cloud by cloud (codec_color_partitions_chain.json)"""
+    import json
+    import os
+    from dataclasses import fields
+    from fastpcc_amd import hipops
+    from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
+    from fastpcc_amd.codecs.lossy_coord_lossy_color.model_config import ModelConfig
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_color_partitions_chain.json')) as f:
+        g = json.load(f)
+    assert g['numerics_version'] == hipops.numerics_version(), 'numerics version bumped: regenerate codec_color_partitions_chain.json'
+    known = {f.name for f in fields(ModelConfig)}
+    for run in g['runs']:
+        cfg = ModelConfig(**{k: tuple(v) if isinstance(v, list) else v for k, v in run['config'].items() if k in known})
+        torch.manual_seed(0)
+        m = Model(cfg)
+        enliven(m, run['seed'], gain=run['gain'])
+        m = m.cuda().eval()
+        xyz = [_dev(np.array(x, dtype=np.int32)) for x in run['xyz']]
+        rgb = [torch.from_numpy(np.array(c, dtype=np.uint8)).cuda() for c in run['color']]
+        want = bytes.fromhex(run['blob_hex'])
+        assert m.compress_partitions([torch.cat(xyz), *xyz], [torch.cat(rgb), *rgb]) == want
+        pos, streams = 0, []
+        while pos != len(want):
+            length = int.from_bytes(want[pos:pos + 3], 'little')
+            streams.append(want[pos + 3: pos + 3 + length])
+            pos += 3 + length
+        for (c, f), part in zip(m.decompress_many(streams), run['parts']):
+            assert c.cpu().numpy().tolist() == part['recon_xyz']
+            assert f.cpu().numpy().astype(int).tolist() == part['recon_rgb']

@@ -138,3 +138,36 @@ def test_reference_run_in_chain_order(run):
     assert oracle.compress(coords) == want
     rec = oracle.decompress(want)
     assert len(rec) == run['recon_points'] and recon_digest(rec.tolist()) == run['recon_sha256']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's LIST path in chain order (tests/golden/codec_v2_partitions_chain.json, round 5): compress_partitions /
+# decompress_partitions of the reference's model code on lists of clouds of very different sizes.  The oracle codes the clouds one at a
+# time (as the reference does); the product codes them in ONE traversal (tests/test_gpu_codec_many.py) -- both must give these bytes.
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'codec_v2_partitions_chain.json')) as f:
+    GP = json.load(f)
+
+
+def _partition_runs():
+    keys = {f.name for f in __import__('dataclasses').fields(ModelConfig)}
+    return [dict(r, config={k: v for k, v in r['config'].items() if k in keys}) for r in GP['runs']]
+
+
+@pytest.mark.parametrize('run', _partition_runs(), ids=[r['label'] for r in _partition_runs()])
+def test_reference_partition_lists_in_chain_order(run):
+    from oracle.orders import summation_order, NUMERICS_VERSION
+    assert GP['numerics_version'] == NUMERICS_VERSION, 'numerics version bumped: regenerate codec_v2_partitions_chain.json'
+    cfg, model = model_of(run)
+    weights = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    oracle = OracleV2(weights, cfg, conv='chain', order_fn=summation_order)
+    blob = bytes.fromhex(run['blob_hex'])
+    pos = 0
+    for part, n_i, sha in zip(run['parts'], run['recon_points'], run['recon_sha256']):
+        length = int.from_bytes(blob[pos:pos + 3], 'little')
+        stream = blob[pos + 3: pos + 3 + length]
+        xyz = np.array(part, dtype=np.int64)
+        assert oracle.compress(np.concatenate((np.zeros((len(xyz), 1), np.int64), xyz), 1)) == stream
+        rec = oracle.decompress(stream)
+        assert len(rec) == n_i and recon_digest(rec.tolist()) == sha
+        pos += 3 + length
+    assert pos == len(blob)
