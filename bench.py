@@ -40,6 +40,10 @@ def parse():
     ap.add_argument('--frames-in-flight', type=int, default=2, help='batches a rank keeps in flight on its GPU (fastpcc_amd/serving.py): '
                     '1 = one batch at a time')
     ap.add_argument('--latency-frames', type=int, default=12, help='frames of the one-frame-at-a-time figure `value_one_frame` (median; >= 10)')
+    ap.add_argument('--stages', type=int, default=-1, help='named stages of serving.py (one batch encodes while the other decodes): 1 on, 0 off '
+                    '(batches in flight run free), -1 = on below 4 frames per batch.  Single frames in flight fall into lock-step without '
+                    'them (profiles/r04/frames_in_flight.md); batches of 4-8 frames are GPU-bound either way and run 2-3 %% faster free '
+                    '(profiles/r05/batched_traversal.md)')
     ap.add_argument('--own-streams', type=int, default=0, help='1: every frame in flight on a HIP stream of its own (kernels of different frames overlap)')
     ap.add_argument('--ddp-steps', type=int, default=10, help='optimisation steps of the cfg#5 DDP figure (N > 1)')
     ap.add_argument('--ddp-deadline', type=float, default=420.0, help='seconds after which rank 0 prints the headline without the DDP figure')
@@ -398,11 +402,15 @@ def main():
     one_frame_ms = statistics.median(t[0] + t[1] for t in lat) * 1e3
     value_one_frame = n_points / one_frame_ms / 1e3
 
+    import contextlib
+    use_stages = args.stages == 1 or (args.stages < 0 and B < 4)
+    stage = pipeline.stage if use_stages else (lambda name: contextlib.nullcontext())
+
     def step_of(ctx_model, _):
-        with pipeline.stage('compress'):                 # one batch encodes while the other decodes (serving.py: FramePipeline.stage)
+        with stage('compress'):                          # one batch encodes while the other decodes (serving.py: FramePipeline.stage)
             data = ctx_model.compress_many(frames)       # returns when the bytes of every cloud are written
             ME.clear_global_coordinate_manager()
-        with pipeline.stage('decompress'):
+        with stage('decompress'):
             rec = ctx_model.decompress_many(data)
             wait_for_my_work(device)                     # this batch's last kernel, not the other batch's queue
             ME.clear_global_coordinate_manager()
@@ -562,7 +570,7 @@ def main():
                                    f'{depth} batch(es) in flight per GPU',
                        'parallelism': (f'replicas x{world} (independent frames)' if world > 1 else 'single GPU') +
                                       (f', {depth} batches in flight per GPU on one stream (fastpcc_amd/serving.py)' if depth > 1 else ''),
-                       'batch_clouds': B, 'frames_in_flight': depth, 'voxels_per_step': points_per_step,
+                       'batch_clouds': B, 'frames_in_flight': depth, 'named_stages': bool(use_stages), 'voxels_per_step': points_per_step,
                        'value_note': 'value = steps x voxels_per_step / elapsed of the whole timed region (throughput of a stream of frames); '
                                      f'value_one_frame = N0 / median(t_enc + t_dec) over {len(lat)} frames coded one at a time, each half closed '
                                      'by a device synchronise (the reference\'s timer placement), measured before the timed region; '
