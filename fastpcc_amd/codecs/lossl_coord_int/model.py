@@ -468,8 +468,12 @@ class Model(nn.Module):
             return sym
         rows_h = torch.empty(rows_d.shape, dtype=rows_d.dtype, pin_memory=True)
         out_h = torch.empty(n, dtype=torch.int16, pin_memory=True)
-        step = self.DECODE_CHUNK_ROWS
-        edges = list(range(0, n, step)) + [n]
+        # chunk sizes grow 2 Ki, 4 Ki, 8 Ki, then DECODE_CHUNK_ROWS: the host starts decoding after 1 MB has crossed instead of 8 MB
+        # (the first chunk is pure latency on the level's critical path), the later chunks keep the per-copy overhead small
+        edges, step = [0], min(2048, self.DECODE_CHUNK_ROWS)
+        while edges[-1] < n:
+            edges.append(min(n, edges[-1] + step))
+            step = min(2 * step, self.DECODE_CHUNK_ROWS)
         events = []
         for a, b in zip(edges[:-1], edges[1:]):
             rows_h[a:b].copy_(rows_d[a:b], non_blocking=True)
