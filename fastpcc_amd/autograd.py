@@ -106,6 +106,17 @@ def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
     if s.kind == 'k1':
         return _wide(lambda wt, c, out: ops.conv_f32(dy, wt, c, s.n_in, out=out, pack=PACK),
                      ops.transpose_weights(w, 1, c_in, c_out, flip=False).view(c_out, c_in), c_in, s.n_in, dy.device)
+    if s.kind == 'k3' and _one_channel_ok(c_in, c_out):
+        # Input gradient of a 3x3x3 convolution to ONE channel, the mirror of the forward's two-phase form: the 27 upstream scalars of
+        # every row gathered side by side, G[i][k] = dy[nbr[k][i]] (0 where the neighbour is absent), then ONE per-point MFMA GEMM
+        # G [n, 32] @ W' [32, c_in] with W'[k] = W[26 - k] -- instead of 27 scalar-times-row products per row on the VALU kernel
+        # (k_conv_valu<16>: 1.3 ms per step, profiles/r05/train_host_ops.md).
+        idx = s.table.long()                                              # [27, n]
+        g = torch.where(idx >= 0, dy.reshape(-1)[idx.clamp(min=0)], dy.new_zeros(()))
+        g = torch.nn.functional.pad(g.t(), (0, 5)).contiguous()           # [n, 32]
+        wt = torch.zeros((32, c_in), dtype=w.dtype, device=w.device)
+        wt[:27] = w.detach().reshape(27, c_in).flip(0)
+        return ops.conv_f32(g, wt, c_in, s.n_in, pack=PACK)
     if s.kind == 'k3':
         wt = ops.transpose_weights(w, 27, c_in, c_out, flip=True)         # W'[k] = W[26-k]^T
         return _wide(lambda wk, c, out: ops.conv_f32(dy, wk, c, s.n_in, nbr=s.table, n_offsets=27, nbr_ks=s.n_in, nbr_os=1,

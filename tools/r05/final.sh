@@ -8,9 +8,10 @@ timeout 1700 python3 -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.
 tail -4 $O/pytest_gpu.txt
 timeout 120 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt; tail -2 $O/smoke.txt
 timeout 900 python3 bench.py --dump-trace $O/conv_launches.txt > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; head -c 500 $O/bench_default.json; echo
-for cfg in "1 1" "1 2" "4 2" "8 1"; do set -- $cfg
+for cfg in "1 1" "1 2" "4 2" "8 1" "8 3"; do set -- $cfg
   timeout 400 python3 bench.py --batch $1 --frames-in-flight $2 --cpu-baseline 0 --secondary 0 > $O/bench_b$1_d$2.json 2> $O/bench_b$1_d$2.err; head -c 200 $O/bench_b$1_d$2.json; echo
 done
+timeout 400 python3 bench.py --stages 1 --cpu-baseline 0 --secondary 0 > $O/bench_b8_d2_stages.json 2> $O/bench_b8_d2_stages.err; head -c 200 $O/bench_b8_d2_stages.json; echo
 CMD="python3 bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- $CMD > $O/stats.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $CMD > $O/fetch.log 2>&1
