@@ -414,6 +414,8 @@ class Model(nn.Module):
         # True: the occupancy symbols of every level are decoded by fpcc_simple_dec_pop_dev (CDF rows never cross PCIe);
         # slower than the chunked host path on this codec (profiles/r02/device_rans.md), hence off by default
         self.device_decoder = False
+        self._clouds = None            # decompress_many: {'decoders', 'rows' (per cloud, of the level being decoded), 'threads'}
+        self._extra_encoders: List[RansEncoder] = []
 
     # ---------------------------------------------------------------------------------------------------------------
     def forward(self, pc_data: PCData):
@@ -481,29 +483,49 @@ class Model(nn.Module):
             ev.record()
             events.append(ev)
         rows_np, out_np = rows_h.numpy().view(np.uint16), out_h.numpy().view(np.uint16)
-        for (a, b), ev in zip(zip(edges[:-1], edges[1:]), events):
-            ev.synchronize()
-            self.rans_decoder.decode(rows_np[a:b], out_np[a:b])
+        clouds = self._clouds
+        if clouds is None:
+            for (a, b), ev in zip(zip(edges[:-1], edges[1:]), events):
+                ev.synchronize()
+                self.rans_decoder.decode(rows_np[a:b], out_np[a:b])
+        else:
+            # several clouds in one traversal (decompress_many): the level's rows are cloud-major, cloud c's symbols come from its own
+            # stream -- one host thread per cloud, each waiting only for the copies that cover its rows
+            if n != sum(clouds['rows']):
+                raise RuntimeError('the level does not hold the rows the clouds\' streams account for')
+            starts = np.concatenate(([0], np.cumsum(clouds['rows'])))
+
+            def decode_cloud(c: int) -> int:
+                lo, hi = int(starts[c]), int(starts[c + 1])
+                for (a, b), ev in zip(zip(edges[:-1], edges[1:]), events):
+                    a2, b2 = max(a, lo), min(b, hi)
+                    if a2 < b2:
+                        ev.synchronize()
+                        clouds['decoders'][c].decode(rows_np[a2:b2], out_np[a2:b2])
+                return _children_count(out_h.numpy()[lo:hi])
+            clouds['rows'] = list(clouds['threads'].map(decode_cloud, range(len(clouds['rows']))))
         out = out_h.to(logits.device, non_blocking=True)
-        out._fpcc_children = _children_count(out_h.numpy())
+        out._fpcc_children = _children_count(out_h.numpy()) if clouds is None else sum(clouds['rows'])
         return out
 
-    def rans_encode_fea(self, quantized_cdf: np.ndarray, rounded: np.ndarray):
-        self.rans_encoder.encode(quantized_cdf[None], rounded)
-        self.rans_encoder.encode(self.fea_side_info_cdf1, quantized_cdf[:-1] - 1)
+    def rans_encode_fea(self, quantized_cdf: np.ndarray, rounded: np.ndarray, encoder: Optional[RansEncoder] = None):
+        enc = encoder or self.rans_encoder
+        enc.encode(quantized_cdf[None], rounded)
+        enc.encode(self.fea_side_info_cdf1, quantized_cdf[:-1] - 1)
         if len(quantized_cdf) - 2 > self.fea_side_info_cdf2.shape[1]:
             raise ValueError('bottom coordinate alphabet too large')
-        self.rans_encoder.encode(self.fea_side_info_cdf2, np.array((len(quantized_cdf) - 2,), dtype=np.uint16))
+        enc.encode(self.fea_side_info_cdf2, np.array((len(quantized_cdf) - 2,), dtype=np.uint16))
 
-    def rans_decode_fea(self, length: int) -> np.ndarray:
+    def rans_decode_fea(self, length: int, decoder: Optional[RansDecoder] = None) -> np.ndarray:
+        dec = decoder or self.rans_decoder
         cdf_len = np.empty(1, dtype=np.uint16)
-        self.rans_decoder.decode(self.fea_side_info_cdf2, cdf_len)
+        dec.decode(self.fea_side_info_cdf2, cdf_len)
         cdf = np.empty(int(cdf_len[0]) + 1, dtype=np.uint16)
-        self.rans_decoder.decode(self.fea_side_info_cdf1, cdf)
+        dec.decode(self.fea_side_info_cdf1, cdf)
         cdf = np.pad(cdf + 1, (0, 1))
         cdf[-1] = 65535
         decoded = np.empty(length, dtype=np.uint16)
-        self.rans_decoder.decode(cdf[None], decoded)
+        dec.decode(cdf[None], decoded)
         return decoded
 
     @staticmethod
@@ -578,9 +600,177 @@ class Model(nn.Module):
             bs.write(self.rans_encoder.flush())
             return bs.getvalue()
 
+    # -- several clouds in one traversal -------------------------------------------------------------------------------------------
+    MANY_MAX_VOXELS = 2_000_000
+
+    def _groups(self, sizes: List[int]) -> List[List[int]]:
+        groups, cur, acc = [], [], 0
+        for i, n in enumerate(sizes):
+            if cur and (acc + n > self.MANY_MAX_VOXELS or len(cur) == 64):
+                groups.append(cur)
+                cur, acc = [], 0
+            cur.append(i)
+            acc += n
+        if cur:
+            groups.append(cur)
+        return groups
+
+    def _thread_pool(self, n: int):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = getattr(self, '_host_threads', None)
+        if pool is None or pool._max_workers < n:
+            pool = self._host_threads = ThreadPoolExecutor(max_workers=max(n, 4), thread_name_prefix='fpcc-int-coder')
+        return pool
+
+    @ops.no_gc_pause
+    @torch.no_grad()
+    def compress_many(self, clouds: List[torch.Tensor]) -> List[bytes]:
+        """B independent clouds (each int32 [n, 4], batch column 0) -> the stream `compress` writes for each, from ONE traversal of the
+        octree networks: the clouds become the samples of one batch (the hash-table kernel maps key on the batch column, so rows of
+        different clouds never neighbour; integer sums are exact in any order), every operator is launched once per level over all
+        clouds, and each cloud's (start, freq) pairs go to its own rANS stream, the clouds' streams coded side by side on host
+        threads.  The codec's launches are small (a LiDAR sweep has 113 K voxels on its finest level and 13 levels of ~60
+        operators each): this is what fills them.  What the reference does with a list one cloud at a time
+        (/root/reference/models/convolutional/lossl_coord_int/model.py compress_partitions)."""
+        B = len(clouds)
+        if B == 1:
+            return [self.compress(clouds[0])]
+        if B == 0 or not all(c.is_cuda for c in clouds):
+            raise RuntimeError('compress_many() takes a non-empty list of GPU tensors')
+        offsets = torch.stack([c.amin(0) for c in clouds])                  # [B, 4]; batch column 0
+        shift = offsets.clone()
+        shift[:, 0] = -torch.arange(B, device=shift.device, dtype=shift.dtype)
+        xyz = torch.cat([c - shift[b] for b, c in enumerate(clouds)])       # cloud b = sample b
+        keys = ops.morton3d_encode(xyz[:, 1:], (2, 1, 0)) | (xyz[:, 0].to(torch.int64) << 48)      # 'zyx' Morton inside a cloud
+        _, perm = ops.sort_keys(keys)
+        xyz = xyz[perm.long()].contiguous()
+        org = self.get_init_pc(xyz, 1)
+        skip = self.cfg.skip_top_scales_num
+        blocks = self.blocks_dec[skip:]
+        levels = self.max_downsample_times - skip
+        strided = [org]
+        for _ in range(levels):
+            strided.append(self.get_bin(strided[-1], org.F))
+        top = strided[-1]
+        cur_rec = SparseTensor(org.F[:top.C.shape[0]], top.C, (2 ** levels,) * 3)
+        cur_rec._caches = org._caches
+        # rows of every cloud on every coded level (level idx = levels .. 1) -- one small reduction per level, read back with the symbols
+        # (rows are cloud-major: a search for the cloud numbers in the batch column, no read-back -- torch.bincount would synchronise)
+        marks = torch.arange(B + 1, device=xyz.device, dtype=torch.int32)
+        rows_d = torch.stack([torch.searchsorted(strided[idx].C[:, 0].contiguous(), marks).diff() for idx in range(levels, 0, -1)])
+        pending = []
+        for idx in range(levels, 0, -1):
+            block = self._block(idx, blocks)
+            if isinstance(block, OneScalePredictor):
+                cur_rec, logits, symbols = block.compress(cur_rec, strided[idx - 1], strided[idx].F, self.bin2oct_kernel,
+                                                          if_upsample=idx != 1 and block.if_upsample,
+                                                          next_block=self._block(idx - 1, blocks) if idx > 1 else None)
+            else:
+                cur_rec, logits, symbols = block.compress(cur_rec, strided[idx: idx + block.pred_steps], self.bin2oct_kernel)
+            pending.append(ops.logits_to_ranges(logits.contiguous(), PRE_SHIFT, symbols.contiguous()))
+        sizes = [s.shape[0] for s, _ in pending]
+        start_h = torch.empty(sum(sizes), dtype=torch.int16, pin_memory=True)
+        freq_h = torch.empty(sum(sizes), dtype=torch.int16, pin_memory=True)
+        start_h.copy_(torch.cat([s for s, _ in pending]), non_blocking=True)
+        freq_h.copy_(torch.cat([f for _, f in pending]), non_blocking=True)
+        bottom_h = torch.empty((top.C.shape[0], 3), dtype=torch.int32, pin_memory=True)
+        bottom_h.copy_(top.C[:, 1:], non_blocking=True)
+        rows_h = torch.empty(rows_d.shape, dtype=rows_d.dtype, pin_memory=True)
+        rows_h.copy_(rows_d, non_blocking=True)
+        offset_h = torch.empty((B, 3), dtype=offsets.dtype, pin_memory=True)
+        offset_h.copy_(offsets[:, 1:], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+
+        start_np, freq_np = start_h.numpy().view(np.uint16), freq_h.numpy().view(np.uint16)
+        rows = rows_h.numpy().astype(np.int64)                              # [coded levels (coarse -> fine), B]
+        if (rows.sum(1) != np.array(sizes)).any():
+            raise RuntimeError('cloud row counts do not add up to the levels')
+        level_start = np.concatenate(([0], np.cumsum(sizes)))
+        cloud_start = np.concatenate((np.zeros((len(sizes), 1), np.int64), np.cumsum(rows, 1)), 1)
+        bottom_np, offs = bottom_h.numpy(), offset_h.numpy()
+        bottom_rows = rows[0]                                               # the coarsest coded level's rows ARE the bottom voxels
+        bottom_at = np.concatenate(([0], np.cumsum(bottom_rows)))
+        while len(self._extra_encoders) < B - 1:
+            self._extra_encoders.append(RansEncoder(32 * 1024 * 1024))
+        encoders = [self.rans_encoder, *self._extra_encoders[:B - 1]]
+
+        def code_cloud(c: int) -> bytes:
+            enc = encoders[c]
+            for lvl in range(len(sizes) - 1, -1, -1):                       # finest level first: the decoder pops coarse -> fine
+                a = int(level_start[lvl] + cloud_start[lvl, c])
+                enc.encode_ranges(start_np[a: a + rows[lvl, c]], freq_np[a: a + rows[lvl, c]])
+            mine = bottom_np[bottom_at[c]: bottom_at[c + 1]].reshape(-1)
+            self.rans_encode_fea(self.bottom_cdf(mine), mine.astype(np.uint16), enc)
+            head = b''.join(int(v).to_bytes(2, 'little') for v in offs[c].tolist()) + int(bottom_rows[c]).to_bytes(2, 'little')
+            return head + enc.flush()
+        return list(self._thread_pool(B).map(code_cloud, range(B)))
+
+    @ops.no_gc_pause
+    @torch.no_grad()
+    def decompress_many(self, streams: List[bytes]) -> List[torch.Tensor]:
+        """inverse of compress_many: the clouds' streams decoded in one traversal (per level one CDF launch and one set of copies for all
+        clouds, the clouds' symbols decoded side by side on host threads); -> one int32 [n_b, 3] tensor per cloud"""
+        B = len(streams)
+        if B == 1:
+            return [self.decompress(streams[0])]
+        if B == 0:
+            raise RuntimeError('decompress_many() takes a non-empty list of streams')
+        if self.device_decoder:
+            raise NotImplementedError('the device-side decoder takes one cloud')
+        device = self.fold2bin_kernel.device
+        skip = self.cfg.skip_top_scales_num
+        blocks = self.blocks_dec[skip:]
+        levels = self.max_downsample_times - skip
+        decoders, bottoms, offsets = [], [], []
+        for b, data in enumerate(streams):
+            offsets.append([int.from_bytes(data[i:i + 2], 'little') for i in (0, 2, 4)])
+            n_bottom = int.from_bytes(data[6:8], 'little')
+            dec = RansDecoder()
+            dec.flush(data[8:])
+            xyz = torch.from_numpy(self.rans_decode_fea(n_bottom * 3, dec).astype(np.int32)).reshape(-1, 3)
+            bottoms.append(F.pad(xyz, (1, 0, 0, 0), value=b))
+            decoders.append(dec)
+        self._clouds = {'decoders': decoders, 'rows': [b.shape[0] for b in bottoms], 'threads': self._thread_pool(B)}
+        try:
+            cur_rec = self.get_init_pc(torch.cat(bottoms).to(device), 2 ** levels)
+            cur_bins, top_rec, top_stride, cur_bin = [], None, None, None
+            for idx in range(levels, 0, -1):
+                block = self._block(idx, blocks)
+                if isinstance(block, OneScalePredictor):
+                    cur_rec, cur_bin = block.decompress(cur_rec, self.bin2oct_kernel, self.unfold_kernel, self.rans_decode_oct,
+                                                        if_upsample=idx != 1 and block.if_upsample,
+                                                        next_block=self._block(idx - 1, blocks) if idx > 1 else None)
+                else:
+                    cur_bins.append(cur_bin)
+                    cur_rec, cur_bin, top_rec, top_stride = block.decompress(
+                        cur_rec, cur_bins, top_rec, top_stride, self.bin2oct_kernel, self.unfold_kernel, self.rans_decode_oct)
+            if top_rec is None:
+                if cur_rec.stride[0] != 2:
+                    raise RuntimeError('unexpected final stride')
+                parents = cur_rec.C
+            else:
+                if top_stride != 2:
+                    raise RuntimeError('unexpected final stride')
+                parents = top_rec
+            recon = _children_of(parents, self.unfold_kernel, cur_bin)[:, 1:]
+            counts = self._clouds['rows']                                   # after the last level: the clouds' point counts
+        finally:
+            self._clouds = None
+        if sum(counts) != recon.shape[0]:
+            raise RuntimeError('decoded point counts do not add up')
+        offset_t = torch.tensor(offsets, device=device, dtype=torch.int32)
+        out, at = [], 0
+        for b, n in enumerate(counts):
+            out.append(recon[at: at + n] + offset_t[b][None])
+            at += n
+        return out
+
     def compress_partitions(self, batched_coord: List[torch.Tensor]) -> bytes:
-        parts = [self.compress(p) for p in batched_coord[1:]]
-        return b''.join(len(s).to_bytes(3, 'little') + s for s in parts)
+        parts = list(batched_coord[1:])                                      # element 0: the unpartitioned cloud
+        coded: List[bytes] = []
+        for g in self._groups([p.shape[0] for p in parts]):
+            coded.extend(self.compress_many([parts[i] for i in g]))
+        return b''.join(len(s).to_bytes(3, 'little') + s for s in coded)
 
     @ops.no_gc_pause
     @torch.no_grad()
@@ -625,11 +815,14 @@ class Model(nn.Module):
         return recon + torch.tensor(coord_offset, device=device, dtype=torch.int32)[None]
 
     def decompress_partitions(self, concat_bytes: bytes) -> torch.Tensor:
-        out, pos = [], 0
+        streams, pos = [], 0
         while pos != len(concat_bytes):
             length = int.from_bytes(concat_bytes[pos:pos + 3], 'little')
-            out.append(self.decompress(concat_bytes[pos + 3: pos + 3 + length]))
+            streams.append(concat_bytes[pos + 3: pos + 3 + length])
             pos += 3 + length
+        out: List[torch.Tensor] = []
+        for g in self._groups([len(s) for s in streams]):                    # (bytes ~ voxels at a few bits per voxel: a size proxy)
+            out.extend(self.decompress_many([streams[i] for i in g]))
         return torch.cat(out, 0)
 
     def test_forward(self, pc_data: PCData) -> dict:

@@ -84,3 +84,56 @@ def test_stream_identical_to_the_reference_run(run):
     assert model.compress(dev) == want
     rec = model.decompress(want).cpu().numpy().astype(np.int32)
     assert hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest() == run['recon_sha256']
+
+
+def test_several_clouds_in_one_traversal_write_the_single_cloud_streams():
+    """compress_many / decompress_many of the integer codec: B LiDAR sweeps as the samples of one batch, one launch per operator and
+    level over all of them, every cloud's stream byte-identical to the one it gets alone (and therefore to the oracle's) and decoded to
+    the same points in the same order; partition lists go through the same path"""
+    cfg, model, weights = _model(32, 0, 5)
+    clouds = [lidar_cloud(3, beams=16, azimuths=512) + np.array([11, 0, 5], dtype=np.int32),
+              lidar_cloud(4, beams=8, azimuths=256),
+              lidar_cloud(6, beams=24, azimuths=384) + np.array([0, 7, 0], dtype=np.int32)]
+    devs = [torch.from_numpy(batched(c)).cuda() for c in clouds]
+    alone = [model.compress(d) for d in devs]
+    recs = [model.decompress(s) for s in alone]
+    oracle = OracleInt(weights, cfg)
+    assert alone[1] == oracle.compress(batched(clouds[1]).astype(np.int64))
+    for pick in ([0, 1, 2], [2, 0], [1, 1]):
+        many = model.compress_many([devs[i] for i in pick])
+        for i, s in zip(pick, many):
+            assert s == alone[i], f'cloud {i} of batch {pick}: stream differs from the one coded alone'
+        for i, r in zip(pick, model.decompress_many(many)):
+            assert torch.equal(r, recs[i]), f'cloud {i} of batch {pick}: decoded points differ'
+    blob = model.compress_partitions([torch.cat(devs), *devs])
+    assert blob == b''.join(len(s).to_bytes(3, 'little') + s for s in alone)
+    rec = model.decompress_partitions(blob)
+    assert torch.equal(rec, torch.cat(recs))
+
+
+def test_batched_streams_equal_the_reference_runs():
+    """two clouds of the reference runs of codec_int.json that share a configuration, coded in one batch: each stream is the reference
+    run's bytes"""
+    from fastpcc_amd.codecs.lossl_coord_int import Config, Model
+    from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+    runs = _golden_runs()
+    by_cfg = {}
+    for r in runs:
+        by_cfg.setdefault((str(sorted(r['config'].items())), r['seed']), []).append(r)
+    checked = 0
+    for group in by_cfg.values():
+        run = group[0]
+        model = Model(Config(**run['config']), 'cuda')
+        randomize_(model, run['seed'])
+        model = model.cuda().eval()
+        mine = [torch.from_numpy(batched(np.array(r['xyz'], dtype=np.int32))).cuda() for r in group]
+        other = torch.from_numpy(batched(lidar_cloud(9, beams=8, azimuths=256))).cuda()
+        streams = model.compress_many([other, *mine])
+        for r, s in zip(group, streams[1:]):
+            assert s == bytes.fromhex(r['stream_hex'])
+            checked += 1
+        back = model.decompress_many(streams)
+        for r, rec in zip(group, back[1:]):
+            import hashlib
+            assert hashlib.sha256(np.ascontiguousarray(rec.cpu().numpy().astype(np.int32)).tobytes()).hexdigest() == r['recon_sha256']
+    assert checked == len(runs)
