@@ -24,9 +24,9 @@ import torch.nn.functional as F
 from ... import hipops as ops
 from ...data import PCData
 from ...int_sparse_conv import LinearIn8W8Out8, LinearIn8W8Out32, LinearPReLUIn8W8Out8, LinearPReLUIn8W8Out32, \
-    PReLUIn32Out32, RequantFxpToScaledInt8, SharedFxpShift, SparseConvIn8W8Out8, SparseConvIn8W8Out32, \
-    SparseConvPReLUIn8W8Out8, SparseConvPReLUIn8W8Out32, SparseResBlockIn32W8Out32, SparseTensor, \
-    sparse_conv_in8w8out32
+    PReLUIn32Out32, RequantFxpToScaledInt8, ROW_ORDER_MIN_ROWS, ROW_ORDER_WINDOW_LOG2, SharedFxpShift, SparseConvIn8W8Out8, \
+    SparseConvIn8W8Out32, SparseConvPReLUIn8W8Out8, SparseConvPReLUIn8W8Out32, SparseResBlockIn32W8Out32, SparseTensor, \
+    _kernel_table, sparse_conv_in8w8out32
 from ...rans_coder import RansDecoder, RansEncoder
 from .model_config import Config
 
@@ -132,7 +132,8 @@ def _as_occ(mask, count: Optional[int] = None) -> Occupancy:
         return mask
     occ = getattr(mask, '_fpcc_occ', None)                      # a bits matrix seen before (the encoder's levels)
     if occ is None:
-        occ = Occupancy(bits=mask, count=count)
+        sym = getattr(mask, '_fpcc_symbols', None)
+        occ = Occupancy(bits=mask, count=count) if sym is None else Occupancy(symbols=sym, count=count)
         try:
             mask._fpcc_occ = occ
         except AttributeError:
@@ -186,11 +187,78 @@ def _children_count(symbols: np.ndarray) -> int:
 
 def _symbols_of(bits: torch.Tensor, bin2oct: torch.Tensor) -> torch.Tensor:
     """8 occupancy bits (child k = 4dx + 2dy + dz) -> symbol in [0, 254] (model.py:60)"""
+    ready = getattr(bits, '_fpcc_symbols', None)                # written beside the bits by the octree analysis (fpcc_octree_level)
+    if ready is not None:
+        return ready
     return (bits.to(torch.int32) << bin2oct).sum(1, dtype=torch.int32).add_(-1).to(torch.int16)
 
 
 def _bits_of(symbols: torch.Tensor, bin2oct: torch.Tensor) -> Occupancy:
     return Occupancy(symbols=symbols)          # count: `_fpcc_children`, set where the symbols came from the host decoder
+
+
+# ---- a level per call -------------------------------------------------------------------------------------------------------------
+# The standard integer OneScalePredictor (ten of the thirteen levels of a LiDAR sweep, the seven coarsest of them a few hundred rows
+# each) is a fixed sequence of layers: its modules are described ONCE to the library (fpcc_int_onescale) and a level is two calls,
+# fpcc_int_level_trunk and fpcc_int_level_expand, instead of ~14 module calls -- the module tree, the state dict and the integers stay
+# what they are (every layer still goes through fpcc_conv_i8_also).  FAST_LEVELS = False keeps the layer-by-layer path (tests compare).
+FAST_LEVELS = True
+
+
+def _map27(x: SparseTensor):
+    """kernel map of the 3x3x3 / stride-1 convolutions on x's coordinates (and its neighbour-pattern row order on large maps), from or
+    into the cloud's caches -- what `_conv_on_sparse_tensor` + `sparse_conv_in8w8out32` do for the first such convolution of a level"""
+    caches, tag = x._caches, (x.stride, (3, 3, 3), (1, 1, 1))
+    cur = caches.kmaps.get(tag)
+    table = cur.get('in_out_maps') if cur is not None else None
+    if table is None:
+        hashmap, table = _kernel_table(x.C, x.C, (3, 3, 3), (1, 1, 1), caches.hashmaps.get(x.stride))
+        caches.kmaps.setdefault(tag, {}).setdefault('in_out_maps', table)
+        caches.hashmaps.setdefault(x.stride, hashmap)
+        caches.cmaps.setdefault(x.stride, (x.C, x.spatial_range))
+    order = getattr(table, '_fpcc_row_order', None)
+    if order is None and x.C.shape[0] > ROW_ORDER_MIN_ROWS:
+        order = table._fpcc_row_order = ops.conv_row_order(table - 1, 27, 1, 27, x.C.shape[0], ROW_ORDER_WINDOW_LOG2)
+    return table, order
+
+
+class _Described:
+    """a ctypes descriptor together with the tensors it points at and the modules it was read from"""
+
+    def __init__(self):
+        self.keep, self.layers, self.requants, self.desc = [], [], [], None
+
+    def layer(self, mod):
+        w = mod._padded_weight()
+        ep = mod._epilogue()
+        d = ops.i8_layer(w, mod.in_ch, mod.out_ch, bias=ep['bias'], slope=ep['slope'], requant_mul=ep['requant_mul'],
+                         zero_point=ep['zero_point'], shift=ep['shift'], out_bits=ep['out_bits'],
+                         zp_comp=mod.int_zero_point_in_comp if getattr(mod, 'use_zero_point_in', False) else None, keep=self.keep)
+        self.layers.append((mod, mod._buffers['weight'], mod._buffers['weight']._version, mod._buffers['weight'].data_ptr()))
+        return d
+
+    def requant(self, mod):
+        mul, zp, shift, _ = mod.hint(0)
+        self.requants.append((mod, mod._buffers['requant_mul']))
+        return ops.i8_requant(mul, zp, shift, keep=self.keep)
+
+    def valid(self) -> bool:
+        for mod, w, version, ptr in self.layers:
+            if mod._buffers['weight'] is not w or w._version != version or w.data_ptr() != ptr or mod._shift_host is None:
+                return False
+        for mod, mul in self.requants:
+            if mod._buffers['requant_mul'] is not mul or mod._shift_host is None:
+                return False
+        return True
+
+
+def _requant_desc(mod: RequantFxpToScaledInt8):
+    d = mod.__dict__.get('_fpcc_desc')
+    if d is None or not d.valid():
+        d = _Described()
+        d.desc = d.requant(mod)
+        mod.__dict__['_fpcc_desc'] = d
+    return d.desc
 
 
 class OneScalePredictor(nn.Module):
@@ -255,7 +323,83 @@ class OneScalePredictor(nn.Module):
             return [dec.input_requant]
         return None
 
+    # -- the level-per-call path ---------------------------------------------------------------------------------------------------
+    def _described(self):
+        """this block as a fpcc_int_onescale, or None when it is not the standard integer block (the float twin, other layer types,
+        a width that is not a multiple of 16): then the layer-by-layer path runs"""
+        if not FAST_LEVELS or self._feat is not OneScalePredictor._feat:
+            return None
+        d = self.__dict__.get('_fpcc_desc')
+        if d is not None and (d is False or d.valid()):
+            return d or None
+        self.__dict__['_fpcc_desc'] = d = self._describe() or False
+        return d or None
+
+    def _describe(self):
+        dec, pred, up = self.dec, self.pred, self.upsample
+        c = getattr(dec, 'ch', 0)
+        conv3 = lambda m, cls: type(m) is cls and m.kernel_size == (3, 3, 3) and m.stride == (1, 1, 1) and (m.in_ch, m.out_ch) == (c, c)
+        block = lambda b: type(b) is SparseResBlockIn32W8Out32 and b.ch == c and conv3(b.conv_prelu, SparseConvPReLUIn8W8Out8) and \
+            conv3(b.conv2, SparseConvIn8W8Out32)
+        if c < 16 or c % 16 or not block(dec) or len(pred) != 3 or type(pred[0]) is not RequantFxpToScaledInt8 or \
+                not conv3(pred[1], SparseConvPReLUIn8W8Out8) or type(pred[2]) is not LinearIn8W8Out32 or pred[2].in_ch != c:
+            return None
+        if up is not None and (len(up) != 5 or type(up[0]) is not RequantFxpToScaledInt8 or type(up[1]) is not LinearPReLUIn8W8Out32 or
+                               (up[1].in_ch, up[1].out_ch) != (c + 8, c) or not block(up[2]) or type(up[3]) is not RequantFxpToScaledInt8 or
+                               type(up[4]) is not LinearIn8W8Out32 or (up[4].in_ch, up[4].out_ch) != (c, 8 * c)):
+            return None
+        d = _Described()
+        t = ops.IntOneScale()
+        t.channels, t.has_upsample = c, int(up is not None)
+        t.dec_in, t.dec_conv1, t.dec_conv2 = d.requant(dec.input_requant), d.layer(dec.conv_prelu), d.layer(dec.conv2)
+        t.dec_slope = dec.prelu.slope.data_ptr()
+        t.pred_in, t.pred_conv, t.pred_linear = d.requant(pred[0]), d.layer(pred[1]), d.layer(pred[2])
+        d.keep.append(dec.prelu.slope)
+        if up is not None:
+            t.up_in, t.up_linear = d.requant(up[0]), d.layer(up[1])
+            t.up_res_in, t.up_conv1, t.up_conv2 = d.requant(up[2].input_requant), d.layer(up[2].conv_prelu), d.layer(up[2].conv2)
+            t.up_slope = up[2].prelu.slope.data_ptr()
+            t.up_out_in, t.up_out = d.requant(up[3]), d.layer(up[4])
+            d.keep.append(up[2].prelu.slope)
+        d.slopes = [(dec.prelu, dec.prelu._buffers['slope'])] + ([(up[2].prelu, up[2].prelu._buffers['slope'])] if up is not None else [])
+        base_valid = d.valid
+        d.valid = lambda: base_valid() and all(m._buffers['slope'] is s for m, s in d.slopes)
+        d.desc = t
+        return d
+
+    def _trunk_fast(self, d, cur_rec: SparseTensor):
+        if cur_rec.F.shape[1] == 1:
+            cur_rec = self.dec_init(cur_rec)
+        feat = cur_rec.F if cur_rec.F.is_contiguous() else cur_rec.F.contiguous()
+        ready = getattr(cur_rec.F, '_fpcc_q8', None)
+        table, order = _map27(cur_rec)
+        res, q_pred, q_up, logits = ops.int_level_trunk(d.desc, feat.shape[0], feat, None if ready is None else ready.get(id(self.dec.input_requant)),
+                                                        table, order, self.upsample is not None)
+        res._fpcc_q8 = {id(self.pred[0]): q_pred} if q_up is None else {id(self.pred[0]): q_pred, id(self.upsample[0]): q_up}
+        out = SparseTensor(res, cur_rec.C, cur_rec.stride, cur_rec.spatial_range)
+        out._caches = cur_rec._caches
+        return out, logits
+
+    def _expand_fast(self, d, cur_rec: SparseTensor, symbols: torch.Tensor, count: int, coords: Optional[torch.Tensor],
+                     child_coords: Optional[torch.Tensor], next_block) -> SparseTensor:
+        """coords: the level's coordinates when the children's are to be derived (decoder), else child_coords are given (encoder)"""
+        nxt = self._first_requant_of(next_block)
+        table, order = _map27(cur_rec)
+        feat, feat_q8, child = ops.int_level_expand(d.desc, cur_rec.F.shape[0], count, cur_rec.F, cur_rec.F._fpcc_q8[id(self.upsample[0])],
+                                                    symbols, coords, table, order, None if not nxt else _requant_desc(nxt[0]))
+        if feat_q8 is not None:
+            feat._fpcc_q8 = {id(nxt[0]): feat_q8}
+        return SparseTensor(feat, child if coords is not None else child_coords, tuple(s // 2 for s in cur_rec.stride))
+
     def compress(self, cur_rec, up_ref: SparseTensor, cur_bin, bin2oct_kernel, if_upsample, next_block=None):
+        d = self._described()
+        if d is not None:
+            cur_rec, cur_pred = self._trunk_fast(d, cur_rec)
+            cur_oct = _symbols_of(cur_bin, bin2oct_kernel).contiguous()
+            if if_upsample:
+                cur_rec = self._expand_fast(d, cur_rec, cur_oct, up_ref.C.shape[0], None, up_ref.C, next_block)
+                cur_rec._caches = up_ref._caches
+            return cur_rec, cur_pred, cur_oct
         cur_rec, cur_pred = self._trunk(cur_rec)
         cur_oct = _symbols_of(cur_bin, bin2oct_kernel)
         if if_upsample:
@@ -265,6 +409,14 @@ class OneScalePredictor(nn.Module):
         return cur_rec, cur_pred, cur_oct
 
     def decompress(self, cur_rec, bin2oct_kernel, unfold_kernel, rans_decode_oct, if_upsample, next_block=None):
+        d = self._described()
+        if d is not None:
+            cur_rec, cur_pred = self._trunk_fast(d, cur_rec)
+            symbols = rans_decode_oct(cur_pred)
+            cur_bin = _bits_of(symbols, bin2oct_kernel)
+            if if_upsample:         # (a fresh cache namespace per decoded level, as the layer-by-layer path has it)
+                cur_rec = self._expand_fast(d, cur_rec, symbols.contiguous(), cur_bin.count, cur_rec.C.contiguous(), None, next_block)
+            return cur_rec, cur_bin
         cur_rec, cur_pred = self._trunk(cur_rec)
         cur_bin = _bits_of(rans_decode_oct(cur_pred), bin2oct_kernel)
         if if_upsample:
@@ -451,6 +603,33 @@ class Model(nn.Module):
         ret._caches = caches
         return ret
 
+    @torch.no_grad()
+    def analyse(self, xyz: torch.Tensor, keys: torch.Tensor, levels: int, clouds: int = 1):
+        """The encoder's octree of a Morton-sorted cloud: what `levels` calls of `get_bin` return (the coordinate levels with their
+        child-occupancy bits, the (2, 2, 2) / stride-2 kernel maps and coordinate maps in the cloud's caches), from the sorted keys
+        instead of coordinate rows: one counting pass tells the rows of every level (the traversal's only read-back, where
+        unique_consecutive synchronised once per level), then each level is one call -- head flags, a scan and one kernel that
+        writes coordinates, bits, kernel map and coded symbols (fpcc_octree_level) -- against ~21 operators.
+        keys: `cloud << 48 | Morton('zyx')` of xyz's rows, ascending.  -> (levels of SparseTensor, rows[level][cloud])"""
+        org = self.get_init_pc(xyz, 1)
+        rows = ops.level_counts_clouds(keys, levels, 48, clouds)
+        caches = org._caches
+        strided, cur = [org], keys
+        for l in range(1, levels + 1):
+            d = ops.octree_level(cur, sum(rows[l]), 48 - 3 * l)
+            prev, stride = strided[-1], (2 ** l,) * 3
+            if prev.stride != (1, 1, 1):
+                caches.kmaps.setdefault((prev.stride, (2, 2, 2), (2, 2, 2)), {}).setdefault('in_out_maps', d['table'])
+                caches.cmaps.setdefault(prev.stride, (prev.C, prev.spatial_range))
+            caches.cmaps.setdefault(stride, (d['coords'], None))
+            bits = d['bits']
+            bits._fpcc_symbols = d['symbols']
+            level = SparseTensor(bits, d['coords'], stride, None)
+            level._caches = caches
+            strided.append(level)
+            cur = d['keys']
+        return strided, rows
+
     # -- entropy coding ------------------------------------------------------------------------------------------------
     DECODE_CHUNK_ROWS = 16384      # 8 MB of CDF rows per device->host copy
 
@@ -548,17 +727,13 @@ class Model(nn.Module):
             raise RuntimeError('compress() runs on the GPU; move the coordinates there first')
         coord_offset = xyz.amin(0)[1:]
         xyz = xyz - F.pad(coord_offset, (1, 0))
-        _, perm = ops.sort_keys(ops.morton3d_encode(xyz[:, 1:], (2, 1, 0)))       # 'zyx': z on Morton bit 0
+        keys, perm = ops.sort_keys(ops.morton3d_encode(xyz[:, 1:], (2, 1, 0)))    # 'zyx': z on Morton bit 0
         xyz = xyz[perm.long()].contiguous()
-        org = self.get_init_pc(xyz, 1)
         skip = self.cfg.skip_top_scales_num
         blocks = self.blocks_dec[skip:]
         levels = self.max_downsample_times - skip
-
-        strided = [org]
-        for _ in range(levels):
-            strided.append(self.get_bin(strided[-1], org.F))
-        top = strided[-1]
+        strided, _ = self.analyse(xyz, keys, levels)
+        org, top = strided[0], strided[-1]
         bottom_vals = top.C[:, 1:].reshape(-1)
         cur_rec = SparseTensor(org.F[:top.C.shape[0]], top.C, (2 ** levels,) * 3)
         cur_rec._caches = org._caches
@@ -642,22 +817,15 @@ class Model(nn.Module):
         shift[:, 0] = -torch.arange(B, device=shift.device, dtype=shift.dtype)
         xyz = torch.cat([c - shift[b] for b, c in enumerate(clouds)])       # cloud b = sample b
         keys = ops.morton3d_encode(xyz[:, 1:], (2, 1, 0)) | (xyz[:, 0].to(torch.int64) << 48)      # 'zyx' Morton inside a cloud
-        _, perm = ops.sort_keys(keys)
+        keys, perm = ops.sort_keys(keys)
         xyz = xyz[perm.long()].contiguous()
-        org = self.get_init_pc(xyz, 1)
         skip = self.cfg.skip_top_scales_num
         blocks = self.blocks_dec[skip:]
         levels = self.max_downsample_times - skip
-        strided = [org]
-        for _ in range(levels):
-            strided.append(self.get_bin(strided[-1], org.F))
-        top = strided[-1]
+        strided, level_rows = self.analyse(xyz, keys, levels, B)           # level_rows[l][c]: rows of cloud c on level l
+        org, top = strided[0], strided[-1]
         cur_rec = SparseTensor(org.F[:top.C.shape[0]], top.C, (2 ** levels,) * 3)
         cur_rec._caches = org._caches
-        # rows of every cloud on every coded level (level idx = levels .. 1) -- one small reduction per level, read back with the symbols
-        # (rows are cloud-major: a search for the cloud numbers in the batch column, no read-back -- torch.bincount would synchronise)
-        marks = torch.arange(B + 1, device=xyz.device, dtype=torch.int32)
-        rows_d = torch.stack([torch.searchsorted(strided[idx].C[:, 0].contiguous(), marks).diff() for idx in range(levels, 0, -1)])
         pending = []
         for idx in range(levels, 0, -1):
             block = self._block(idx, blocks)
@@ -675,14 +843,12 @@ class Model(nn.Module):
         freq_h.copy_(torch.cat([f for _, f in pending]), non_blocking=True)
         bottom_h = torch.empty((top.C.shape[0], 3), dtype=torch.int32, pin_memory=True)
         bottom_h.copy_(top.C[:, 1:], non_blocking=True)
-        rows_h = torch.empty(rows_d.shape, dtype=rows_d.dtype, pin_memory=True)
-        rows_h.copy_(rows_d, non_blocking=True)
         offset_h = torch.empty((B, 3), dtype=offsets.dtype, pin_memory=True)
         offset_h.copy_(offsets[:, 1:], non_blocking=True)
         torch.cuda.current_stream().synchronize()
 
         start_np, freq_np = start_h.numpy().view(np.uint16), freq_h.numpy().view(np.uint16)
-        rows = rows_h.numpy().astype(np.int64)                              # [coded levels (coarse -> fine), B]
+        rows = np.array([level_rows[idx] for idx in range(levels, 0, -1)], dtype=np.int64)     # [coded levels (coarse -> fine), B]
         if (rows.sum(1) != np.array(sizes)).any():
             raise RuntimeError('cloud row counts do not add up to the levels')
         level_start = np.concatenate(([0], np.cumsum(sizes)))

@@ -160,6 +160,56 @@ __global__ void k_coarsen_scatter(const int64_t *__restrict__ keys, int64_t n, c
     if (i == n - 1) count[0] = pos[i];
 }
 
+// ---- integer codec: one level of the encoder's octree analysis -----------------------------------------------------------------------
+// The first child of every parent (head flag set) walks its <= 7 following siblings and writes the parent's whole row of every table;
+// the spare threads zero the padding rows of the kernel map.  Keys: Morton code with z on bit 0 (child k = 4 dx + 2 dy + dz = key & 7),
+// sample index from bit `batch_shift` of the PARENT key upwards.
+__global__ void k_octree_level(const int64_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ flag,
+                               const int32_t *__restrict__ pos, int64_t m, int batch_shift, int64_t *__restrict__ pkeys,
+                               int32_t *__restrict__ coords, int32_t *__restrict__ bits, int32_t *__restrict__ table, int64_t table_rows,
+                               int16_t *__restrict__ symbols) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (table && i < table_rows - m) {
+        int4 *t = reinterpret_cast<int4 *>(table + (m + i) * 8);
+        t[0] = make_int4(0, 0, 0, 0);
+        t[1] = make_int4(0, 0, 0, 0);
+    }
+    if (i >= n || !flag[i]) return;
+    const int64_t p = pos[i] - 1;
+    if (p >= m) return;                                   // a caller's wrong row count must not write out of bounds
+    const int64_t pk = keys[i] >> 3;
+    int32_t rows[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[k] = 0;
+    for (int64_t j = i; j < n && j < i + 8; ++j) {
+        const int64_t kj = keys[j];
+        if ((kj >> 3) != pk) break;
+        const int oct = (int)(kj & 7);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k == oct) rows[k] = (int32_t)j + 1;
+    }
+    if (pkeys) pkeys[p] = pk;
+    if (coords) {
+        const uint64_t lo = (uint64_t)pk & ((1ull << batch_shift) - 1);
+        reinterpret_cast<int4 *>(coords)[p] = make_int4((int32_t)(pk >> batch_shift), (int32_t)gather21(lo >> 2), (int32_t)gather21(lo >> 1),
+                                                        (int32_t)gather21(lo));
+    }
+    if (table) {
+        int4 *t = reinterpret_cast<int4 *>(table + p * 8);
+        t[0] = make_int4(rows[0], rows[1], rows[2], rows[3]);
+        t[1] = make_int4(rows[4], rows[5], rows[6], rows[7]);
+    }
+    int sym = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sym |= (rows[k] != 0) << (7 - k);
+    if (bits) {
+        int4 *b = reinterpret_cast<int4 *>(bits + p * 8);
+        b[0] = make_int4(rows[0] != 0, rows[1] != 0, rows[2] != 0, rows[3] != 0);
+        b[1] = make_int4(rows[4] != 0, rows[5] != 0, rows[6] != 0, rows[7] != 0);
+    }
+    if (symbols) symbols[p] = (int16_t)(sym - 1);
+}
+
 struct ByteToInt {
     __host__ __device__ int32_t operator()(uint8_t b) const { return b ? 1 : 0; }
 };
@@ -530,6 +580,27 @@ extern "C" int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_
     hipLaunchKernelGGL(k_coarsen_scatter, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
                        (const int32_t *)flag, (const int32_t *)pos, parent_of, pkeys, child_row, count_out);
     FPCC_LAUNCHED(k_coarsen_scatter);
+    return FPCC_OK;
+}
+
+extern "C" int64_t fpcc_octree_level(const int64_t *keys, int64_t n, int64_t m, int batch_shift, int64_t *pkeys, int32_t *coords,
+                                     int32_t *bits, int32_t *table, int64_t table_rows, int16_t *symbols, void *ws, int64_t ws_bytes,
+                                     void *stream) {
+    if (n < 0 || m < 0 || m > n || batch_shift < 0 || batch_shift > 62) return fail_arg("octree_level: sizes out of range");
+    int32_t *flag = nullptr, *pos = nullptr;
+    if (ws && n > 0 && !keys) return fail_arg("octree_level: null pointer");
+    if (ws && table && (table_rows < m || (reinterpret_cast<uintptr_t>(table) & 15) != 0))
+        return fail_arg("octree_level: the kernel map needs >= m rows and 16-byte alignment");
+    if (ws && ((reinterpret_cast<uintptr_t>(coords) & 15) != 0 || (reinterpret_cast<uintptr_t>(bits) & 15) != 0))
+        return fail_arg("octree_level: coords and bits must be 16-byte aligned");
+    int64_t rc = flags_and_scan(keys, n, 3, ws, ws_bytes, stream, &flag, &pos, "octree_level");
+    if (!ws || rc != FPCC_OK) return rc;
+    const int64_t spare = table ? table_rows - m : 0;
+    const int64_t threads = n > spare ? n : spare;
+    if (threads == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_octree_level, dim3(blocks_for(threads, kThreads)), dim3(kThreads), 0, as_stream(stream), keys, n,
+                       (const int32_t *)flag, (const int32_t *)pos, m, batch_shift, pkeys, coords, bits, table, table_rows, symbols);
+    FPCC_LAUNCHED(k_octree_level);
     return FPCC_OK;
 }
 

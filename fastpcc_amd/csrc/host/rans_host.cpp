@@ -458,7 +458,9 @@ static int64_t count_le_avx512(const uint16_t *row, int64_t width, uint16_t targ
 // CPUs that share a last-level cache with the calling thread (sysfs), FPCC_HOST_WARMERS = 0 .. 8 sets their number.
 // Measured (tools/r05/dec_bench.py, profiles/r05/int8_stage.md): on the build container's Xeon one helper halves the time per symbol
 // (62.8 -> 31.2 ns); on the GPU boxes' EPYC 9575F a single core already streams the rows at 42 GB/s and helpers change nothing
-// (12.1 ns without, 11.1-13.3 ns with 1-6) -- hence OFF by default; the AVX-512 search above is what moved that host (15.5 -> 12.1 ns).
+// (12.1 ns without, 11.1-13.3 ns with 1-6) in that bench, whose rows the CPU itself had just written.  In the codec the rows arrive
+// by DMA from the GPU and are cold: there ONE helper takes cfg#3's decode from 19.1 to 16.9 ms (2 or 4: 18.5; tools/r05/g27.sh) --
+// hence one helper by default.
 namespace {
 class RowWarmers {
 public:
@@ -494,7 +496,7 @@ public:
 private:
     RowWarmers() {
         const char *e = getenv("FPCC_HOST_WARMERS");
-        n_ = e ? atoi(e) : 0;
+        n_ = e ? atoi(e) : 1;
         n_ = n_ < 0 ? 0 : (n_ > 8 ? 8 : n_);
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && (unsigned)n_ + 1 > hw) n_ = hw > 1 ? (int)hw - 1 : 0;

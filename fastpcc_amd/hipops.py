@@ -26,6 +26,7 @@ _SIGS = {
     'fpcc_sort_keys': (_i64, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_unique_keys': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_coarsen': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'fpcc_octree_level': (_i64, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     'fpcc_level_histogram': (_i64, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_level_histogram_clouds': (_i64, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -101,6 +102,8 @@ _SIGS = {
                                  _vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     'fpcc_epilogue_i32_also': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
     'fpcc_fill_bits_i8': (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'fpcc_int_level_trunk': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    'fpcc_int_level_expand': (_i64, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_octree_children': (_i64, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 HIP_SYMBOLS = tuple(_SIGS) + ('fpcc_last_error',)
@@ -296,6 +299,23 @@ def coarsen(keys: torch.Tensor):
     _ok(L.fpcc_coarsen(kp, n, parent_of.data_ptr(), pkeys.data_ptr(), child_row.data_ptr(), count.data_ptr(),
                        ws.data_ptr(), need, _stream()))
     return parent_of, pkeys, child_row, count
+
+
+def octree_level(keys: torch.Tensor, m: int, batch_shift: int) -> dict:
+    """One level of the integer codec's encoder-side octree analysis (fpcc_octree_level): sorted duplicate-free keys [n] (Morton code
+    with z on bit 0, sample index above it) and the row count m of the next coarser level -> dict(keys int64 [m], coords int32 [m, 4]
+    = (sample, x, y, z), bits int32 [m, 8], table int32 [ceil128(m), 8] (child row + 1 | 0), symbols int16 [m])."""
+    n, dev = keys.shape[0], keys.device
+    rows = (m + 127) // 128 * 128
+    out = {'keys': torch.empty(m, dtype=torch.int64, device=dev), 'coords': torch.empty((m, 4), dtype=torch.int32, device=dev),
+           'bits': torch.empty((m, 8), dtype=torch.int32, device=dev), 'table': torch.empty((rows, 8), dtype=torch.int32, device=dev),
+           'symbols': torch.empty(m, dtype=torch.int16, device=dev)}
+    L = lib()
+    ws, need = _ws(lambda: L.fpcc_octree_level(None, n, m, batch_shift, None, None, None, None, 0, None, None, 0, None), dev)
+    _ok(L.fpcc_octree_level(_dev(keys, torch.int64, 'keys'), n, m, int(batch_shift), out['keys'].data_ptr(), out['coords'].data_ptr(),
+                            out['bits'].data_ptr(), out['table'].data_ptr(), rows, out['symbols'].data_ptr(), ws.data_ptr(), need,
+                            _stream()))
+    return out
 
 
 def level_counts(keys: torch.Tensor, levels: int) -> List[int]:
@@ -1180,6 +1200,107 @@ def octree_children(n: int, m: int, *, symbols: Optional[torch.Tensor] = None, b
                                ptr('octant'), ptr('table'), table_rows if want_table else 0, ptr('bits'), ptr('fxp'),
                                ws.data_ptr(), need, _stream()))
     return out
+
+
+
+# ---- integer codec: one level of the traversal per call (fpcc_int_level_trunk / fpcc_int_level_expand) ------------------------------------
+class I8Layer(C.Structure):
+    """fpcc_i8_layer"""
+    _fields_ = [('w', _vp), ('ldw', _i32), ('c_in', _i32), ('c_out', _i32), ('n_offsets', _i32), ('zp_comp', _vp), ('bias', _vp),
+                ('slope', _vp), ('requant_mul', _vp), ('zero_point', _vp), ('shift', _i32), ('out_bits', _i32)]
+
+
+class I8Requant(C.Structure):
+    """fpcc_i8_requant"""
+    _fields_ = [('requant_mul', _vp), ('zero_point', _vp), ('shift', _i32)]
+
+
+class IntOneScale(C.Structure):
+    """fpcc_int_onescale"""
+    _fields_ = [('channels', _i32), ('has_upsample', _i32),
+                ('dec_in', I8Requant), ('dec_conv1', I8Layer), ('dec_conv2', I8Layer), ('dec_slope', _vp),
+                ('pred_in', I8Requant), ('pred_conv', I8Layer), ('pred_linear', I8Layer),
+                ('up_in', I8Requant), ('up_linear', I8Layer),
+                ('up_res_in', I8Requant), ('up_conv1', I8Layer), ('up_conv2', I8Layer), ('up_slope', _vp),
+                ('up_out_in', I8Requant), ('up_out', I8Layer)]
+
+
+def i8_layer(w_padded: torch.Tensor, c_in: int, c_out: int, *, bias, slope, requant_mul, zero_point, shift: int, out_bits: int,
+             zp_comp=None, keep: list) -> I8Layer:
+    """descriptor of one int8 layer; the tensors it points at are appended to `keep` (the caller holds them as long as the descriptor)"""
+    mul = _mul_u32(requant_mul)
+    keep.extend(t for t in (w_padded, bias, slope, mul, zero_point, zp_comp) if t is not None)
+    if w_padded.dtype != torch.int8 or not w_padded.is_contiguous() or w_padded.dim() != 3 or w_padded.shape[1] != c_out or w_padded.shape[2] % 16:
+        raise ValueError('weights must be contiguous int8 [n_offsets, c_out, ldw] with ldw a multiple of 16')
+    return I8Layer(w_padded.data_ptr(), w_padded.shape[2], c_in, c_out, w_padded.shape[0], _dev(zp_comp, torch.int32, 'zp_comp', True),
+                   _dev(bias, torch.int32, 'bias', True), _dev(slope, torch.int32, 'slope', True), _any(mul, 'requant_mul', _U32),
+                   _dev(zero_point, torch.int64, 'zero_point'), int(shift), int(out_bits))
+
+
+def i8_requant(requant_mul: torch.Tensor, zero_point: torch.Tensor, shift: int, *, keep: list) -> I8Requant:
+    mul = _mul_u32(requant_mul)
+    keep.extend((mul, zero_point))
+    return I8Requant(_any(mul, 'requant_mul', _U32), _dev(zero_point, torch.int64, 'zero_point'), int(shift))
+
+
+_level_ws = {}          # (entry point, C, n, m) -> bytes: the size queries of the last levels seen (a frame asks for the same few again)
+
+
+def int_level_trunk(blk: IntOneScale, n: int, feat: torch.Tensor, feat_q8: Optional[torch.Tensor], nbr27: torch.Tensor,
+                    row_order: Optional[torch.Tensor], want_up: bool):
+    """fpcc_int_level_trunk -> (res int32 [n, C], q_pred int8 [n, C], q_up int8 [n, ceil16(C + 8)] | None, logits int32 [n, 255])"""
+    c, dev = blk.channels, feat.device
+    if feat.dtype != torch.int32 or tuple(feat.shape) != (n, c) or not feat.is_contiguous():
+        raise ValueError('feat must be contiguous int32 [n, channels]')
+    if feat_q8 is not None and (feat_q8.dtype != torch.int8 or tuple(feat_q8.shape) != (n, c) or not feat_q8.is_contiguous()):
+        raise ValueError('feat_q8 must be contiguous int8 [n, channels]')
+    ld_up = (c + 8 + 15) // 16 * 16
+    res = torch.empty((n, c), dtype=torch.int32, device=dev)
+    q_pred = torch.empty((n, c), dtype=torch.int8, device=dev)
+    q_up = torch.empty((n, ld_up), dtype=torch.int8, device=dev) if want_up else None
+    logits = torch.empty((n, blk.pred_linear.c_out), dtype=torch.int32, device=dev)
+    L, ref = lib(), C.byref(blk)
+    key = ('trunk', c, n, feat_q8 is None)
+    need = _level_ws.get(key)
+    if need is None:
+        if len(_level_ws) > 256:
+            _level_ws.clear()
+        need = _level_ws[key] = int(_ok(L.fpcc_int_level_trunk(ref, n, None, feat_q8.data_ptr() if feat_q8 is not None else None, None,
+                                                              None, None, None, None, 0, None, None, 0, None)))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _ok(L.fpcc_int_level_trunk(ref, n, feat.data_ptr(), None if feat_q8 is None else feat_q8.data_ptr(), _dev(nbr27, torch.int32, 'nbr27'),
+                               _dev(row_order, torch.int32, 'row_order', True), res.data_ptr(), q_pred.data_ptr(),
+                               None if q_up is None else q_up.data_ptr(), ld_up, logits.data_ptr(), ws.data_ptr(), need, _stream()))
+    return res, q_pred, q_up, logits
+
+
+def int_level_expand(blk: IntOneScale, n: int, m: int, res: torch.Tensor, q_up: torch.Tensor, symbols: torch.Tensor,
+                     coords: Optional[torch.Tensor], nbr27: torch.Tensor, row_order: Optional[torch.Tensor],
+                     next_in: Optional[I8Requant]):
+    """fpcc_int_level_expand -> (feat int32 [m, C], feat_q8 int8 [m, C] | None, child_coords int32 [m, 4] | None)"""
+    c, dev = blk.channels, res.device
+    if symbols.dtype != torch.int16 or symbols.shape[0] != n or not symbols.is_contiguous():
+        raise ValueError('symbols must be contiguous int16 [n]')
+    if q_up.dtype != torch.int8 or q_up.shape[0] != n or not q_up.is_contiguous() or tuple(res.shape) != (n, c) or not res.is_contiguous():
+        raise ValueError('res / q_up must be the tensors int_level_trunk returned')
+    feat = torch.empty((m, c), dtype=torch.int32, device=dev)
+    feat_q8 = torch.empty((m, c), dtype=torch.int8, device=dev) if next_in is not None else None
+    child = torch.empty((m, 4), dtype=torch.int32, device=dev) if coords is not None else None
+    L, ref = lib(), C.byref(blk)
+    key = ('expand', c, n, m)
+    need = _level_ws.get(key)
+    if need is None:
+        if len(_level_ws) > 256:
+            _level_ws.clear()
+        need = _level_ws[key] = int(_ok(L.fpcc_int_level_expand(ref, n, m, None, None, 0, None, None, None, None, None, None, None, None,
+                                                               None, 0, None)))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _ok(L.fpcc_int_level_expand(ref, n, m, res.data_ptr(), q_up.data_ptr(), q_up.shape[1], symbols.data_ptr(),
+                                _dev(coords, torch.int32, 'coords', True), _dev(nbr27, torch.int32, 'nbr27'),
+                                _dev(row_order, torch.int32, 'row_order', True), None if child is None else child.data_ptr(), feat.data_ptr(),
+                                None if next_in is None else C.byref(next_in), None if feat_q8 is None else feat_q8.data_ptr(),
+                                ws.data_ptr(), need, _stream()))
+    return feat, feat_q8, child
 
 
 def prelu_i32(a: torch.Tensor, slope: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:

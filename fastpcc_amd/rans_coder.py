@@ -161,7 +161,10 @@ class RansEncoder:
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
         if h:
-            host().fpcc_simple_enc_free(h)
+            try:
+                host().fpcc_simple_enc_free(h)
+            except Exception:                     # interpreter shutdown: the module globals are already gone, the OS takes the memory
+                pass
 
     def __deepcopy__(self, memo):                 # the native handle is not shareable: a copy gets its own (empty) coder
         return RansEncoder(self._cap)
@@ -203,7 +206,10 @@ class RansDecoder:
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
         if h:
-            host().fpcc_simple_dec_free(h)
+            try:
+                host().fpcc_simple_dec_free(h)
+            except Exception:
+                pass
 
     def __deepcopy__(self, memo):
         return RansDecoder()

@@ -86,6 +86,17 @@ int64_t fpcc_unique_keys(const int64_t *keys, int64_t n, int64_t *ukeys_out, int
  *   count_out             device int32[1], number of parents. */
 int64_t fpcc_coarsen(const int64_t *keys, int64_t n, int32_t *parent_of, int64_t *pkeys, int32_t *child_row,
                      int32_t *count_out, void *ws, int64_t ws_bytes, void *stream);
+/* One level of the integer codec's ENCODER-side octree analysis (replaces get_bin: out_coords = unique_consecutive(coords >> 1) and the
+ * (2, 2, 2) / stride-2 "fold" convolution over a hash-table kernel map, models/convolutional/lossl_coord_int/model.py:262-295 -- about
+ * 21 device operations and one synchronisation per level there): from the sorted, duplicate-free keys[n] of a level -- Morton code
+ * with z on bit 0, so that key & 7 = 4 dx + 2 dy + dz is the child's kernel offset, the sample index above the code -- the next coarser
+ * level with m rows (known from fpcc_level_histogram[_clouds]): pkeys[m] = keys >> 3 (sample index from bit `batch_shift` up),
+ * coords int32 [m][4] = (sample, x, y, z), bits int32 [m][8] (0 | 1 per child: the fold convolution's output), table int32
+ * [table_rows >= m][8] (child row + 1, 0 = none, padding rows zeroed: the kernel map fpcc_conv_i8 reads for that convolution),
+ * symbols int16 [m] (occupancy byte - 1, bit 7 - k = child k, model.py:60).  Any output may be NULL.  ws == NULL returns the
+ * workspace size. */
+int64_t fpcc_octree_level(const int64_t *keys, int64_t n, int64_t m, int batch_shift, int64_t *pkeys, int32_t *coords, int32_t *bits,
+                          int32_t *table, int64_t table_rows, int16_t *symbols, void *ws, int64_t ws_bytes, void *stream);
 /* Row counts of the `levels` (1..21) next coarser levels of a sorted, duplicate-free key array in ONE pass, so that a whole pyramid
  * costs one count read-back instead of one per level: hist[t], t = 0..levels (int32, zeroed here), = number of neighbouring key pairs
  * whose highest differing bit is in [3 t, 3 t + 3) (t clamped to `levels`); the map `l` levels coarser has
@@ -537,6 +548,52 @@ int fpcc_logits_to_cdf16(const int32_t *logits, int64_t n, int c, int pre_shift,
  * symbol instead of 2*c), ready for fpcc_simple_enc_push_ranges. */
 int fpcc_logits_to_ranges(const int32_t *logits, int64_t n, int c, int pre_shift, const int16_t *symbols,
                           uint16_t *start_out, uint16_t *freq_minus_1_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Integer codec: the traversal of one octree level in two calls                                                  */
+/* ------------------------------------------------------------------------------------------------------------ */
+/* One int8 convolution / linear layer with its fixed-point epilogue -- the state of a SparseConv*In8W8* / Linear*In8W8* module
+ * (lib/int_sparse_conv/cuda_ops.py:194-206,516-528): w int8 [n_offsets][c_out][ldw] (rows zero-padded to ldw, a multiple of 16);
+ * the other fields as fpcc_conv_i8 takes them. */
+typedef struct {
+    const int8_t *w; int ldw; int c_in; int c_out; int n_offsets;
+    const int32_t *zp_comp; const int32_t *bias; const int32_t *slope;
+    const uint32_t *requant_mul; const int64_t *zero_point; int shift; int out_bits;
+} fpcc_i8_layer;
+/* RequantFxpToScaledInt8 (cuda_ops.py:473-509): Q8.23 -> scaled int8; shift already includes the 23 fraction bits */
+typedef struct { const uint32_t *requant_mul; const int64_t *zero_point; int shift; } fpcc_i8_requant;
+/* The layers of a OneScalePredictor (models/convolutional/lossl_coord_int/model.py:95-213) of `channels` = C (a multiple of 16):
+ *   dec      SparseResBlockIn32W8Out32: dec_in (input_requant), dec_conv1 (C->C, 3x3x3, PReLU, int8), dec_conv2 (C->C, 3x3x3, Q8.23),
+ *            dec_slope (the block's PReLU, Q6.25)
+ *   pred     pred_in, pred_conv (C->C, 3x3x3, PReLU, int8), pred_linear (C->255, Q8.23 logits)
+ *   upsample (has_upsample) up_in, up_linear (C+8 -> C, PReLU, Q8.23), a residual block (up_res_in, up_conv1, up_conv2, up_slope),
+ *            up_out_in, up_out (C -> 8 C, Q8.23). */
+typedef struct {
+    int channels; int has_upsample;
+    fpcc_i8_requant dec_in; fpcc_i8_layer dec_conv1, dec_conv2; const int32_t *dec_slope;
+    fpcc_i8_requant pred_in; fpcc_i8_layer pred_conv, pred_linear;
+    fpcc_i8_requant up_in; fpcc_i8_layer up_linear;
+    fpcc_i8_requant up_res_in; fpcc_i8_layer up_conv1, up_conv2; const int32_t *up_slope;
+    fpcc_i8_requant up_out_in; fpcc_i8_layer up_out;
+} fpcc_int_onescale;
+/* First half of a level (OneScalePredictor._trunk, model.py:125-137,150-152): res_out = dec(feat), logits = pred(res_out), every layer
+ * through fpcc_conv_i8_also as the layer-by-layer path issues it (same integers).  feat int32 [n][C] (Q8.23); feat_q8 int8 [n][C] =
+ * feat requantised by dec_in when its producer wrote it (NULL: done here); nbr27 / row_order: the kernel map of the level's 3x3x3
+ * convolutions as fpcc_conv_i8 reads it (row + 1 | 0, [ceil128(n)][27]; row_order may be NULL).  Outputs: res_out int32 [n][C], q_pred
+ * int8 [n][C] (res_out requantised by pred_in), q_up int8 [n][ld_up] (by up_in, columns [C, ld_up) left to fpcc_int_level_expand; NULL
+ * for a block without upsampling), logits int32 [n][255].  ws == NULL returns the workspace size. */
+int64_t fpcc_int_level_trunk(const fpcc_int_onescale *blk, int64_t n, const int32_t *feat, const int8_t *feat_q8, const int32_t *nbr27,
+                             const int32_t *row_order, int32_t *res_out, int8_t *q_pred, int8_t *q_up, int ld_up, int32_t *logits,
+                             void *ws, int64_t ws_bytes, void *stream);
+/* Second half (OneScalePredictor._expand, model.py:139-148,169-175): the features of the m occupied children of the level's n voxels,
+ * feat_out int32 [m][C] = upsample(cat(res, occupancy bits)) evaluated for the occupied (row, octant) pairs only (row-major), and
+ * feat_q8_out int8 [m][C] = feat_out requantised by *next_in (the next level's dec_in; both may be NULL).  symbols int16 [n] (symbol + 1
+ * = the occupancy byte); coords int32 [n][4] + child_coords int32 [m][4]: the decoder's coordinate step (both NULL on the encoder side,
+ * which has the coordinates from its analysis); q_up as fpcc_int_level_trunk left it, ld_up >= ceil16(C + 8). */
+int64_t fpcc_int_level_expand(const fpcc_int_onescale *blk, int64_t n, int64_t m, const int32_t *res, int8_t *q_up, int ld_up,
+                              const int16_t *symbols, const int32_t *coords, const int32_t *nbr27, const int32_t *row_order,
+                              int32_t *child_coords, int32_t *feat_out, const fpcc_i8_requant *next_in, int8_t *feat_q8_out, void *ws,
+                              int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* rANS decoders on the device (one wave per stream; the streams of libfpcc_host, same arithmetic)                  */

@@ -137,3 +137,84 @@ def test_batched_streams_equal_the_reference_runs():
             import hashlib
             assert hashlib.sha256(np.ascontiguousarray(rec.cpu().numpy().astype(np.int32)).tobytes()).hexdigest() == r['recon_sha256']
     assert checked == len(runs)
+
+
+@pytest.mark.parametrize('clouds', [1, 3])
+def test_octree_analysis_equals_get_bin(clouds):
+    """Model.analyse (one counting pass + fpcc_octree_level per level, from the sorted keys) against the operator-by-operator form
+    it replaces (get_bin: unique_consecutive + the fold convolution over a hash-table kernel map, the reference's own sequence):
+    coordinates, occupancy bits, coded symbols and the (2, 2, 2) kernel map of every level, for one cloud and for a batch"""
+    from fastpcc_amd import hipops as ops
+    from fastpcc_amd.codecs.lossl_coord_int.model import _symbols_of
+    cfg, model, _ = _model(32, 0, 5)
+    parts = []
+    for b in range(clouds):
+        c = batched(lidar_cloud(3 + b, beams=8 + 4 * b, azimuths=256))
+        c[:, 0] = b
+        parts.append(c)
+    xyz = torch.from_numpy(np.concatenate(parts)).cuda()
+    keys = ops.morton3d_encode(xyz[:, 1:], (2, 1, 0)) | (xyz[:, 0].to(torch.int64) << 48)
+    keys, perm = ops.sort_keys(keys)
+    xyz = xyz[perm.long()].contiguous()
+    levels = model.max_downsample_times
+    mine, rows = model.analyse(xyz, keys, levels, clouds)
+    ref = [model.get_init_pc(xyz, 1)]
+    for _ in range(levels):
+        ref.append(model.get_bin(ref[-1], ref[0].F))
+    assert len(mine) == len(ref) == levels + 1
+    for l in range(1, levels + 1):
+        a, b = mine[l], ref[l]
+        assert a.stride == b.stride and torch.equal(a.C, b.C), f'level {l}: coordinates'
+        assert a.F.dtype == b.F.dtype and torch.equal(a.F, b.F), f'level {l}: occupancy bits'
+        sym = a.F._fpcc_symbols
+        plain = b.F.clone()                                       # no symbols attached: the tensor-operator form
+        assert torch.equal(sym, _symbols_of(plain, model.bin2oct_kernel)), f'level {l}: symbols'
+        assert rows[l] == torch.bincount(a.C[:, 0], minlength=clouds).tolist(), f'level {l}: rows per cloud'
+        if l >= 2:
+            tag = (ref[l - 1].stride, (2, 2, 2), (2, 2, 2))
+            assert torch.equal(mine[0]._caches.kmaps[tag]['in_out_maps'], ref[0]._caches.kmaps[tag]['in_out_maps']), f'level {l}: kernel map'
+            assert torch.equal(mine[0]._caches.cmaps[a.stride][0], ref[0]._caches.cmaps[b.stride][0])
+
+
+def test_level_per_call_path_equals_the_layer_by_layer_path(monkeypatch):
+    """fpcc_int_level_trunk / fpcc_int_level_expand (a OneScalePredictor level in two calls over a descriptor table of its layers)
+    against the module-by-module traversal: same stream, same decoded points, and the intermediate tensors of one level bit for bit"""
+    from fastpcc_amd.codecs.lossl_coord_int import model as M
+    cfg, model, weights = _model(32, 0, 5)
+    xyz = torch.from_numpy(batched(lidar_cloud(5, beams=16, azimuths=512))).cuda()
+    one_scale = [b for b in [*model.blocks_dec, model.block_dec_recurrent] if isinstance(b, M.OneScalePredictor)]
+    assert M.FAST_LEVELS and one_scale and all(b._described() is not None for b in one_scale)
+    fast = model.compress(xyz)
+    rec_fast = model.decompress(fast)
+    monkeypatch.setattr(M, 'FAST_LEVELS', False)
+    assert all(b._described() is None for b in one_scale)
+    slow = model.compress(xyz)
+    assert fast == slow
+    assert torch.equal(model.decompress(slow), rec_fast)
+    mixed = model.decompress(fast)                                   # layer-by-layer decoder on the level-per-call encoder's stream
+    assert torch.equal(mixed, rec_fast)
+    # one level in isolation: trunk + expand against _trunk + _expand on the same inputs
+    block = model.block_dec_recurrent
+    g = torch.Generator().manual_seed(3)
+    coords = torch.unique(torch.cat((torch.zeros(300, 1, dtype=torch.int32), torch.randint(0, 12, (300, 3), generator=g, dtype=torch.int32)), 1), dim=0).cuda()
+    n, c = coords.shape[0], cfg.channels
+    feat = torch.randint(-(1 << 24), 1 << 24, (n, c), generator=g, dtype=torch.int32).cuda()
+    symbols = torch.randint(0, 255, (n,), generator=g, dtype=torch.int16).cuda()
+    count = int(M._children_count(symbols.cpu().numpy()))
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(M, 'FAST_LEVELS', flag)
+        x = M.SparseTensor(feat.clone(), coords, (4, 4, 4))
+        d = block._described()
+        assert (d is not None) == flag
+        if flag:
+            y, logits = block._trunk_fast(d, x)
+            z = block._expand_fast(d, y, symbols, count, coords, None, block)
+        else:
+            y, logits = block._trunk(x)
+            occ = M.Occupancy(symbols=symbols, count=count)
+            z = block._expand(y, occ, occ.children(coords), _also=block._first_requant_of(block))
+        q = z.F._fpcc_q8[id(block.dec.input_requant)]
+        outs.append((y.F, logits, z.F, z.C, q))
+    for a, b in zip(*outs):
+        assert a.dtype == b.dtype and torch.equal(a, b)
