@@ -39,6 +39,13 @@ inline unsigned blocks_for(int64_t n, int threads) { return static_cast<unsigned
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// fpcc_conv_i8_also with one more switch (int_ops.hip): ws_zeroed = the offset-split accumulator in `ws` is already clear
+int conv_i8_run(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int nbr_bias,
+                const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope, const uint32_t *requant_mul,
+                const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad, int c_out, int64_t n_out,
+                const int32_t *row_order, const int32_t *residual, int ld_res, const int32_t *slope2, const fpcc_requant8 *also, int n_also,
+                void *ws, int64_t ws_bytes, bool ws_zeroed, void *stream);
+
 // fpcc_time_next_launch: the calling thread's next convolution-family entry point records ev0 on its stream before its first launch
 // and ev1 after its last one, inside the one C call (see include/fpcc_hip.h)
 struct PendingEvents { void *ev0 = nullptr, *ev1 = nullptr; };

@@ -30,13 +30,14 @@ inline fpcc_requant8 also_of(const fpcc_i8_requant &q, int8_t *out, int ld, int 
     return fpcc_requant8{out, ld, pad, q.requant_mul, q.zero_point, q.shift};
 }
 
-// one layer through fpcc_conv_i8_also; `split_ws`: the scratch of the offset-split form (maps of <= 8192 rows)
+// one layer through the body of fpcc_conv_i8_also; `split_ws`: the accumulator of the offset-split form (maps of <= 8192 rows), one per
+// layer and all of them cleared by ONE memset at the head of the level call
 int run_layer(const fpcc_i8_layer &L, const int8_t *a, int lda, int64_t n_out, const int32_t *nbr, const int32_t *row_order, void *out,
               const int32_t *residual, const int32_t *slope2, const fpcc_requant8 *also, int n_also, void *split_ws, int64_t split_bytes,
               void *stream) {
-    return fpcc_conv_i8_also(a, L.c_in, lda, nbr, L.n_offsets, 1, L.n_offsets, 1, L.w, L.ldw, L.zp_comp, L.bias, L.slope, L.requant_mul,
-                             L.zero_point, L.shift, L.out_bits, out, L.c_out, 0, L.c_out, n_out, row_order, residual, residual ? L.c_out : 0,
-                             slope2, also, n_also, split_ws, split_bytes, stream);
+    return conv_i8_run(a, L.c_in, lda, nbr, L.n_offsets, 1, L.n_offsets, 1, L.w, L.ldw, L.zp_comp, L.bias, L.slope, L.requant_mul,
+                       L.zero_point, L.shift, L.out_bits, out, L.c_out, 0, L.c_out, n_out, row_order, residual, residual ? L.c_out : 0, slope2,
+                       also, n_also, split_ws, split_bytes, split_ws != nullptr, stream);
 }
 
 bool layer_ok(const fpcc_i8_layer &L, int c_in, int c_out, int n_offsets, int out_bits) {
@@ -59,12 +60,13 @@ extern "C" int64_t fpcc_int_level_trunk(const fpcc_int_onescale *blk, int64_t n,
     int8_t *q_in = feat_q8 ? nullptr : cv.take<int8_t>(n * C);
     int8_t *t1 = cv.take<int8_t>(n * C);
     int8_t *t2 = cv.take<int8_t>(n * C);
-    const int64_t split_bytes = fpcc_conv_i8_ws_bytes(1, 27, 1, C, n);
-    void *split = split_bytes ? cv.take<char>(split_bytes) : nullptr;
+    const int64_t split_bytes = align_up(fpcc_conv_i8_ws_bytes(1, 27, 1, C, n), 256);
+    char *split = split_bytes ? cv.take<char>(3 * split_bytes) : nullptr;      // one accumulator per 3x3x3 layer
     if (!ws) return cv.used > 0 ? cv.used : 16;
     if (ws_bytes < cv.used) { set_error("int_level_trunk: workspace %lld < %lld", (long long)ws_bytes, (long long)cv.used); return FPCC_E_WORKSPACE; }
     if (n == 0) return FPCC_OK;
     if (!feat || !nbr27 || !res_out || !q_pred || !logits) return fail_arg("int_level_trunk: null pointer");
+    if (split) FPCC_HIP(hipMemsetAsync(split, 0, (size_t)(3 * split_bytes), as_stream(stream)));
     if (q_up && (ld_up < C || ld_up % 4)) return fail_arg("int_level_trunk: row stride of the second int8 copy");
     if (!feat_q8) {                                                     // dec.input_requant, when the producer of `feat` did not write it
         const fpcc_i8_requant &r = blk->dec_in;
@@ -75,10 +77,13 @@ extern "C" int64_t fpcc_int_level_trunk(const fpcc_int_onescale *blk, int64_t n,
     // dec: conv_prelu, then conv2 with prelu(feat + .) and the int8 copies for `pred` and `upsample` in its epilogue
     if (int rc = run_layer(blk->dec_conv1, feat_q8, C, n, nbr27, row_order, t1, nullptr, nullptr, nullptr, 0, split, split_bytes, stream)) return rc;
     fpcc_requant8 also[2] = {also_of(blk->pred_in, q_pred, C, C), also_of(blk->up_in, q_up, ld_up, C)};
-    if (int rc = run_layer(blk->dec_conv2, t1, C, n, nbr27, row_order, res_out, feat, blk->dec_slope, also, q_up ? 2 : 1, split, split_bytes, stream))
+    if (int rc = run_layer(blk->dec_conv2, t1, C, n, nbr27, row_order, res_out, feat, blk->dec_slope, also, q_up ? 2 : 1,
+                           split ? split + split_bytes : nullptr, split_bytes, stream))
         return rc;
     // pred: 3x3x3 convolution, linear layer to the 255 logits
-    if (int rc = run_layer(blk->pred_conv, q_pred, C, n, nbr27, row_order, t2, nullptr, nullptr, nullptr, 0, split, split_bytes, stream)) return rc;
+    if (int rc = run_layer(blk->pred_conv, q_pred, C, n, nbr27, row_order, t2, nullptr, nullptr, nullptr, 0,
+                           split ? split + 2 * split_bytes : nullptr, split_bytes, stream))
+        return rc;
     return run_layer(blk->pred_linear, t2, C, n, nullptr, nullptr, logits, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
@@ -108,14 +113,15 @@ extern "C" int64_t fpcc_int_level_expand(const fpcc_int_onescale *blk, int64_t n
     int32_t *v = cv.take<int32_t>(n * C);                                 // the residual block's output
     int8_t *v_q = cv.take<int8_t>(n * C);                                 // ... requantised for the last linear layer
     int32_t *raw = cv.take<int32_t>(m * C);                               // that layer's raw sums, occupied (row, octant) pairs only
-    const int64_t split_bytes = fpcc_conv_i8_ws_bytes(1, 27, 1, C, n);
-    void *split = split_bytes ? cv.take<char>(split_bytes) : nullptr;
+    const int64_t split_bytes = align_up(fpcc_conv_i8_ws_bytes(1, 27, 1, C, n), 256);
+    char *split = split_bytes ? cv.take<char>(2 * split_bytes) : nullptr;
     if (!ws) return cv.used > 0 ? cv.used : 16;
     if (ws_bytes < cv.used) { set_error("int_level_expand: workspace %lld < %lld", (long long)ws_bytes, (long long)cv.used); return FPCC_E_WORKSPACE; }
     if (n == 0 || m == 0) return FPCC_OK;
     if (!res || !q_up || !symbols || !nbr27 || !feat_out) return fail_arg("int_level_expand: null pointer");
     if (ld_up < ceil16(C + 8) || ld_up % 16) return fail_arg("int_level_expand: the int8 copy needs room for the eight occupancy columns");
     if (feat_q8_out && !next_in) return fail_arg("int_level_expand: an int8 copy needs its requantiser");
+    if (split) FPCC_HIP(hipMemsetAsync(split, 0, (size_t)(2 * split_bytes), as_stream(stream)));
     // the level's octree step: occupied (row, octant) pairs, their gather table and -- for the decoder -- the children's coordinates
     if (int64_t rc = fpcc_octree_children(symbols, nullptr, coords, n, m, 1 << 23, coords ? child_coords : nullptr, parent_row, octant, table,
                                           table_rows, bits, nullptr, oct_ws, oct_bytes, stream))
@@ -127,7 +133,9 @@ extern "C" int64_t fpcc_int_level_expand(const fpcc_int_onescale *blk, int64_t n
     if (int rc = run_layer(blk->up_linear, q_up, ld_up, n, nullptr, nullptr, u, nullptr, nullptr, &a1, 1, nullptr, 0, stream)) return rc;
     if (int rc = run_layer(blk->up_conv1, u_q, C, n, nbr27, row_order, t1, nullptr, nullptr, nullptr, 0, split, split_bytes, stream)) return rc;
     fpcc_requant8 a2 = also_of(blk->up_out_in, v_q, C, C);
-    if (int rc = run_layer(blk->up_conv2, t1, C, n, nbr27, row_order, v, u, blk->up_slope, &a2, 1, split, split_bytes, stream)) return rc;
+    if (int rc = run_layer(blk->up_conv2, t1, C, n, nbr27, row_order, v, u, blk->up_slope, &a2, 1, split ? split + split_bytes : nullptr, split_bytes,
+                           stream))
+        return rc;
     // the last linear layer C -> 8 C for the occupied octants only: an 8-"offset" gather with one entry per output row, then its epilogue with
     // the octant's bias / multiplier columns (and the next level's first requantiser)
     const fpcc_i8_layer &L = blk->up_out;

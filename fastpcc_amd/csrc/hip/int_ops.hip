@@ -1234,6 +1234,18 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
                                  int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res,
                                  const int32_t *slope2, const fpcc_requant8 *also, int n_also, void *ws, int64_t ws_bytes,
                                  void *stream) {
+    return fpcc::conv_i8_run(a, c_in, lda, nbr, n_offsets, nbr_ks, nbr_os, nbr_bias, w, ldw, zp_comp, bias, slope, requant_mul, zero_point,
+                             shift, out_bits, out, ldo, out_pad, c_out, n_out, row_order, residual, ld_res, slope2, also, n_also, ws, ws_bytes,
+                             false, stream);
+}
+
+// ws_zeroed: the offset-split form's accumulator (ws) already holds zeros -- a caller that runs several such layers clears all their
+// accumulators with one memset (fpcc_int_level_*)
+int fpcc::conv_i8_run(const int8_t *a, int c_in, int lda, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int nbr_bias,
+                      const int8_t *w, int ldw, const int32_t *zp_comp, const int32_t *bias, const int32_t *slope,
+                      const uint32_t *requant_mul, const int64_t *zero_point, int shift, int out_bits, void *out, int ldo, int out_pad,
+                      int c_out, int64_t n_out, const int32_t *row_order, const int32_t *residual, int ld_res, const int32_t *slope2,
+                      const fpcc_requant8 *also, int n_also, void *ws, int64_t ws_bytes, bool ws_zeroed, void *stream) {
     if (residual && (!slope2 || out_bits != 32 || !requant_mul || ld_res < c_out))
         return fail_arg("conv_i8: a fused residual needs its PReLU slope, a requantised int32 output and ld_res >= c_out");
     if (n_out < 0 || c_in < 1 || c_out < 1 || n_offsets < 1 || n_offsets > kI8MaxOffsets)
@@ -1263,7 +1275,8 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
             acc = static_cast<int32_t *>(ws);
             ld_acc = c_out;
         }
-        if (int rc = check_hip(hipMemsetAsync(acc, 0, (size_t)n_out * ld_acc * 4, s), "conv_i8: memset")) return rc;
+        if (!(ws_zeroed && requant_mul))
+            if (int rc = check_hip(hipMemsetAsync(acc, 0, (size_t)n_out * ld_acc * 4, s), "conv_i8: memset")) return rc;
         const dim3 grid(gx, (c_out + 127) / 128, n_offsets);
         if (c_out > 64) hipLaunchKernelGGL((k_conv_i8<4, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
         else if (c_out > 32) hipLaunchKernelGGL((k_conv_i8<2, true>), grid, dim3(256), 0, s, p, acc, ld_acc);
@@ -1284,6 +1297,9 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
         return FPCC_OK;
     }
     static const int tiled = [] { const char *e = getenv("FPCC_I8_TILED"); return e ? atoi(e) : 1; }();
+    // linear layers (identity map): the wave-per-block kernel reads 16 bytes of every 256-byte weight row per lane and spends ~3 us per
+    // k-step on L1 refills whatever the row count (26-29 us for C -> 255 on a 300-row level); the tiled kernel stages W through LDS
+    static const int linear_tiled_min = [] { const char *e = getenv("FPCC_I8_LINEAR_TILED_MIN"); return e ? atoi(e) : 1; }();
     static const int tiled_dbg_env = [] { const char *e = getenv("FPCC_I8_DBG"); return e ? atoi(e) : 0; }();
     const int tiled_dbg = g_i8_stamps_on ? 16 : tiled_dbg_env;
     const unsigned idx_bytes = (unsigned)n_offsets * 128u * 4u;             // the tiled kernel's slice of the kernel map in LDS
@@ -1297,7 +1313,7 @@ extern "C" int fpcc_conv_i8_also(const int8_t *a, int c_in, int lda, const int32
         else if (tiled_dbg == 32) hipLaunchKernelGGL((k_conv_i8_tiled<4, 32>), grid, dim3(256), idx_bytes, s, p);   // epilogue computes, stores nothing
         else if (tiled_dbg == 64) hipLaunchKernelGGL((k_conv_i8_tiled<4, 64>), grid, dim3(256), idx_bytes, s, p);   // epilogue stores, computes nothing
         else hipLaunchKernelGGL((k_conv_i8_tiled<4, 7>), grid, dim3(256), idx_bytes, s, p);
-    } else if (width > 64 && tiled && n_out >= 2048) {
+    } else if (width > 64 && tiled && n_out >= (nbr ? 2048 : linear_tiled_min)) {
         static const int tile_nb = [] { const char *e = getenv("FPCC_I8_NB"); return e ? atoi(e) : 4; }();
         static const int tile_mw = [] { const char *e = getenv("FPCC_I8_MW"); return e ? atoi(e) : 4; }();
         if (tile_nb == 2 && tile_mw == 3) hipLaunchKernelGGL((k_conv_i8_tiled<2, 0, 3>), dim3(gx, (width + 63) / 64), dim3(256), idx_bytes, s, p);

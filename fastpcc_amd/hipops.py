@@ -1040,14 +1040,18 @@ def hash_insert_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coord
 
 
 def hash_lookup_coords(table_keys: torch.Tensor, table_vals: torch.Tensor, coords_xyzb: torch.Tensor, kernel_size,
-                       stride, batch_first: bool = False) -> torch.Tensor:
-    """-> int32 [ceil(n/128)*128, volume], entry = input row + 1 or 0 (rows past n are zero), as the reference returns"""
+                       stride, batch_first: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> int32 [ceil(n/128)*128, volume], entry = input row + 1 or 0 (rows past n are zero), as the reference returns.
+    out: a ZEROED int32 tensor of that shape to fill (a caller that clears it together with other buffers)"""
     n = coords_xyzb.shape[0]
     ks = (C.c_int32 * 3)(*[int(v) for v in kernel_size])
     st = (C.c_int32 * 3)(*[int(v) for v in stride])
     volume = int(kernel_size[0]) * int(kernel_size[1]) * int(kernel_size[2])
     rows = (n + 127) // 128 * 128
-    out = torch.zeros((rows, volume), dtype=torch.int32, device=coords_xyzb.device)
+    if out is None:
+        out = torch.zeros((rows, volume), dtype=torch.int32, device=coords_xyzb.device)
+    elif out.dtype != torch.int32 or tuple(out.shape) != (rows, volume) or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError('out must be a contiguous int32 GPU tensor [ceil128(n), volume]')
     fn = lib().fpcc_hash_lookup_coords_bxyz if batch_first else lib().fpcc_hash_lookup_coords
     _ok(fn(_dev(table_keys, torch.int64, 'table_keys'), _dev(table_vals, torch.int32, 'table_vals'),
            table_keys.shape[0], _dev(coords_xyzb, torch.int32, 'coords'), n, ks, st, out.data_ptr(), _stream()))

@@ -87,13 +87,18 @@ def _pad_weight(weight: torch.Tensor) -> torch.Tensor:
 
 def _kernel_table(in_coords: torch.Tensor, out_coords: torch.Tensor, kernel_size, stride, hashmap_kv):
     """hash table of the input coordinates (built on first use) and the dense lookup table [N_out_padded, K] (row + 1 | 0)"""
+    table = None
     if hashmap_kv is None:
+        # keys, values and the lookup table are cleared by ONE fill (three small launches less per level of the integer codec)
         cap = 2 * in_coords.shape[0]
-        keys = torch.zeros(cap, dtype=torch.int64, device=in_coords.device)
-        vals = torch.zeros(cap, dtype=torch.int32, device=in_coords.device)
+        rows, volume = (out_coords.shape[0] + 127) // 128 * 128, kernel_size[0] * kernel_size[1] * kernel_size[2]
+        at = (12 * cap + 15) // 16 * 16
+        buf = torch.zeros(at + 4 * rows * volume, dtype=torch.uint8, device=in_coords.device)
+        keys, vals = buf[:8 * cap].view(torch.int64), buf[8 * cap:12 * cap].view(torch.int32)
+        table = buf[at:].view(torch.int32).view(rows, volume)
         ops.hash_insert_coords(keys, vals, in_coords.contiguous(), batch_first=True)
         hashmap_kv = (keys, vals)
-    table = ops.hash_lookup_coords(hashmap_kv[0], hashmap_kv[1], out_coords.contiguous(), kernel_size, stride, batch_first=True)
+    table = ops.hash_lookup_coords(hashmap_kv[0], hashmap_kv[1], out_coords.contiguous(), kernel_size, stride, batch_first=True, out=table)
     return hashmap_kv, table
 
 

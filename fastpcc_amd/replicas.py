@@ -47,16 +47,18 @@ def _parse_cpulist(text: str) -> List[int]:
 
 def bind_to_device_numa_node(device_index: int) -> Optional[dict]:
     """Pin every thread of the process (those the HIP runtime has already started included, and with them every thread started
-    later: the coder pool, torch's workers) to the CPUs of the NUMA node the GPU hangs off, read from sysfs by its PCI address.  MI355X hosts here are two-socket machines; a process scheduled on the far
-    socket allocates its pinned staging buffers there and every device<->host copy, flag write and launch crosses the inter-socket
-    link.  What `numactl --cpunodebind` does for a
-    serving process.  Default: on for the ranks of a multi-process job (one rank per GPU, the usual practice), off for a single
-    process -- on the one box where it was A/B'd (`tools/r03/numa.sh`, GPU on node 1) the unpinned process ran as fast, so the
-    box-to-box spread of the single-GPU bench (22-26 ms per frame at equal kernel times) is not shown to come from placement;
-    FPCC_NUMA_BIND=1 / 0 forces.  Returns None when nothing was changed (topology unreadable, one node, switched off)."""
-    want = os.environ.get('FPCC_NUMA_BIND')
-    if want is None:
-        want = '1' if env_rank()[1] > 1 else '0'
+    later: the coder pool, torch's workers) to the CPUs of the NUMA node the GPU hangs off, read from sysfs by its PCI address.
+    MI355X hosts here are two-socket machines with four GPUs behind each socket; a process scheduled on the far socket allocates its
+    pinned staging buffers there and every device<->host copy, flag write and launch crosses the inter-socket link, and an unbound
+    process is moved between the sockets by the scheduler.  What `numactl --cpunodebind` does for a serving process.
+    On by default (FPCC_NUMA_BIND=0 switches it off).  Measured, bench.py twice each way on one box (tools/r05/g32.sh): the integer
+    codec, whose decoder reads 50 MB of DMA-written CDF rows per frame on one host thread, 10.6 + 15.5 / 10.1 + 15.3 ms bound against
+    10.8 + 20.2 / 10.4 + 15.9 ms unbound (tools/r05/numa_probe.py: 15.5 ms from the GPU's node, 17.0 from the other, 17.6-19.8 left
+    to the scheduler); the training step 46.9 / 48.0 against 48.5 / 50.1 ms; the colour codec 41.5 / 41.3 against 44.0 / 42.5 ms; the
+    headline (batches of eight frames) unchanged at 80.3 / 80.4 against 78.8 / 80.7 Mpoints/s.  (Round 3's A/B on a box whose GPU sat
+    on node 1 had seen no difference for the one-frame bench, hence the earlier default of off for a single process.)
+    Returns None when nothing was changed (topology unreadable, one node, switched off)."""
+    want = os.environ.get('FPCC_NUMA_BIND', '1')
     if want == '0' or not hasattr(os, 'sched_setaffinity'):
         return None
     try:

@@ -5,6 +5,7 @@ import os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
+from fastpcc_amd import replicas; replicas.bind_to_device_numa_node(0)       # as bench.py does
 from fastpcc_amd.codecs.lossl_coord_int import Model, Config
 from fastpcc_amd.codecs.lossl_coord_int import model as M
 from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
+from fastpcc_amd import replicas; replicas.bind_to_device_numa_node(0)       # as bench.py does
 from fastpcc_amd.synthetic import enliven
 from fastpcc_amd import engine as ME
 from fastpcc_amd.codecs.lossy_coord_lossy_color import Model
