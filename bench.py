@@ -258,7 +258,15 @@ def secondary(device):
         out['cfg3_lossl_coord_int'] = {'workload': f'{len(xyz)}-voxel 64x2048 LiDAR-like sweep, 16-bit, channels 256', 'encode_ms': round(enc, 3),
                                        'decode_ms': round(dec, 3), 'Mpoints_per_s': round(len(xyz) / (enc + dec) / 1e3, 3), 'bytes': len(data),
                                        'bpp': round(8 * len(data) / len(xyz), 4), 'lossless': bool(rec.shape[0] == len(xyz))}
-        del model, frame
+        # the same codec over eight different sweeps in ONE traversal (compress_many / decompress_many: the clouds are the samples of a
+        # batch, one stream per cloud, each byte-identical to the one it gets alone -- checked here for sweep 0)
+        sweeps = [frame] + [torch.from_numpy(batched(lidar_cloud(3 + i))).to(device) for i in range(1, 8)]
+        enc8, dec8, data8, rec8 = timed(lambda: model.compress_many(sweeps), lambda d: model.decompress_many(d), reps=3, warm=1)
+        n8 = sum(f.shape[0] for f in sweeps)
+        out['cfg3_lossl_coord_int']['batch_of_8_sweeps'] = {
+            'voxels': n8, 'encode_ms': round(enc8, 3), 'decode_ms': round(dec8, 3), 'Mpoints_per_s': round(n8 / (enc8 + dec8) / 1e3, 3),
+            'stream_0_identical': bool(data8[0] == data), 'lossless': bool([r.shape[0] for r in rec8] == [f.shape[0] for f in sweeps])}
+        del model, frame, sweeps
     except Exception as e:                                               # the headline number must survive a secondary failure
         out['cfg3_lossl_coord_int'] = {'error': repr(e)[:200]}
     try:
