@@ -35,8 +35,9 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--secondary', type=int, default=1, help='0 skips the figures reported next to the headline: cfg#3 / #4 / #5 at N = 1, '
                                                              'the cfg#5 DDP training step over all N ranks at N > 1')
-    ap.add_argument('--batch', type=int, default=8, help='frames per step: B independent ~1M-voxel frames coded in ONE network traversal '
-                    '(compress_many / decompress_many; every stream byte-identical to the frame coded alone)')
+    ap.add_argument('--batch', type=int, default=16, help='frames per step: B independent ~1M-voxel frames coded in ONE network traversal '
+                    '(compress_many / decompress_many; every stream byte-identical to the frame coded alone).  Measured on one box '
+                    '(tools/r05/g34.sh): 8 -> 79.9, 12 -> 83.5, 16 -> 85.0, 24 -> 84.4, 32 -> 86.4 Mpoints/s')
     ap.add_argument('--frames-in-flight', type=int, default=2, help='batches a rank keeps in flight on its GPU (fastpcc_amd/serving.py): '
                     '1 = one batch at a time')
     ap.add_argument('--latency-frames', type=int, default=12, help='frames of the one-frame-at-a-time figure `value_one_frame` (median; >= 10)')

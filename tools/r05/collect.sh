@@ -3,14 +3,14 @@
 S=gpurun_out/r05F; D=profiles/r05
 f() { find $S/$1 -name "$2" | head -1; }
 cp $(f stats s_kernel_stats.csv) $D/final_kernel_stats.csv
-FRAMES=${1:-60}
-{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0   (round 5, final state; batch 8, two batches in flight: 8 reference frames + 4 latency frames + 2 warm-up and 3 timed batches of 8 + 1 clock-probe batch of 8 = $FRAMES frame-equivalents)"; python profiles/summarize.py $D/final_kernel_stats.csv $FRAMES; } > $D/final_summary.md
+FRAMES=${1:-116}
+{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0   (round 5, final state; batch 16, two batches in flight: 16 reference frames + 4 one-frame-at-a-time frames + 2 warm-up and 3 timed batches of 16 + 1 clock-probe batch of 16 = $FRAMES frame-equivalents)"; python profiles/summarize.py $D/final_kernel_stats.csv $FRAMES; } > $D/final_summary.md
 python profiles/pmc_summary.py $(f fetch p_counter_collection.csv) $(f write p_counter_collection.csv) $D/final_pmc_traffic.json > $D/final_pmc_traffic.md
 python - <<PY
 import json
 p = '$D/final_pmc_traffic.json'
 d = json.load(open(p))
-d['_meta'] = {'frame_equivalents': $FRAMES, 'command': 'bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0 (batch 8, two batches in flight)'}
+d['_meta'] = {'frame_equivalents': $FRAMES, 'command': 'bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0 (batch 16, two batches in flight)'}
 json.dump(d, open(p, 'w'), indent=1)
 PY
 python profiles/hbm_bandwidth.py $(dirname $(f fetch p_counter_collection.csv)) $(dirname $(f write p_counter_collection.csv)) > $D/final_hbm_bandwidth.md
@@ -18,7 +18,7 @@ python profiles/hbm_bandwidth.py $(dirname $(f fetch p_counter_collection.csv)) 
 cp $S/conv_launches.txt $D/final_conv_launches.txt
 python profiles/conv_by_level.py $D/final_conv_launches.txt > $D/final_conv_by_level.md
 cp $S/bench_default.json $D/final_bench.json
-for c in b1_d1 b1_d2 b4_d2 b8_d1 b8_d3 b8_d2_stages; do cp $S/bench_$c.json $D/final_bench_$c.json; done
+for c in b1_d1 b1_d2 b4_d2 b8_d2 b16_d1 b16_d3 b16_d2_stages; do cp $S/bench_$c.json $D/final_bench_$c.json; done
 cp $S/mfma_busy.md $D/final_mfma_busy.md
 cp $S/step_gaps.md $D/final_step_gaps.md
 for c in int color train; do cp $(f $c s_kernel_stats.csv) $D/final_${c}_kernel_stats.csv; done

@@ -8,18 +8,18 @@ timeout 1700 python3 -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.
 tail -4 $O/pytest_gpu.txt
 timeout 120 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt; tail -2 $O/smoke.txt
 timeout 900 python3 bench.py --dump-trace $O/conv_launches.txt > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; head -c 500 $O/bench_default.json; echo
-for cfg in "1 1" "1 2" "4 2" "8 1" "8 3"; do set -- $cfg
+for cfg in "1 1" "1 2" "4 2" "8 2" "16 1" "16 3"; do set -- $cfg
   timeout 400 python3 bench.py --batch $1 --frames-in-flight $2 --cpu-baseline 0 --secondary 0 > $O/bench_b$1_d$2.json 2> $O/bench_b$1_d$2.err; head -c 200 $O/bench_b$1_d$2.json; echo
 done
-timeout 400 python3 bench.py --stages 1 --cpu-baseline 0 --secondary 0 > $O/bench_b8_d2_stages.json 2> $O/bench_b8_d2_stages.err; head -c 200 $O/bench_b8_d2_stages.json; echo
+timeout 400 python3 bench.py --stages 1 --cpu-baseline 0 --secondary 0 > $O/bench_b16_d2_stages.json 2> $O/bench_b16_d2_stages.err; head -c 200 $O/bench_b16_d2_stages.json; echo
 CMD="python3 bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- $CMD > $O/stats.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $CMD > $O/fetch.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $CMD > $O/write.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/busy -o p --output-format csv -- $CMD > $O/busy.log 2>&1
 python3 profiles/mfma_busy.py $O/busy > $O/mfma_busy.md 2>&1; head -8 $O/mfma_busy.md
-timeout 400 rocprofv3 --kernel-trace -d $O/gap -o p --output-format csv -- python3 bench.py --steps 16 --warmup 2 --latency-frames 1 --cpu-baseline 0 --secondary 0 > $O/gap.log 2>&1
-python3 profiles/step_gaps.py $(find $O/gap -name p_kernel_trace.csv | head -1) "batches of 8 frames, two batches in flight (bench.py --steps 16 --warmup 2 --latency-frames 1, the default batch and depth)" > $O/step_gaps.md 2>&1
+timeout 400 rocprofv3 --kernel-trace -d $O/gap -o p --output-format csv -- python3 bench.py --steps 10 --warmup 2 --latency-frames 1 --cpu-baseline 0 --secondary 0 > $O/gap.log 2>&1
+python3 profiles/step_gaps.py $(find $O/gap -name p_kernel_trace.csv | head -1) "batches of 16 frames, two batches in flight (bench.py --steps 10 --warmup 2 --latency-frames 1, the default batch and depth)" > $O/step_gaps.md 2>&1
 head -12 $O/step_gaps.md
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/int -o s --output-format csv -- python3 tools/timeline_int.py > $O/int.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/color -o s --output-format csv -- python3 tools/timeline_color.py > $O/color.log 2>&1
