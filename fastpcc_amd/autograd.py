@@ -38,6 +38,11 @@ import os as _os
 PACK = 'fresh' if _os.environ.get('FPCC_TRAIN_PACK', 'off') in ('fresh', '1') else False
 
 
+def _strided_rows(t: torch.Tensor) -> bool:
+    """a matrix the kernels read in place: unit column stride, rows at any pitch >= the row"""
+    return t.dim() == 2 and t.stride(1) == 1 and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1])
+
+
 def _mfma(c_in: int, c_out: int) -> bool:
     return ops.conv_order(c_in, 0, c_out) != 0
 
@@ -47,8 +52,7 @@ def _k3_one_channel(x: torch.Tensor, w: torch.Tensor, s: ConvSpec, **epilogue) -
     all 27 offset kernels on the MFMA kernel (a pointwise GEMM to 27 -> 32 columns), then 27 gathered scalars per output
     row -- instead of 27 gathered rows per output row on the VALU kernel"""
     c_in = w.shape[-2]
-    wt = torch.zeros((c_in, 32), dtype=w.dtype, device=w.device)
-    wt[:, :27] = w.detach().reshape(27, c_in).t()
+    wt = torch.nn.functional.pad(w.detach().reshape(27, c_in).t(), (0, 5))         # [c_in, 32], columns 27.. zero (one launch)
     y = ops.conv_f32(x, wt, 32, s.n_in, pack=PACK)
     return ops.gather_sum(y, s.table, 27, s.n_in, 1, s.n_in, **epilogue)
 
@@ -111,11 +115,14 @@ def _input_grad(dy: torch.Tensor, w: torch.Tensor, s: ConvSpec) -> torch.Tensor:
         # every row gathered side by side, G[i][k] = dy[nbr[k][i]] (0 where the neighbour is absent), then ONE per-point MFMA GEMM
         # G [n, 32] @ W' [32, c_in] with W'[k] = W[26 - k] -- instead of 27 scalar-times-row products per row on the VALU kernel
         # (k_conv_valu<16>: 1.3 ms per step, profiles/r05/train_host_ops.md).
-        idx = s.table.long()                                              # [27, n]
-        g = torch.where(idx >= 0, dy.reshape(-1)[idx.clamp(min=0)], dy.new_zeros(()))
-        g = torch.nn.functional.pad(g.t(), (0, 5)).contiguous()           # [n, 32]
-        wt = torch.zeros((32, c_in), dtype=w.dtype, device=w.device)
-        wt[:27] = w.detach().reshape(27, c_in).flip(0)
+        # The gather is ONE indexing launch: absent neighbours and the five padding columns point at a zero appended to dy; the index
+        # matrix [n, 32] belongs to the map and is built once per map and step (the layers of a level share their table).
+        gidx = getattr(s.table, '_fpcc_gather_rows', None)
+        if gidx is None:
+            t = s.table.t()                                                                           # [n, 27]
+            gidx = s.table._fpcc_gather_rows = torch.nn.functional.pad(torch.where(t >= 0, t, s.n_in), (0, 5), value=s.n_in).long()
+        g = torch.cat((dy.reshape(-1), dy.new_zeros(1)))[gidx]                                        # [n, 32]
+        wt = torch.nn.functional.pad(w.detach().reshape(27, c_in).flip(0), (0, 0, 0, 5))              # [32, c_in], rows 27.. zero
         return ops.conv_f32(g, wt, c_in, s.n_in, pack=PACK)
     if s.kind == 'k3':
         wt = ops.transpose_weights(w, 27, c_in, c_out, flip=True)         # W'[k] = W[26-k]^T
@@ -221,13 +228,13 @@ class SparseConvActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y, slope = ctx.saved_tensors
         s = ctx.spec
-        dy = dy.contiguous()
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_s = ctx.has_slope and ctx.needs_input_grad[3]
         if ctx.act == ops.ACT_NONE and not want_b:
-            g, dbias, dslope = dy, None, None
-        else:
-            g, dbias, dslope = ops.epilogue_bwd(y, dy, ctx.act, slope if ctx.has_slope else None, want_b, want_s)
+            g, dbias, dslope = dy.contiguous(), None, None
+        else:       # the epilogue kernel reads rows at any stride (a column slice of a concatenation's gradient) and writes g packed
+            g, dbias, dslope = ops.epilogue_bwd(y, dy if _strided_rows(dy) else dy.contiguous(), ctx.act, slope if ctx.has_slope else None,
+                                                want_b, want_s)
         dx = _input_grad(g, w, s) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(x, g, w, s) if ctx.needs_input_grad[1] else None
         if dbias is not None:
@@ -239,6 +246,56 @@ class SparseConvActFn(torch.autograd.Function):
 
 def sparse_conv_act(x, w, bias, slope, spec: ConvSpec, act: int) -> torch.Tensor:
     return SparseConvActFn.apply(x, w, bias, slope, spec, act)
+
+
+class LinearActFn(torch.autograd.Function):
+    """per-point linear layer + bias + (P)ReLU on an nn.Linear weight [c_out, c_in] as it is stored.  Through SparseConvActFn the layer
+    cost a transposed weight copy forward, a weight transposition kernel backward (the input gradient wants [c_out, c_in] -- which IS
+    the stored layout) and a copy of the weight gradient (computed as [c_in, c_out], handed to autograd through the `.t()` view,
+    made contiguous when stored).  Here the input gradient reads the parameter itself and the weight gradient is computed transposed,
+    dW [c_out, c_in] = g^T x (the weight-gradient kernel with its operands swapped): two launches and a copy less per layer and step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, act: int):
+        x = x.contiguous()
+        c_out, c_in = weight.shape
+        n = x.shape[0]
+        y = ops.conv_f32(x, weight.detach().t().contiguous(), c_out, n, bias=None if bias is None else bias.reshape(-1), act=act, slope=slope,
+                         pack=PACK)
+        ctx.save_for_backward(x, weight, y, slope if slope is not None else x.new_empty(0))
+        ctx.act, ctx.has_bias, ctx.has_slope = act, bias is not None, slope is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y, slope = ctx.saved_tensors
+        c_out, c_in = weight.shape
+        n = x.shape[0]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_s = ctx.has_slope and ctx.needs_input_grad[3]
+        if ctx.act == ops.ACT_NONE and not want_b:
+            g, dbias, dslope = dy.contiguous(), None, None
+        else:
+            g, dbias, dslope = ops.epilogue_bwd(y, dy if _strided_rows(dy) else dy.contiguous(), ctx.act, slope if ctx.has_slope else None,
+                                                want_b, want_s)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _wide(lambda wt, c, out: ops.conv_f32(g, wt, c, n, out=out, pack=PACK), weight.detach(), c_in, n, dy.device)
+        if ctx.needs_input_grad[1]:
+            if c_in in (32, 64, 128) and c_out % 64 == 0:        # shapes the matrix-core gradient kernel takes with the operands swapped
+                dw = ops.conv_wgrad(g, x, n).view(c_out, c_in)
+            else:                                                # (a 256-wide input: its own orientation, transposed as a view)
+                dw = ops.conv_wgrad(x, g, n).view(c_in, c_out).t()
+        if dbias is not None:
+            dbias = dbias.view(ctx.bias_shape)
+        if dslope is not None:
+            dslope = dslope.view(slope.shape)
+        return dx, dw, dbias, dslope, None
+
+
+def sparse_linear_act(x, weight, bias, slope, act: int) -> torch.Tensor:
+    return LinearActFn.apply(x, weight, bias, slope, act)
 
 
 class BoundFunction(torch.autograd.Function):
@@ -253,5 +310,5 @@ class BoundFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, bound = ctx.saved_tensors
-        one = torch.ones((), dtype=g.dtype, device=g.device)
-        return torch.where(x > bound, one, torch.where(x < -bound, -one, g)), None      # no mask indexing: that would synchronise
+        # +1 right of the interval, -1 left of it, g inside (bound >= 0): four launches, no mask indexing (that would synchronise)
+        return torch.where(x.abs() > bound, torch.sign(x), g), None

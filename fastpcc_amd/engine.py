@@ -979,9 +979,8 @@ class MinkowskiLinear(nn.Module):
             from .autograd import ConvSpec, sparse_conv
             n = x.parts[0].shape[0]
             if _fusable_in_training(act):
-                from .autograd import sparse_conv_act
-                out = sparse_conv_act(x.F, self.linear.weight.t(), self.linear.bias,
-                                      act.param if act.kind == ops.ACT_PRELU else None, ConvSpec('k1', n, n), act.kind)
+                from .autograd import sparse_linear_act
+                out = sparse_linear_act(x.F, self.linear.weight, self.linear.bias, act.param if act.kind == ops.ACT_PRELU else None, act.kind)
                 out = _finish_autograd(out, None, _Act(), clip)
             else:
                 out = _finish_autograd(sparse_conv(x.F, self.linear.weight.t(), ConvSpec('k1', n, n)), self.linear.bias, act, clip)

@@ -170,11 +170,34 @@ class _DeepFactorizedBits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         out, dy = ctx.saved_tensors
+        # the 14 parameter gradients: ONE scaling and ONE re-ordering launch (channel-major [c, 58] -> the parameters' own contiguous
+        # blocks one after the other), then contiguous views of the result -- not 14 slice products (and no copies when autograd
+        # stores them: a contiguous view obeys the parameter's layout)
+        c = out.shape[0]
+        flat = (out[:, :58] * g).reshape(-1)[_param_major(c, out.device)]
         grads, at = [], 0
-        for shape, width in zip(ctx.param_shapes, (3, 9, 9, 9, 3, 3, 3, 3, 3, 1, 3, 3, 3, 3)):
-            grads.append((out[:, at: at + width] * g).reshape(shape))
+        for shape, width in zip(ctx.param_shapes, _DF_WIDTHS):
+            grads.append(flat[at * c: (at + width) * c].view(shape))
             at += width
         return (dy * g).reshape(ctx.y_shape), None, *grads
+
+
+_DF_WIDTHS = (3, 9, 9, 9, 3, 3, 3, 3, 3, 1, 3, 3, 3, 3)      # columns of fpcc_deep_factorized_bits_f32's gradient rows, per parameter
+_PARAM_MAJOR = {}
+
+
+def _param_major(c: int, device) -> torch.Tensor:
+    """index of element (parameter p, channel ch, j) in the flattened [c, 58] gradient matrix, parameters one after the other"""
+    key = (c, str(device))
+    perm = _PARAM_MAJOR.get(key)
+    if perm is None:
+        ch = torch.arange(c).view(c, 1)
+        parts, at = [], 0
+        for width in _DF_WIDTHS:
+            parts.append((ch * 58 + at + torch.arange(width).view(1, width)).reshape(-1))
+            at += width
+        perm = _PARAM_MAJOR[key] = torch.cat(parts).to(device)
+    return perm
 
 
 # ---- quantised CDF table -------------------------------------------------------------------------------------------

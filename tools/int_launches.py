@@ -4,6 +4,7 @@ import collections, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
+from fastpcc_amd import replicas; replicas.bind_to_device_numa_node(0)       # as bench.py does
 from torch.profiler import profile, ProfilerActivity
 from fastpcc_amd.codecs.lossl_coord_int import Model, Config
 from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_

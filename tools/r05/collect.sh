@@ -5,7 +5,7 @@ f() { find $S/$1 -name "$2" | head -1; }
 cp $(f stats s_kernel_stats.csv) $D/final_kernel_stats.csv
 FRAMES=${1:-116}
 { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0   (round 5, final state; batch 16, two batches in flight: 16 reference frames + 4 one-frame-at-a-time frames + 2 warm-up and 3 timed batches of 16 + 1 clock-probe batch of 16 = $FRAMES frame-equivalents)"; python profiles/summarize.py $D/final_kernel_stats.csv $FRAMES; } > $D/final_summary.md
-python profiles/pmc_summary.py $(f fetch p_counter_collection.csv) $(f write p_counter_collection.csv) $D/final_pmc_traffic.json > $D/final_pmc_traffic.md
+cp $S/pmc_traffic.json $D/final_pmc_traffic.json; cp $S/pmc_traffic.md $D/final_pmc_traffic.md       # summarised on the GPU box (final.sh)
 python - <<PY
 import json
 p = '$D/final_pmc_traffic.json'
@@ -13,8 +13,8 @@ d = json.load(open(p))
 d['_meta'] = {'frame_equivalents': $FRAMES, 'command': 'bench.py --steps 3 --warmup 1 --latency-frames 2 --cpu-baseline 0 --secondary 0 (batch 16, two batches in flight)'}
 json.dump(d, open(p, 'w'), indent=1)
 PY
-python profiles/hbm_bandwidth.py $(dirname $(f fetch p_counter_collection.csv)) $(dirname $(f write p_counter_collection.csv)) > $D/final_hbm_bandwidth.md
-{ echo; echo "## The helper kernels by launch size (profiles/hbm_bandwidth_by_size.py)"; echo; python profiles/hbm_bandwidth_by_size.py $(dirname $(f fetch p_counter_collection.csv)) $(dirname $(f write p_counter_collection.csv)); } >> $D/final_hbm_bandwidth.md
+cp $S/hbm_bandwidth.md $D/final_hbm_bandwidth.md
+{ echo; echo "## The helper kernels by launch size (profiles/hbm_bandwidth_by_size.py)"; echo; cat $S/hbm_bandwidth_by_size.md; } >> $D/final_hbm_bandwidth.md
 cp $S/conv_launches.txt $D/final_conv_launches.txt
 python profiles/conv_by_level.py $D/final_conv_launches.txt > $D/final_conv_by_level.md
 cp $S/bench_default.json $D/final_bench.json

@@ -26,4 +26,11 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/color -o s --output-format cs
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/train -o s --output-format csv -- python3 bench_train.py --steps 4 --warmup 1 > $O/train.log 2>&1
 tail -3 $O/int.log; tail -3 $O/color.log
 find $O -name 's_kernel_trace.csv' -delete; rm -f $O/write/p_kernel_trace.csv; find $O/gap $O/busy -name p_kernel_trace.csv -delete
-find $O -name '*.csv' | xargs ls -la | head -40
+# what travels back must stay under 64 MiB: the counter tables are summarised here and only their gzip goes home
+python3 profiles/pmc_summary.py $(find $O/fetch -name p_counter_collection.csv | head -1) $(find $O/write -name p_counter_collection.csv | head -1) $O/pmc_traffic.json > $O/pmc_traffic.md 2>&1
+FD=$(dirname $(find $O/fetch -name p_counter_collection.csv | head -1)); WD=$(dirname $(find $O/write -name p_counter_collection.csv | head -1))
+python3 profiles/hbm_bandwidth.py $FD $WD > $O/hbm_bandwidth.md 2>&1
+python3 profiles/hbm_bandwidth_by_size.py $FD $WD > $O/hbm_bandwidth_by_size.md 2>&1
+find $O/fetch -name p_kernel_trace.csv -delete
+find $O/fetch $O/write $O/busy -name p_counter_collection.csv -exec gzip -9 {} \;
+du -sh gpurun_out; find $O -name '*.csv*' | xargs ls -la | head -40
