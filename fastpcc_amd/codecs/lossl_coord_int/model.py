@@ -610,7 +610,8 @@ class Model(nn.Module):
         instead of coordinate rows: one counting pass tells the rows of every level (the traversal's only read-back, where
         unique_consecutive synchronised once per level), then each level is one call -- head flags, a scan and one kernel that
         writes coordinates, bits, kernel map and coded symbols (fpcc_octree_level) -- against ~21 operators.
-        keys: `cloud << 48 | Morton('zyx')` of xyz's rows, ascending.  -> (levels of SparseTensor, rows[level][cloud])"""
+        keys: `cloud << 48 | Morton('zyx')` of xyz's rows, ascending and -- like the voxels of the reference's data sets -- unique (a
+        repeated voxel is reported by the counting pass as a ValueError).  -> (levels of SparseTensor, rows[level][cloud])"""
         org = self.get_init_pc(xyz, 1)
         rows = ops.level_counts_clouds(keys, levels, 48, clouds)
         caches = org._caches

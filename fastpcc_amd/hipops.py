@@ -346,6 +346,8 @@ def level_counts_clouds(keys: torch.Tensor, levels: int, cloud_shift: int, n_clo
         raise ValueError('a key carries a cloud index outside the batch')
     out = [[0] * n_clouds for _ in range(levels + 1)]
     for c, row in enumerate(h):
+        if row[levels + 1] and row[levels + 1] != 1 + sum(row[:levels + 1]):        # every neighbouring pair of distinct keys is in one bin
+            raise ValueError(f'cloud {c}: the keys are not unique ({row[levels + 1]} keys, {1 + sum(row[:levels + 1])} distinct)')
         out[0][c] = row[levels + 1]
         acc = 0
         for t in range(levels, 0, -1):

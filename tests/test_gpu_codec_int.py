@@ -218,3 +218,14 @@ def test_level_per_call_path_equals_the_layer_by_layer_path(monkeypatch):
         outs.append((y.F, logits, z.F, z.C, q))
     for a, b in zip(*outs):
         assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+def test_repeated_voxels_are_refused_not_miscoded():
+    """the octree analysis counts its levels from the sorted keys and needs them unique (as the reference's data sets deliver them):
+    a repeated voxel is an error from the counting pass, not a wrong stream"""
+    cfg, model, _ = _model(32, 0, 5)
+    xyz = batched(lidar_cloud(4, beams=8, azimuths=256))
+    twice = torch.from_numpy(np.concatenate((xyz, xyz[100:103]))).cuda()
+    with pytest.raises(ValueError, match='not unique'):
+        model.compress(twice)
+    assert len(model.compress(torch.from_numpy(xyz).cuda())) > 0          # the model is usable afterwards

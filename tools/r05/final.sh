@@ -19,7 +19,7 @@ timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-
 timeout 500 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/busy -o p --output-format csv -- $CMD > $O/busy.log 2>&1
 python3 profiles/mfma_busy.py $O/busy > $O/mfma_busy.md 2>&1; head -8 $O/mfma_busy.md
 timeout 400 rocprofv3 --kernel-trace -d $O/gap -o p --output-format csv -- python3 bench.py --steps 10 --warmup 2 --latency-frames 1 --cpu-baseline 0 --secondary 0 > $O/gap.log 2>&1
-python3 profiles/step_gaps.py $(find $O/gap -name p_kernel_trace.csv | head -1) "batches of 16 frames, two batches in flight (bench.py --steps 10 --warmup 2 --latency-frames 1, the default batch and depth)" > $O/step_gaps.md 2>&1
+python3 profiles/step_gaps.py $(find $O/gap -name p_kernel_trace.csv | head -1) "batches of 16 frames, two batches in flight (bench.py --steps 10 --warmup 2 --latency-frames 1, the default batch and depth; the window starts behind the 19 single frames the bench codes first)" 0.66 0.97 > $O/step_gaps.md 2>&1
 head -12 $O/step_gaps.md
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/int -o s --output-format csv -- python3 tools/timeline_int.py > $O/int.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/color -o s --output-format csv -- python3 tools/timeline_color.py > $O/color.log 2>&1
