@@ -229,3 +229,25 @@ def test_repeated_voxels_are_refused_not_miscoded():
     with pytest.raises(ValueError, match='not unique'):
         model.compress(twice)
     assert len(model.compress(torch.from_numpy(xyz).cuda())) > 0          # the model is usable afterwards
+
+
+@pytest.mark.parametrize('points', [
+    [(0, 0, 0)],                                                    # one voxel: every level has one row
+    [(5, 9, 2), (65535, 65535, 65535)],                             # two voxels a full 16-bit cube apart
+    [(100, 100, 100), (100, 100, 101), (100, 101, 100), (101, 100, 100), (3000, 7, 9)],      # siblings and a stray
+])
+def test_tiny_clouds_equal_the_oracle(points):
+    """the smallest maps: one row per level, a parent with several children beside a single voxel far away, coordinates at the 16-bit
+    maximum -- stream bytes equal the oracle's, decoding is lossless, and the same clouds come through a batch unchanged"""
+    cfg, model, weights = _model(32, 0, 5)
+    xyz = np.array(points, dtype=np.int32)
+    dev = torch.from_numpy(batched(xyz)).cuda()
+    data = model.compress(dev)
+    assert data == OracleInt(weights, cfg).compress(batched(xyz).astype(np.int64))
+    rec = model.decompress(data).cpu().numpy()
+    assert sorted(map(tuple, rec.tolist())) == sorted(map(tuple, xyz.tolist()))
+    other = torch.from_numpy(batched(lidar_cloud(4, beams=8, azimuths=256))).cuda()
+    many = model.compress_many([other, dev, dev])
+    assert many[1] == data and many[2] == data and many[0] == model.compress(other)
+    back = model.decompress_many(many)
+    assert torch.equal(back[1], model.decompress(data)) and torch.equal(back[2], back[1])
