@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Weight gradient of the 3x3x3 layers: active (32-row block, offset) pairs per offset on the maps of a training batch -- how unevenly
-the work of the (row split, offset) workgroups of k_wgrad_rows is spread over the 27 offsets."""
+the work of the (row split, offset) workgroups of k_wgrad_rows is spread over the 27 offsets, and how full the executed blocks are."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -18,12 +18,10 @@ while m is not None and m.n > 200:
     order = cm._row_order(m, training=True)
     rows = nbr if order is None or order is False else nbr[:, order.long()]
     n = m.n
-    pad = (-n) % 32
-    present = torch.nn.functional.pad(rows >= 0, (0, pad)).view(27, -1, 32)
-    active = present.any(2).sum(1).tolist()              # active blocks per offset
+    present = torch.nn.functional.pad(rows >= 0, (0, (-n) % 32)).view(27, -1, 32)
+    active = present.any(2).sum(1).tolist()              # executed blocks per offset
     pairs = (rows >= 0).sum(1).tolist()
-    blocks = (n + 31) // 32
-    dens = sum(pairs) / (32 * sum(active))
-    print(f'rows {n:7d} blocks {blocks:5d}: active blocks per offset min {min(active)} median {sorted(active)[13]} max {max(active)} '
-          f'(sum {sum(active)}, mean {sum(active) / 27:.0f}); max / mean = {max(active) * 27 / sum(active):.2f}; row density inside active blocks {dens:.2f}')
+    print(f'rows {n:7d} blocks {(n + 31) // 32:5d}: executed blocks per offset min {min(active)} median {sorted(active)[13]} max {max(active)} '
+          f'(mean {sum(active) / 27:.0f}); max / mean = {max(active) * 27 / sum(active):.2f}; rows with the offset inside executed blocks '
+          f'{sum(pairs) / (32 * sum(active)):.2f}')
     m = m.parent
