@@ -156,6 +156,20 @@ def test_cfg3_lidar_sweep_256_channels_lossless_and_tuning_invariance():
     with _Tuning(ops, ME, int_sparse_conv, row_order=False):
         assert model.compress(frame) == data, 'bytes depend on the row order of the int8 convolution'
         assert (_key(model.decompress(data).cpu().numpy()) == _key(xyz)).all()
+    # the level-per-call traversal (fpcc_int_level_*) against the module-by-module one, and a batch of sweeps against single sweeps
+    from fastpcc_amd.codecs.lossl_coord_int import model as int_model
+    assert int_model.FAST_LEVELS
+    int_model.FAST_LEVELS = False
+    try:
+        assert model.compress(frame) == data, 'bytes depend on the traversal path'
+        assert (_key(model.decompress(data).cpu().numpy()) == _key(xyz)).all()
+    finally:
+        int_model.FAST_LEVELS = True
+    other = torch.from_numpy(batched(lidar_cloud(7))).cuda()
+    many = model.compress_many([other, frame])
+    assert many[1] == data and many[0] == model.compress(other)
+    back = model.decompress_many(many)
+    assert (_key(back[1].cpu().numpy()) == _key(xyz)).all() and back[0].shape[0] == other.shape[0]
 
 
 def test_cfg4_two_million_coloured_voxels_round_trip_and_tuning_invariance():
