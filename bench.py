@@ -285,7 +285,19 @@ def secondary(device):
         out['cfg4_lossy_coord_lossy_color'] = {'workload': f'{len(xyz)}-voxel 2048^3 coloured body-surface frame', 'encode_ms': round(enc, 3),
                                                'decode_ms': round(dec, 3), 'Mpoints_per_s': round(len(xyz) / (enc + dec) / 1e3, 3),
                                                'bytes': len(data), 'bpp': round(8 * len(data) / len(xyz), 4), 'decoded_points': int(rec[0].shape[0])}
-        del model, frame, rgb
+        # four such frames in ONE traversal (compress_many / decompress_many; frame 0's stream is checked against the one it gets alone)
+        frames4, rgbs4 = [frame], [rgb]
+        for i in range(1, 4):
+            x4 = body_cloud(2048, SCALE[2048], seed=4 + i)
+            b4 = 127 + 90 * np.stack((np.sin(x4[:, 0] / 90.0), np.cos(x4[:, 1] / 70.0), np.sin((x4[:, 2] + x4[:, 0]) / 110.0)), 1)
+            frames4.append(torch.from_numpy(batched(x4)).to(device))
+            rgbs4.append(torch.from_numpy(np.clip(b4 + rng.normal(0, 8, b4.shape), 0, 255).astype(np.uint8)).to(device))
+        enc4, dec4, data4, rec4 = timed(lambda: model.compress_many(frames4, rgbs4), lambda d: model.decompress_many(d), reps=3, warm=1)
+        n4 = sum(f.shape[0] for f in frames4)
+        out['cfg4_lossy_coord_lossy_color']['batch_of_4_frames'] = {
+            'voxels': n4, 'encode_ms': round(enc4, 3), 'decode_ms': round(dec4, 3), 'Mpoints_per_s': round(n4 / (enc4 + dec4) / 1e3, 3),
+            'stream_0_identical': bool(data4[0] == data), 'decoded_points': [int(r[0].shape[0]) for r in rec4]}
+        del model, frame, rgb, frames4, rgbs4
     except Exception as e:
         out['cfg4_lossy_coord_lossy_color'] = {'error': repr(e)[:200]}
     try:
