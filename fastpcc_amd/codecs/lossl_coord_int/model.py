@@ -242,6 +242,9 @@ class _Described:
         self.requants.append((mod, mod._buffers['requant_mul']))
         return ops.i8_requant(mul, zp, shift, keep=self.keep)
 
+    def __deepcopy__(self, memo):
+        return None                # a copied module (serving.clone_context) describes itself again: the table holds raw pointers
+
     def valid(self) -> bool:
         for mod, w, version, ptr in self.layers:
             if mod._buffers['weight'] is not w or w._version != version or w.data_ptr() != ptr or mod._shift_host is None:
@@ -530,6 +533,10 @@ class OneScaleMultiStepPredictor(nn.Module):
         return cur_rec, cur_bin, top_rec, top_stride
 
 
+_HOST_THREADS = None
+_HOST_THREADS_LOCK = __import__('threading').Lock()
+
+
 class Model(nn.Module):
     one_scale_cls, multi_step_cls = OneScalePredictor, OneScaleMultiStepPredictor
 
@@ -792,11 +799,13 @@ class Model(nn.Module):
         return groups
 
     def _thread_pool(self, n: int):
+        """host threads that code the clouds of a batch side by side (one pool per process: the jobs are short and independent)"""
+        global _HOST_THREADS
         from concurrent.futures import ThreadPoolExecutor
-        pool = getattr(self, '_host_threads', None)
-        if pool is None or pool._max_workers < n:
-            pool = self._host_threads = ThreadPoolExecutor(max_workers=max(n, 4), thread_name_prefix='fpcc-int-coder')
-        return pool
+        with _HOST_THREADS_LOCK:
+            if _HOST_THREADS is None or _HOST_THREADS._max_workers < n:
+                _HOST_THREADS = ThreadPoolExecutor(max_workers=max(n, 8), thread_name_prefix='fpcc-int-coder')
+            return _HOST_THREADS
 
     @ops.no_gc_pause
     @torch.no_grad()

@@ -75,7 +75,10 @@ class FramePipeline:
             raise ValueError('depth >= 1')
         self.depth = depth
         self.own_streams = own_streams and depth > 1
-        self.device = device if device is not None else next(model.parameters()).device
+        if device is None:                                  # (the integer codec holds buffers only)
+            first = next(model.parameters(), None)
+            device = (first if first is not None else next(model.buffers())).device
+        self.device = device
         self.models: List[torch.nn.Module] = [model] + [clone_context(model) for _ in range(depth - 1)]
         self._jobs: 'queue.Queue' = queue.Queue()
         self._threads: List[threading.Thread] = []

@@ -251,3 +251,22 @@ def test_tiny_clouds_equal_the_oracle(points):
     assert many[1] == data and many[2] == data and many[0] == model.compress(other)
     back = model.decompress_many(many)
     assert torch.equal(back[1], model.decompress(data)) and torch.equal(back[2], back[1])
+
+
+def test_two_sweeps_in_flight_write_the_single_sweep_streams():
+    """serving.FramePipeline over the integer codec: the second context is a copy of the modules over the same buffers (its layer
+    descriptor tables are rebuilt, not copied: they hold raw pointers); streams and decoded points as alone"""
+    from fastpcc_amd.serving import FramePipeline
+    cfg, model, _ = _model(32, 0, 5)
+    sweeps = [torch.from_numpy(batched(lidar_cloud(3 + i, beams=16, azimuths=384))).cuda() for i in range(4)]
+    alone = [model.compress(s) for s in sweeps]                       # (also builds the descriptor tables that the copy must not share)
+    recs = [model.decompress(d) for d in alone]
+
+    def step(m, i):
+        data = m.compress(sweeps[i])
+        return data, m.decompress(data)
+    with FramePipeline(model, depth=2) as pipe:
+        assert pipe.models[1] is not model and pipe.models[1].block_dec_recurrent._described() is not model.block_dec_recurrent._described()
+        out = pipe.map(step, [0, 1, 2, 3, 0, 1])
+    for i, (data, rec) in zip([0, 1, 2, 3, 0, 1], out):
+        assert data == alone[i] and torch.equal(rec, recs[i])
