@@ -459,8 +459,10 @@ static int64_t count_le_avx512(const uint16_t *row, int64_t width, uint16_t targ
 // Measured (tools/r05/dec_bench.py, profiles/r05/int8_stage.md): on the build container's Xeon one helper halves the time per symbol
 // (62.8 -> 31.2 ns); on the GPU boxes' EPYC 9575F a single core already streams the rows at 42 GB/s and helpers change nothing
 // (12.1 ns without, 11.1-13.3 ns with 1-6) in that bench, whose rows the CPU itself had just written.  In the codec the rows arrive
-// by DMA from the GPU and are cold: there ONE helper takes cfg#3's decode from 19.1 to 16.9 ms (2 or 4: 18.5; tools/r05/g27.sh) --
-// hence one helper by default.
+// by DMA from the GPU and are cold: there ONE helper takes cfg#3's decode from 19.1 to 16.9 ms (2 or 4: 18.5; tools/r05/g27.sh) in a
+// process the scheduler moves between the sockets; in a process bound to the GPU's NUMA node (replicas.bind_to_device_numa_node, what
+// bench.py does) it is neutral (15.3-16.2 ms without, 15.4-15.9 with; tools/r05/g47.sh) -- hence one helper by default: it costs
+// nothing where the placement is right and recovers 2 ms where it is not.
 namespace {
 class RowWarmers {
 public:
