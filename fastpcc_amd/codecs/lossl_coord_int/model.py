@@ -182,6 +182,8 @@ _POPCOUNT8 = np.array([bin(v).count('1') for v in range(256)], dtype=np.int64)
 
 def _children_count(symbols: np.ndarray) -> int:
     """occupied children of the decoded symbols (symbol + 1 = the 8 occupancy bits), counted on the host"""
+    if hasattr(np, 'bitwise_count'):                            # numpy >= 2: three narrow passes instead of a 64-bit table look-up
+        return int(np.bitwise_count(((symbols.astype(np.uint16) + 1) & 0xff).astype(np.uint8)).sum(dtype=np.int64))
     return int(_POPCOUNT8[(symbols.astype(np.int64) + 1) & 0xff].sum())
 
 
