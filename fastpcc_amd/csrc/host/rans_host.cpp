@@ -74,6 +74,25 @@ public:
         state_ = x + start + q * ((1u << BITS) - freq);           // == (q << BITS) + (x - q * freq) + start, one multiply-add on the chain
     }
 
+    // the same step without a data-dependent branch, for callers that have checked the room (2 bytes per symbol) up front: a symbol
+    // shifts out 0, 1 or 2 bytes (x < 2^31, the ceiling >= 2^15 * freq), which of them is as good as random to the branch predictor
+    // -- the loop above spends more on mispredictions than on arithmetic.  Both bytes are stored below the write position whether or
+    // not they are emitted; what is not emitted is overwritten by the next symbol or by finish().
+    template <uint32_t BITS>
+    inline void put_roomy(uint32_t start, uint32_t freq) {
+        static_assert(BITS == 16, "the byte count below is derived for 16-bit frequencies");
+        uint32_t x = state_;
+        const uint32_t ceiling = ((kLow >> BITS) << 8) * freq;
+        const uint32_t k = static_cast<uint32_t>(x >= ceiling) + static_cast<uint32_t>((x >> 8) >= ceiling);
+        cur_[-1] = static_cast<uint8_t>(x);
+        cur_[-2] = static_cast<uint8_t>(x >> 8);
+        cur_ -= k;
+        x >>= 8 * k;
+        const uint32_t q = static_cast<uint32_t>((static_cast<unsigned __int128>(x) * kRcp.m[freq]) >> 47);
+        state_ = x + start + q * ((1u << BITS) - freq);
+    }
+    bool room(int64_t bytes) const { return cur_ - base_ >= bytes; }
+
     // emit the state and return the stream length, or a negative code
     int64_t finish() {
         if (full_ || cur_ - base_ < 4) return FPCC_HOST_E_BUFFER;
@@ -620,7 +639,11 @@ int64_t fpcc_simple_enc_push_bin(fpcc_simple_enc *e, const uint16_t *edge, int64
 
 int64_t fpcc_simple_enc_push_ranges(fpcc_simple_enc *e, const uint16_t *start, const uint16_t *freq_m1, int64_t n) {
     if (!e || !start || !freq_m1) return FPCC_HOST_E_ARG;
-    for (int64_t i = n - 1; i >= 0; --i) e->w.put<kProbBits>(start[i], uint32_t(freq_m1[i]) + 1u);
+    if (e->w.room(2 * n + 8)) {
+        for (int64_t i = n - 1; i >= 0; --i) e->w.put_roomy<kProbBits>(start[i], uint32_t(freq_m1[i]) + 1u);
+    } else {
+        for (int64_t i = n - 1; i >= 0; --i) e->w.put<kProbBits>(start[i], uint32_t(freq_m1[i]) + 1u);
+    }
     return e->w.full() ? int64_t(FPCC_HOST_E_BUFFER) : e->w.buffered();
 }
 

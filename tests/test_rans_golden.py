@@ -255,3 +255,41 @@ print('ok')
         env = dict(os.environ, FPCC_HOST_WARMERS=warmers, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+def test_resolved_ranges_write_the_bytes_of_row_coding():
+    """RansEncoder.encode_ranges (the integer codec's encoder: symbols resolved to (start, freq - 1) on the device) against
+    RansEncoder.encode on the CDF rows themselves -- the stream format's definition -- for peaked and flat rows, frequencies 1 and
+    65 535, with and without the room for the branch-free step (two spare bytes per symbol) in the coder's buffer"""
+    import time
+    from fastpcc_amd.rans_coder import RansDecoder, RansEncoder
+    rng = np.random.default_rng(11)
+    n, width = 6000, 255
+    # strictly increasing rows that end at 65 535: a few distinct cuts close together (peaked: most symbols have small frequencies, the
+    # gaps are large) or spread over the whole range (flat)
+    cdf = np.empty((n, width), dtype=np.int64)
+    for i in range(n):
+        span = 65534 if i % 3 else 2000
+        base = int(rng.integers(1, 65535 - span)) if span < 65534 else 1
+        cdf[i, :-1] = base + np.sort(rng.choice(span, width - 1, replace=False))
+    cdf[:, -1] = 65535
+    cdf[0] = np.where(np.arange(width) < 7, np.arange(width) + 1, 65535 - (width - 1 - np.arange(width)))     # symbol 7 takes nearly all
+    rows = cdf.astype(np.uint16)
+    sym = rng.integers(0, width, n).astype(np.uint16)
+    sym[0] = 7
+    lo = np.where(sym == 0, 0, rows[np.arange(n), np.maximum(sym, 1) - 1]).astype(np.int64)
+    hi = rows[np.arange(n), sym].astype(np.int64)
+    hi[sym == width - 1] = 65536                                        # the last edge stands for 2^16
+    assert (hi > lo).all()
+    want_enc = RansEncoder(1 << 20)
+    want_enc.encode(rows, sym)
+    want = want_enc.flush()
+    for cap in (1 << 20, len(want) + 64):                        # roomy buffer: branch-free step; tight buffer: the checked loop
+        enc = RansEncoder(cap)
+        enc.encode_ranges(lo.astype(np.uint16), (hi - lo - 1).astype(np.uint16))
+        assert enc.flush() == want
+    dec = RansDecoder()
+    dec.flush(want)
+    back = np.empty(n, dtype=np.uint16)
+    dec.decode(rows, back)
+    assert (back == sym).all()
