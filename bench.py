@@ -495,6 +495,7 @@ def main():
     results = pipeline.map(timed_step, range(args.steps))
     barrier()
     elapsed = time.perf_counter() - t0
+    hbm_peak_gib = torch.cuda.max_memory_allocated(device) / 2 ** 30          # reference frames, warm-up and the timed region
     data, rec = results[-1][0][0], results[-1][1][0]
     del results
     if os.environ.get('FPCC_BENCH_STEP_TIMES') == '1':
@@ -601,6 +602,7 @@ def main():
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
                        'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results',
                        'coder_handover_retries': GeoLosslessEntropyModel.handover_retries,
+                       'hbm_peak_gib': round(hbm_peak_gib, 1),
                        'host_binding': numa if numa is not None else 'none'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
