@@ -139,6 +139,27 @@ public:
         }
         state_ = x;
     }
+    // The same step for the long symbol loops (255-ary rows of the integer codec): whether a symbol shifts in 0, 1 or 2 bytes is as
+    // good as random to the branch predictor, and the loop above pays for that on the decoder's serial chain.  With two readable
+    // bytes ahead and a state that needs at most two (every valid stream: x >= 2^7), the count is arithmetic and both bytes are read
+    // unconditionally; anything else (the stream's last bytes, a corrupt state) takes the checked loop -- same result in every case.
+    template <uint32_t BITS>
+    inline void take_fast(uint32_t start, uint32_t freq) {
+        uint32_t x = freq * (state_ >> BITS) + (state_ & ((1u << BITS) - 1u)) - start;
+        if (__builtin_expect(end_ - p_ >= 2 && x >= (1u << 7), 1)) {
+            const uint32_t k = static_cast<uint32_t>(x < kLow) + static_cast<uint32_t>(x < (kLow >> 8));
+            const uint32_t w = uint32_t(p_[0]) << 8 | uint32_t(p_[1]);
+            state_ = (x << (8 * k)) | (w >> (16 - 8 * k));
+            p_ += k;
+            return;
+        }
+        for (int r = 0; r < kMaxRefill && x < kLow; ++r) {
+            uint32_t b = p_ < end_ ? *p_ : 0u;
+            ++p_;
+            x = (x << 8) | b;
+        }
+        state_ = x;
+    }
 
 private:
     const uint8_t *p_, *end_;
@@ -688,7 +709,7 @@ int64_t fpcc_simple_dec_pop(fpcc_simple_dec *d, const uint16_t *rows, int64_t n_
         s = std::min<int64_t>(s, width - 1);
         uint32_t lo, hi;
         edge_range(row, width, static_cast<uint32_t>(s), lo, hi);
-        d->r.take<kProbBits>(lo, hi - lo);
+        d->r.take_fast<kProbBits>(lo, hi - lo);
         symbols_out[i] = static_cast<uint16_t>(s);
     }
     return FPCC_HOST_OK;
