@@ -264,3 +264,29 @@ def test_streams_of_earlier_numerics_versions_are_refused(v2, version):
     rec = versioned.decompress(bytes([ops.numerics_version()]) + bytes.fromhex(cur['stream_hex']))
     ME.clear_global_coordinate_manager()
     assert len(rec) == cur['decoded_voxels']
+
+
+def test_cfg3_sweeps_of_three_sizes_lossless_on_both_traversal_paths():
+    """six LiDAR-like sweeps (28 K, 64 K, 113 K voxels; different seeds put their octree levels on both sides of the 8192-row switch
+    between the offset-split and the tiled int8 convolution): lossless, the level-per-call path writes the module-by-module path's bytes,
+    a batch writes the single sweeps' streams"""
+    from fastpcc_amd.codecs.lossl_coord_int import Config, Model, model as int_model
+    from fastpcc_amd.codecs.lossl_coord_int.init_random import randomize_
+    model = Model(Config(), 'cuda')
+    randomize_(model, 1)
+    model = model.cuda().eval()
+    frames, streams = [], []
+    for s in range(6):
+        beams, az = (64, 2048) if s % 3 == 0 else ((32, 1024) if s % 3 == 1 else (48, 1536))
+        xyz = lidar_cloud(100 + s, beams=beams, azimuths=az)
+        frame = torch.from_numpy(batched(xyz)).cuda()
+        data = model.compress(frame)
+        assert (_key(model.decompress(data).cpu().numpy()) == _key(xyz)).all(), f'sweep {s}: not lossless'
+        int_model.FAST_LEVELS = False
+        try:
+            assert model.compress(frame) == data, f'sweep {s}: the traversal paths write different bytes'
+        finally:
+            int_model.FAST_LEVELS = True
+        frames.append(frame)
+        streams.append(data)
+    assert model.compress_many(frames[:3]) == streams[:3] and model.compress_many(frames[3:]) == streams[3:]
