@@ -399,8 +399,9 @@ __device__ __forceinline__ void conv_i8_epilogue(const ConvI8Args &p, const i32x
         int64_t orow[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) orow[reg] = my_rows[(reg & 3) + 8 * (reg >> 2) + 4 * lh];
-        // (uniform) may the range checks be dropped?  |acc| <= n_off x (32 k_steps) x 127 x 128 when nothing but products went into it
-        const int64_t acc_max = (int64_t)p.n_off * p.k_steps * 32 * (127 * 128);
+        // (uniform) may the range checks be dropped?  |acc| <= n_off x (32 k_steps) x 128 x 128 when nothing but products went into it
+        // (any int8 weight, -128 included: the entry points take arbitrary int8 weights)
+        const int64_t acc_max = (int64_t)p.n_off * p.k_steps * 32 * (128 * 128);
         bool cols_fit = !p.zp_comp && acc_max < ((int64_t)1 << 31);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

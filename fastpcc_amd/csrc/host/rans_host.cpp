@@ -24,6 +24,7 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -512,6 +513,7 @@ public:
     // arrives meanwhile simply runs without them): true = the caller owns them and must call end()
     bool begin(const void *base, size_t bytes) {
         if (n_ == 0 || bytes < (size_t)1 << 20) return false;
+        if (getpid() != owner_) return false;        // a fork()ed child inherits the object but none of its threads: decode without helpers
         if (busy_.exchange(true, std::memory_order_acquire)) return false;
         pin_near_caller();
         std::lock_guard<std::mutex> g(mu_);
@@ -543,6 +545,7 @@ private:
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && (unsigned)n_ + 1 > hw) n_ = hw > 1 ? (int)hw - 1 : 0;
         for (int i = 0; i < n_; ++i) threads_.emplace_back([this] { run(); });
+        owner_ = getpid();
     }
     ~RowWarmers() {
         { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
@@ -612,6 +615,7 @@ private:
 #endif
     }
     int n_ = 0;
+    pid_t owner_ = 0;
     std::vector<std::thread> threads_;
     std::mutex mu_;
     std::condition_variable cv_, idle_;

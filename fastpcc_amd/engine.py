@@ -653,7 +653,11 @@ PAD_MIN_ROWS = 8192        # FPCC_PAD_MIN_ROWS of include/fpcc_hip.h: part of th
 def _pad_plan(c1: int, c2: int, c_out: int, n_out: int):
     """Shapes the MFMA kernel does not take as they are (C_in not a multiple of 16, C_out not 32/64/128) but that are big
     enough to matter are zero-padded to the next MFMA shape: -> (c1p, c2p, c_outp) or None.  Zero channels add exact
-    zeros to the FMA chains, so only the (documented) summation order changes."""
+    zeros to the FMA chains, so only the (documented) summation order changes.
+    INVARIANT (the batch interface rests on it): n_out is the row count of the CLOUD a row belongs to, never of the launch -- encoder
+    and decoder may batch different sets of clouds together (compress_partitions groups by voxel counts, decompress_partitions by a
+    header proxy), so any rule that selects a summation order from a row count must look at the cloud's own rows
+    (tests/test_gpu_codec_many.py::test_encoder_and_decoder_may_group_a_partition_list_differently)."""
     if ops.conv_order(c1, c2, c_out) != 0 or c_out > 128 or c1 + c2 < 4 or (c1 + c2) * c_out < 32 or n_out < PAD_MIN_ROWS:
         return None
     c1p = (c1 + 15) // 16 * 16

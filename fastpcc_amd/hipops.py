@@ -343,7 +343,9 @@ def level_counts_clouds(keys: torch.Tensor, levels: int, cloud_shift: int, n_clo
                                           hist.data_ptr(), _stream()))
     h = hist.tolist()
     if sum(row[levels + 1] for row in h) != n:
-        raise ValueError('a key carries a cloud index outside the batch')
+        raise ValueError(f'a key carries a cloud index outside the batch of {n_clouds}: either the batch column is wrong or a coordinate '
+                         f'(after subtracting its cloud\'s minimum) needs more than {cloud_shift // 3} bits per axis -- the Morton code of a '
+                         f'cloud is {cloud_shift} bits wide (resolutions up to {1 << (cloud_shift // 3)})')
     out = [[0] * n_clouds for _ in range(levels + 1)]
     for c, row in enumerate(h):
         if row[levels + 1] and row[levels + 1] != 1 + sum(row[:levels + 1]):        # every neighbouring pair of distinct keys is in one bin

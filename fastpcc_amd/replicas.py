@@ -110,6 +110,22 @@ def aggregate(elapsed_s: float, units: float, device: torch.device) -> Tuple[flo
     return float(t.item()), float(u.item())
 
 
+def rank_spread(value: float, device: torch.device) -> dict:
+    """collective: what lets a reader of the bench line confirm the job ran on as many ranks as it says -- `ranks` is the sum over
+    ranks of a device tensor of ones through the data-path backend (RCCL on GPUs), next to the backend's name and the min / max over
+    ranks of every rank's own `value`"""
+    ones = torch.ones(1, dtype=torch.float64, device=device)
+    lo = torch.tensor([value], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    backend = 'none'
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        backend = str(dist.get_backend())
+    return {'ranks': int(round(float(ones.item()))), 'backend': backend, 'min': float(lo.item()), 'max': float(hi.item())}
+
+
 def gather_bytes(blob: bytes, device: torch.device) -> List[bytes]:
     """variable-length all-gather of one byte string per rank (partition bitstreams of one frame, a few 100 KB):
     lengths first, then one padded uint8 all_gather."""

@@ -333,7 +333,11 @@ int64_t fpcc_conv_f32_ws_bytes(int c1, int c2, int c_out, int n_offsets, int gro
 int fpcc_conv_f32_order(int c1, int c2, int c_out);
 /* Same, including the launch-dependent choice: the offset-split shapes of fpcc_conv_f32_ws_bytes have order 2
  * (per-offset FMA chains from zero in the MFMA channel order, partial sums added in ascending offset order, then the
- * bias). */
+ * bias).
+ * INVARIANT for callers that batch independent clouds in one launch: since numerics version 2 the order is a function of the
+ * layer's SHAPE alone (n_out is accepted and ignored); the one rule above this interface that does look at a row count
+ * (FPCC_PAD_MIN_ROWS, zero-padding of narrow shapes) must be applied to the rows of the cloud a row belongs to, not of the launch:
+ * an encoder and a decoder may batch different sets of clouds together and must still agree bit for bit. */
 int fpcc_conv_f32_order_ex(int c1, int c2, int c_out, int n_offsets, int groups, int64_t n_out);
 
 /* Weight gradient of the same operator (training; MinkowskiEngine's autograd backward, reached from

@@ -95,6 +95,28 @@ def test_partition_lists_go_through_grouped_traversals(model, clouds, monkeypatc
         assert rec.shape[0] == sum(c.shape[0] for c in clouds)
 
 
+def test_encoder_and_decoder_may_group_a_partition_list_differently(model, clouds, monkeypatch):
+    """compress_partitions groups by input voxel counts, decompress_partitions by a proxy read from the headers: the two sides may
+    batch DIFFERENT sets of clouds together.  That is sound only because a cloud's activations do not depend on what shares its batch
+    (every output row is its own summation chain; the row-count rules -- PAD_MIN_ROWS, top-k, headers -- look at the cloud's own rows:
+    include/fpcc_hip.h at fpcc_conv_f32_order_ex, engine._pad_plan).  Encode under every grouping, decode under every other one."""
+    whole = torch.cat(clouds)
+    sizes = [c.shape[0] for c in clouds]
+    caps = (10 ** 9, sum(sizes[:3]), sizes[0] + sizes[1], 1)
+    monkeypatch.setattr(type(model), 'MANY_MAX_VOXELS', 10 ** 9)
+    want_blob = model.compress_partitions([whole, *clouds])
+    want_rec = model.decompress_partitions(want_blob)
+    for enc_cap in caps:
+        monkeypatch.setattr(type(model), 'MANY_MAX_VOXELS', enc_cap)
+        blob = model.compress_partitions([whole, *clouds])
+        assert blob == want_blob
+        for dec_cap in caps:
+            if dec_cap == enc_cap:
+                continue
+            monkeypatch.setattr(type(model), 'MANY_MAX_VOXELS', dec_cap)
+            assert _same_points(model.decompress_partitions(blob), want_rec), (enc_cap, dec_cap)
+
+
 def _chain_runs():
     import json
     import os

@@ -125,12 +125,8 @@ def test_v2_against_the_oracle_at_300k_voxels(v2):
     assert (sym['residual'].reshape(-1) == o.symbols['residual'].reshape(-1)).all()
     assert (sym['occupancy'].astype(bool) == np.concatenate(o.symbols['occupancy'])).all()
     p_gpu, p_cpu = sym['prob'].astype(np.int64), np.concatenate(o.symbols['prob']).astype(np.int64)
-    assert np.abs(p_gpu - p_cpu).max() <= 1
-    assert data[:9] == want[:9]
-    if (p_gpu == p_cpu).all():
-        assert data == want
-    else:
-        assert abs(len(data) - len(want)) <= max(4, 0.002 * len(want))
+    assert (p_gpu == p_cpu).all()                                   # numerics version 3: specified logistic function, no tolerance
+    assert data == want
     rec_o = o.decompress(want)                                       # same symbols -> the same reconstruction, voxel for voxel
     assert (_key(np.asarray(rec_o)[:, -3:]) == _key(rec)).all()
 

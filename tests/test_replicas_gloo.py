@@ -26,8 +26,9 @@ def _worker(rank, world, port, q):
     mine = replicas.frames_of_rank(list(range(5)), rank, world)
     elapsed, units = replicas.aggregate(1.0 + rank, 1000.0 * (rank + 1) * len(mine), dev)
     blobs = replicas.gather_bytes(bytes([rank + 1]) * (3 + 4 * rank) if rank else b'', dev)
+    spread = replicas.rank_spread(10.0 + rank, dev)
     replicas.barrier(dev)
-    q.put((rank, mine, elapsed, units, blobs))
+    q.put((rank, mine, elapsed, units, blobs, spread))
     dist.destroy_process_group()
 
 
@@ -43,7 +44,8 @@ def test_two_rank_aggregation():
         p.join(60)
         assert p.exitcode == 0
     assert got[0][1] == [0, 2, 4] and got[1][1] == [1, 3]
-    for rank, mine, elapsed, units, blobs in got:
+    for rank, mine, elapsed, units, blobs, spread in got:
+        assert spread == {'ranks': 2, 'backend': 'gloo', 'min': 10.0, 'max': 11.0}   # what the bench line's rccl_ranks / per_rank_value carry
         assert elapsed == 2.0                                   # max over ranks
         assert units == 1000.0 * 3 + 2000.0 * 2                 # sum over ranks
         assert blobs == [b'', bytes([2]) * 7]                   # ragged, one of them empty
@@ -53,6 +55,7 @@ def test_single_process_is_identity():
     from fastpcc_amd import replicas
     assert replicas.aggregate(0.5, 7.0, torch.device('cpu')) == (0.5, 7.0)
     assert replicas.gather_bytes(b'abc', torch.device('cpu')) == [b'abc']
+    assert replicas.rank_spread(3.0, torch.device('cpu')) == {'ranks': 1, 'backend': 'none', 'min': 3.0, 'max': 3.0}
     assert replicas.frames_of_rank('abcd', 0, 1) == list('abcd')
 
 
