@@ -2,7 +2,7 @@
 // does with small PyTorch ops and device->host copies.  All are streaming, HBM-bound passes.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include <algorithm>
 
 #include "common.h"
 
@@ -61,31 +61,6 @@ __device__ __forceinline__ float max8(const float4 a, const float4 b) {
     return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
 }
 
-// one thread per parent cell: candidates that equal the cell maximum are "local maxima" and leave the ranking
-__global__ void k_mask_local_max(const float4 *__restrict__ logit, int64_t m, float4 *__restrict__ ranked) {
-    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= m) return;
-    const float4 a = logit[2 * p], b = logit[2 * p + 1];
-    const float mx = max8(a, b);
-    const float inf = __builtin_huge_valf();
-    ranked[2 * p] = make_float4(a.x == mx ? inf : a.x, a.y == mx ? inf : a.y, a.z == mx ? inf : a.z, a.w == mx ? inf : a.w);
-    ranked[2 * p + 1] = make_float4(b.x == mx ? inf : b.x, b.y == mx ? inf : b.y, b.z == mx ? inf : b.z, b.w == mx ? inf : b.w);
-}
-
-__global__ void k_keep(const float4 *__restrict__ logit, int64_t m, const float *__restrict__ sorted, int64_t kth,
-                       uint8_t *__restrict__ keep) {
-    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= m) return;
-    const float thr = kth >= 1 ? sorted[kth - 1] : -__builtin_huge_valf();
-    const float4 a = logit[2 * p], b = logit[2 * p + 1];
-    const float mx = max8(a, b);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint64_t bits = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bits |= (uint64_t)((v[k] > thr || v[k] == mx) ? 1 : 0) << (8 * k);
-    reinterpret_cast<uint64_t *>(keep)[p] = bits;
-}
-
 // --- variant whose "cell" is any run of candidate groups (e.g. all descendants of a stride-4 voxel) -------------------
 __device__ __forceinline__ unsigned f2ord(float f) {     // order-preserving float -> uint
     const unsigned u = __float_as_uint(f);
@@ -101,30 +76,119 @@ __global__ void k_seg_max(const float4 *__restrict__ logit, int64_t m, const int
     atomicMax(&seg_max[seg[p]], f2ord(max8(logit[2 * p], logit[2 * p + 1])));   // exact and order independent
 }
 
-__global__ void k_mask_seg_max(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
-                               const unsigned *__restrict__ seg_max, float4 *__restrict__ ranked) {
-    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= m) return;
-    const float4 a = logit[2 * p], b = logit[2 * p + 1];
-    const float mx = ord2f(seg_max[seg[p]]);
-    const float inf = __builtin_huge_valf();
-    ranked[2 * p] = make_float4(a.x == mx ? inf : a.x, a.y == mx ? inf : a.y, a.z == mx ? inf : a.z, a.w == mx ? inf : a.w);
-    ranked[2 * p + 1] = make_float4(b.x == mx ? inf : b.x, b.y == mx ? inf : b.y, b.z == mx ? inf : b.z, b.w == mx ? inf : b.w);
+// ---- k-th smallest candidate by radix SELECT (three histogram passes over 11 + 11 + 10 key bits) instead of a full sort --------------
+// The threshold of the decoder's adaptive pruning is ONE order statistic of the 8 m candidates (lossy_coord_v2/layers.py:164-180: kthvalue);
+// rounds 1-5 sorted all of them (rocprim radix sort: ~40 bytes moved per candidate and a ranked copy).  A pass reads the logits once
+// (32 bytes per group of 8), recomputes "is this candidate its cell's maximum" on the fly (maxima rank as +inf) and histograms the keys
+// that still match the prefix found so far in LDS; a one-workgroup kernel then walks the 2048 bins.  Exact: an order statistic does not
+// depend on how it is found.
+struct SelectState {
+    unsigned long long rank;      // 1-based rank still to find among the keys matching `prefix`; 0 = no threshold (keep everything)
+    unsigned prefix;              // the key bits fixed so far (right-aligned)
+    float thr;                    // the result, after the last pass
+};
+constexpr int kSelBins = 2048;
+__global__ void k_select_init(SelectState *st, SelectState v) { *st = v; }
+
+template <int PASS, bool SEG>
+__global__ __launch_bounds__(256) void k_select_hist(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
+                                                     const unsigned *__restrict__ seg_max, const SelectState *__restrict__ st,
+                                                     unsigned *__restrict__ hist) {
+    __shared__ unsigned s_h[kSelBins];
+    for (int i = threadIdx.x; i < kSelBins; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const unsigned prefix = PASS ? st->prefix : 0u;
+    const bool live = st->rank != 0ull;
+    // PASS 0: bits 31..21, PASS 1: bits 20..10 under an 11-bit prefix, PASS 2: bits 9..0 under a 22-bit prefix
+    constexpr int kShift = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr unsigned kMask = PASS == 2 ? 1023u : 2047u;
+    if (live)
+        for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < m; p += (int64_t)gridDim.x * 256) {
+            const float4 a = logit[2 * p], b = logit[2 * p + 1];
+            const float mx = SEG ? ord2f(seg_max[seg[p]]) : max8(a, b);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned key = f2ord(v[k] == mx ? __builtin_huge_valf() : v[k]);
+                if (PASS == 0 || (key >> (kShift + (PASS == 2 ? 10 : 11))) == prefix) atomicAdd(&s_h[(key >> kShift) & kMask], 1u);
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
 
-__global__ void k_keep_seg(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
-                           const unsigned *__restrict__ seg_max, const float *__restrict__ sorted, int64_t kth,
-                           uint8_t *__restrict__ keep) {
+template <int PASS>
+__global__ __launch_bounds__(256) void k_select_pick(unsigned *__restrict__ hist, SelectState *__restrict__ st) {
+    __shared__ unsigned long long s_part[256];
+    const unsigned long long rank = st->rank;
+    if (rank == 0ull) {                                                         // no threshold: everything above -inf is kept
+        if (threadIdx.x == 0 && PASS == 2) st->thr = -__builtin_huge_valf();
+        return;
+    }
+    // 8 bins per thread, ascending
+    unsigned long long mine = 0;
+    for (int j = 0; j < 8; ++j) mine += hist[threadIdx.x * 8 + j];
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        int c = 255;
+        for (int t = 0; t < 256; ++t) {
+            if (acc + s_part[t] >= rank) { c = t; break; }
+            acc += s_part[t];
+        }
+        unsigned long long before = acc;
+        int bin = c * 8 + 7;
+        for (int j = 0; j < 8; ++j) {
+            const unsigned h = hist[c * 8 + j];
+            if (before + h >= rank) { bin = c * 8 + j; break; }
+            before += h;
+        }
+        st->rank = rank - before;
+        const unsigned prefix = PASS == 0 ? (unsigned)bin : ((st->prefix << (PASS == 2 ? 10 : 11)) | (unsigned)bin);
+        st->prefix = prefix;
+        if (PASS == 2) st->thr = ord2f(prefix);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += 256) hist[i] = 0;              // clean for the next pass
+}
+
+template <bool SEG>
+__global__ void k_keep_thr(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg, const unsigned *__restrict__ seg_max,
+                           const SelectState *__restrict__ st, uint8_t *__restrict__ keep) {
     int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (p >= m) return;
-    const float thr = kth >= 1 ? sorted[kth - 1] : -__builtin_huge_valf();
+    const float thr = st->thr;
     const float4 a = logit[2 * p], b = logit[2 * p + 1];
-    const float mx = ord2f(seg_max[seg[p]]);
+    const float mx = SEG ? ord2f(seg_max[seg[p]]) : max8(a, b);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint64_t bits = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) bits |= (uint64_t)((v[k] > thr || v[k] == mx) ? 1 : 0) << (8 * k);
     reinterpret_cast<uint64_t *>(keep)[p] = bits;
+}
+
+// the three passes + the final mask; ws = SelectState (16 B, padded to 256) + 2048 bins
+template <bool SEG>
+int select_and_keep(const float *logit, int64_t m, const int32_t *seg, const unsigned *seg_max, int64_t kth, uint8_t *keep_out, void *ws,
+                    hipStream_t s) {
+    SelectState *st = static_cast<SelectState *>(ws);
+    unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 256);
+    SelectState init{kth >= 1 ? (unsigned long long)kth : 0ull, 0u, -__builtin_huge_valf()};
+    // the state goes through a kernel argument copy: hipMemcpyAsync from a stack variable would race with the return
+    FPCC_HIP(hipMemsetAsync(ws, 0, 256 + 4 * kSelBins, s));
+    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, s, st, init);
+    const float4 *lg = reinterpret_cast<const float4 *>(logit);
+    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 2048);
+    hipLaunchKernelGGL((k_select_hist<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
+    hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(256), 0, s, hist, st);
+    hipLaunchKernelGGL((k_select_hist<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
+    hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(256), 0, s, hist, st);
+    hipLaunchKernelGGL((k_select_hist<2, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
+    hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(256), 0, s, hist, st);
+    hipLaunchKernelGGL(k_keep_thr<SEG>, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s, lg, m, seg, seg_max, (const SelectState *)st, keep_out);
+    return check_hip(hipGetLastError(), "topk select");
 }
 
 }  // namespace
@@ -159,68 +223,38 @@ extern "C" int fpcc_child_mask(const int32_t *child_row, int64_t m, uint8_t *mas
     return FPCC_OK;
 }
 
+static int64_t select_ws_bytes() { return 256 + 4 * kSelBins; }
+
 extern "C" int64_t fpcc_topk_keep(const float *logit, int64_t m, int64_t target, uint8_t *keep_out, void *ws,
                                   int64_t ws_bytes, void *stream) {
     if (m < 0 || target < 0) return fail_arg("topk_keep: negative size");
-    const int64_t n = 8 * (m > 0 ? m : 1);
-    size_t sort_bytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, (const float *)nullptr, (float *)nullptr, (size_t)n);
-    if (e != hipSuccess) return check_hip(e, "radix_sort_keys(size query)");
-    const int64_t arr = align_up(4 * n, 256);
-    const int64_t need = 2 * arr + align_up((int64_t)sort_bytes, 256);
+    const int64_t need = select_ws_bytes();
     if (!ws) return need;
     if (ws_bytes < need) { set_error("topk_keep: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
     if (m == 0) return FPCC_OK;
     if (!logit || !keep_out) return fail_arg("topk_keep: null pointer");
-    if ((reinterpret_cast<uintptr_t>(logit) & 15) || (reinterpret_cast<uintptr_t>(keep_out) & 7))
-        return fail_arg("topk_keep: logit must be 16-byte and keep_out 8-byte aligned");
-    float *ranked = static_cast<float *>(ws);
-    float *sorted = reinterpret_cast<float *>(static_cast<char *>(ws) + arr);
-    void *tmp = static_cast<char *>(ws) + 2 * arr;
-    hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_mask_local_max, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s,
-                       reinterpret_cast<const float4 *>(logit), m, reinterpret_cast<float4 *>(ranked));
-    FPCC_LAUNCHED(k_mask_local_max);
-    FPCC_HIP(rocprim::radix_sort_keys(tmp, sort_bytes, (const float *)ranked, sorted, (size_t)(8 * m), 0u, 32u, s));
-    const int64_t kth = 8 * m - target;   // k-th smallest (1-based) of the non-maximum candidates is the threshold
-    hipLaunchKernelGGL(k_keep, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s,
-                       reinterpret_cast<const float4 *>(logit), m, (const float *)sorted, kth, keep_out);
-    FPCC_LAUNCHED(k_keep);
-    return FPCC_OK;
+    if ((reinterpret_cast<uintptr_t>(logit) & 15) || (reinterpret_cast<uintptr_t>(keep_out) & 7) || (reinterpret_cast<uintptr_t>(ws) & 15))
+        return fail_arg("topk_keep: logit / workspace must be 16-byte and keep_out 8-byte aligned");
+    // the k-th smallest (1-based) of the candidates ranked with their cell maxima at +inf is the threshold
+    return select_and_keep<false>(logit, m, nullptr, nullptr, 8 * m - target, keep_out, ws, as_stream(stream));
 }
 
 extern "C" int64_t fpcc_topk_keep_cells(const float *logit, int64_t m, const int32_t *cell_of_group, int64_t n_cells,
                                         int64_t target, uint8_t *keep_out, void *ws, int64_t ws_bytes, void *stream) {
     if (m < 0 || target < 0 || n_cells < 0) return fail_arg("topk_keep_cells: negative size");
-    const int64_t n = 8 * (m > 0 ? m : 1);
-    size_t sort_bytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, (const float *)nullptr, (float *)nullptr, (size_t)n);
-    if (e != hipSuccess) return check_hip(e, "radix_sort_keys(size query)");
-    const int64_t arr = align_up(4 * n, 256);
     const int64_t cells = align_up(4 * (n_cells > 0 ? n_cells : 1), 256);
-    const int64_t need = 2 * arr + cells + align_up((int64_t)sort_bytes, 256);
+    const int64_t need = select_ws_bytes() + cells;
     if (!ws) return need;
     if (ws_bytes < need) { set_error("topk_keep_cells: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return FPCC_E_WORKSPACE; }
     if (m == 0) return FPCC_OK;
     if (!logit || !keep_out || !cell_of_group) return fail_arg("topk_keep_cells: null pointer");
-    if ((reinterpret_cast<uintptr_t>(logit) & 15) || (reinterpret_cast<uintptr_t>(keep_out) & 7))
-        return fail_arg("topk_keep_cells: logit must be 16-byte and keep_out 8-byte aligned");
-    float *ranked = static_cast<float *>(ws);
-    float *sorted = reinterpret_cast<float *>(static_cast<char *>(ws) + arr);
-    unsigned *seg_max = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * arr);
-    void *tmp = static_cast<char *>(ws) + 2 * arr + cells;
+    if ((reinterpret_cast<uintptr_t>(logit) & 15) || (reinterpret_cast<uintptr_t>(keep_out) & 7) || (reinterpret_cast<uintptr_t>(ws) & 15))
+        return fail_arg("topk_keep_cells: logit / workspace must be 16-byte and keep_out 8-byte aligned");
+    unsigned *seg_max = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + select_ws_bytes());
     hipStream_t s = as_stream(stream);
     FPCC_HIP(hipMemsetAsync(seg_max, 0, (size_t)(4 * n_cells), s));       // 0 orders below every float
-    const dim3 grid(blocks_for(m, kThreads)), block(kThreads);
-    const float4 *lg = reinterpret_cast<const float4 *>(logit);
-    hipLaunchKernelGGL(k_seg_max, grid, block, 0, s, lg, m, cell_of_group, seg_max);
+    hipLaunchKernelGGL(k_seg_max, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s, reinterpret_cast<const float4 *>(logit), m, cell_of_group,
+                       seg_max);
     FPCC_LAUNCHED(k_seg_max);
-    hipLaunchKernelGGL(k_mask_seg_max, grid, block, 0, s, lg, m, cell_of_group, (const unsigned *)seg_max,
-                       reinterpret_cast<float4 *>(ranked));
-    FPCC_LAUNCHED(k_mask_seg_max);
-    FPCC_HIP(rocprim::radix_sort_keys(tmp, sort_bytes, (const float *)ranked, sorted, (size_t)(8 * m), 0u, 32u, s));
-    hipLaunchKernelGGL(k_keep_seg, grid, block, 0, s, lg, m, cell_of_group, (const unsigned *)seg_max, (const float *)sorted,
-                       8 * m - target, keep_out);
-    FPCC_LAUNCHED(k_keep_seg);
-    return FPCC_OK;
+    return select_and_keep<true>(logit, m, cell_of_group, (const unsigned *)seg_max, 8 * m - target, keep_out, ws, s);
 }

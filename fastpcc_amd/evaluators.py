@@ -6,7 +6,15 @@ Definitions (pc_error's, restated in SURVEY.md section 8d): with A the original 
     mse1 = mean over a in A of min_b |a-b|^2,  mse2 = mean over b in B of min_a |a-b|^2,  mseF = max(mse1, mse2),
     PSNR = 10 log10(3 peak^2 / mse),  peak = resolution - 1   (the reference passes --resolution={resolution-1}).
 Squared distances are exact integers (fpcc_nn_dist2), sums are 64-bit integers, so the numbers do not depend on any
-reduction order.  Colour (optional): BT.709 YUV of nearest-neighbour pairs, peak 255; where several neighbours tie in
+reduction order.
+Point-to-plane (D2) and Hausdorff (`pc_error_metrics`; the reference always hands pc_error normals, so its result files carry
+'mseF,PSNR (p2plane)', which scripts/compare_performance.py:25 reads for D2 curves): with n_b the normal pc_error gives voxel b,
+    plane1 = mean over a in A of mean over the nearest b (all ties) of ((a - b) . n_b)^2,   h. = max instead of mean over a;
+normals of A: the caller's (`org_normals`, a PLY's nx ny nz) or PCA over the 30 nearest voxels (Open3D's estimate_normals default,
+lib/metrics/pc_error_wrapper.py:66-68); normals of B: transferred from A as pc_error does (fpcc_transfer_normals).  pc_error is an
+external binary that is not in the reference tree: these definitions restate its published algorithm (mpeg-pcc-dmetric), parity with
+the binary is unpinned (oracle/metrics.py says the same); PCA normals carry this build's sign rule (include/fpcc_hip.h).
+Colour (optional): BT.709 YUV of nearest-neighbour pairs, peak 255; where several neighbours tie in
 distance pc_error averages their colours, this build takes the first in Morton order.
 """
 import json
@@ -78,6 +86,69 @@ def d1_metrics(org_xyz: torch.Tensor, rec_xyz: torch.Tensor, resolution: float, 
     return out
 
 
+@torch.no_grad()
+def estimate_normals(xyz: torch.Tensor, knn: int = 30) -> torch.Tensor:
+    """float64 [n, 3] PCA normals of integer voxel coordinates [n, 3] (unique rows), in the caller's row order: the role of
+    Open3D's estimate_normals() in lib/metrics/pc_error_wrapper.py:66-68 (KNN search, 30 neighbours, the point itself included)"""
+    a = xyz.to(torch.int32).contiguous()
+    bits = max(1, int(a.max().item()).bit_length())
+    ca, ka, pa = _keys_of(a, bits)
+    order = pa.long()
+    rows, _ = ops.knn_voxels(ka, bits, ca[order].contiguous(), min(int(knn), 32))
+    normals_sorted = ops.pca_normals(ka, bits, rows)
+    out = torch.empty_like(normals_sorted)
+    out[order] = normals_sorted
+    return out
+
+
+@torch.no_grad()
+def pc_error_metrics(org_xyz: torch.Tensor, rec_xyz: torch.Tensor, resolution: float, org_color: Optional[torch.Tensor] = None,
+                     rec_color: Optional[torch.Tensor] = None, org_normals: Optional[torch.Tensor] = None, hausdorff: bool = False,
+                     knn: int = 30) -> Dict[str, float]:
+    """d1_metrics plus the point-to-plane lines (always, like a pc_error run that is given normals) and, with hausdorff=True, the
+    'h.' lines -- keys as pc_error prints them.  Coordinates must be unique rows (voxel sets); org_normals [n, 3] in org_xyz's order."""
+    out = d1_metrics(org_xyz, rec_xyz, resolution, org_color, rec_color)
+    a = org_xyz.to(torch.int32).contiguous()
+    b = rec_xyz.to(torch.int32).contiguous()
+    bits = max(1, int(max(a.max().item(), b.max().item())).bit_length())
+    ca, ka, pa = _keys_of(a, bits)
+    cb, kb, pb = _keys_of(b, bits)
+    ca_s, cb_s = ca[pa.long()].contiguous(), cb[pb.long()].contiguous()           # voxels in key order
+    if org_normals is None:
+        rows, _ = ops.knn_voxels(ka, bits, ca_s, min(int(knn), 32))
+        na = ops.pca_normals(ka, bits, rows)
+    else:
+        if org_normals.shape != (a.shape[0], 3):
+            raise ValueError('org_normals must be [n, 3] in the order of org_xyz')
+        na = org_normals.to(torch.float64)[pa.long()].contiguous()
+    nb = ops.transfer_normals(ka, ca_s, na, kb, cb_s, bits)
+    peak = 3.0 * float(resolution - 1) ** 2
+    res = {}
+    for tag, (keys, normals, query) in (('1', (kb, nb, ca_s)), ('2', (ka, na, cb_s))):
+        plane, d, _ = ops.nn_plane_dist2(keys, bits, normals, query)
+        s, mx = ops.sum_max_f64(plane).tolist()
+        res[tag] = (s / query.shape[0], mx, float(d.max().item()))
+    for tag in ('1', '2'):
+        mse, h_plane, h_point = res[tag]
+        out[f'mse{tag}      (p2plane)'] = mse
+        out[f'mse{tag},PSNR (p2plane)'] = _psnr(peak, mse)
+        if hausdorff:
+            out[f'h.       {tag}(p2point)'] = h_point
+            out[f'h.,PSNR  {tag}(p2point)'] = _psnr(peak, h_point)
+            out[f'h.       {tag}(p2plane)'] = h_plane
+            out[f'h.,PSNR  {tag}(p2plane)'] = _psnr(peak, h_plane)
+    msef = max(res['1'][0], res['2'][0])
+    out['mseF      (p2plane)'] = msef
+    out['mseF,PSNR (p2plane)'] = _psnr(peak, msef)
+    if hausdorff:
+        hp, hl = max(res['1'][2], res['2'][2]), max(res['1'][1], res['2'][1])
+        out['h.        (p2point)'] = hp
+        out['h.,PSNR   (p2point)'] = _psnr(peak, hp)
+        out['h.        (p2plane)'] = hl
+        out['h.,PSNR   (p2plane)'] = _psnr(peak, hl)
+    return out
+
+
 class Evaluator:
     def __init__(self):
         self.reset()
@@ -96,8 +167,12 @@ class PCCEvaluator(Evaluator):
     """`log` takes the original coordinates as a tensor (`org_xyz`) where the reference takes the path of a PLY file to
     hand to pc_error; everything else (arguments, info keys, '(mean)' aggregation of `show`) follows the reference."""
 
-    def __init__(self, cal_mpeg_pc_error: bool = True, cal_avs_pc_evalue: bool = False, mpeg_pc_error_processes: int = 8):
+    def __init__(self, cal_mpeg_pc_error: bool = True, cal_avs_pc_evalue: bool = False, mpeg_pc_error_processes: int = 8,
+                 p2plane: bool = True, hausdorff: bool = False):
         super().__init__()
+        # the reference's pc_error runs always get normals (the PLY's or Open3D's), so their result files carry the p2plane lines;
+        # it asks for --hausdorff=0 (lib/evaluators.py:98-104).  p2plane=False keeps the evaluation at the D1 lines
+        self.p2plane, self.hausdorff = p2plane, hausdorff
         if cal_mpeg_pc_error + cal_avs_pc_evalue != 1:
             raise ValueError('choose exactly one distortion definition')
         if cal_avs_pc_evalue:
@@ -111,7 +186,8 @@ class PCCEvaluator(Evaluator):
     def log(self, pred: torch.Tensor, org_points_num: int, compressed_bytes: bytes, file_path: str, resolution: float,
             results_dir: Optional[str] = None, pred_color: Optional[torch.Tensor] = None,
             pred_reflectance: Optional[torch.Tensor] = None, extra_info_dict: Optional[Dict] = None,
-            org_xyz: Optional[torch.Tensor] = None, org_color: Optional[torch.Tensor] = None) -> bool:
+            org_xyz: Optional[torch.Tensor] = None, org_color: Optional[torch.Tensor] = None,
+            org_normals: Optional[torch.Tensor] = None) -> bool:
         if pred.ndim != 2 or pred.shape[1] != 3:
             raise ValueError('pred must be [n, 3]')
         info = {'input_points_num': org_points_num, 'output_points_num': pred.shape[0],
@@ -124,7 +200,11 @@ class PCCEvaluator(Evaluator):
             with open(out_path + '.bin', 'wb') as f:
                 f.write(compressed_bytes)
         if org_xyz is not None and self.cal_mpeg_pc_error:
-            info.update(d1_metrics(org_xyz, pred, resolution, org_color, pred_color if org_color is not None else None))
+            rec_color = pred_color if org_color is not None else None
+            if self.p2plane or self.hausdorff:
+                info.update(pc_error_metrics(org_xyz, pred, resolution, org_color, rec_color, org_normals, self.hausdorff))
+            else:
+                info.update(d1_metrics(org_xyz, pred, resolution, org_color, rec_color))
         if file_path in self.file_path_to_info:
             print(f'Warning: Duplicated test sample {file_path}')
         self.file_path_to_info[file_path] = info

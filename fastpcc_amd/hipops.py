@@ -49,6 +49,12 @@ _SIGS = {
     'fpcc_nn_dist2': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_knn3d': (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     'fpcc_sum_i64': (_i32, [_vp, _i64, _vp, _vp]),
+    'fpcc_knn_voxels': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'fpcc_pca_normals': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
+    'fpcc_nn_plane_dist2': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'fpcc_transfer_normals_ws_bytes': (_i64, [_i64, _i64]),
+    'fpcc_transfer_normals': (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp]),
+    'fpcc_sum_max_f64': (_i32, [_vp, _i64, _vp, _vp, _i64, _vp]),
     'fpcc_transpose_weights_f32': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'fpcc_conv_wgrad_ws_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'fpcc_conv_wgrad_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _vp, _vp,
@@ -774,6 +780,64 @@ def knn3d(p1: torch.Tensor, p2: torch.Tensor, K: int, version: int = -1):
 def sum_i64(values: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.int64, device=values.device)
     _ok(lib().fpcc_sum_i64(_dev(values, torch.int64, 'values', values.numel() == 0), values.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def knn_voxels(keys: torch.Tensor, bits: int, query: torch.Tensor, k: int, start_level: int = 1):
+    """the k nearest voxels of every query row (batch, x, y, z) in the sorted key set, ordered by (squared distance, row):
+    (rows int32 [n, k], dist2 int64 [n, k]); -1 where the set holds fewer than k voxels"""
+    if query.dim() != 2 or query.shape[1] != 4:
+        raise ValueError('query must be int32 [n, 4] = (batch, x, y, z)')
+    n = query.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=query.device)
+    d = torch.empty((n, k), dtype=torch.int64, device=query.device)
+    _ok(lib().fpcc_knn_voxels(_dev(keys, torch.int64, 'keys', keys.numel() == 0), keys.shape[0], bits, _dev(query, torch.int32, 'query', n == 0),
+                              n, int(k), int(start_level), idx.data_ptr(), d.data_ptr(), _stream()))
+    return idx, d
+
+
+def pca_normals(keys: torch.Tensor, bits: int, nbr: torch.Tensor) -> torch.Tensor:
+    """unit normals float64 [n, 3] from the covariance of every point's neighbour rows `nbr` int32 [n, k] (fpcc_pca_normals)"""
+    n, k = nbr.shape
+    out = torch.empty((n, 3), dtype=torch.float64, device=nbr.device)
+    _ok(lib().fpcc_pca_normals(_dev(keys, torch.int64, 'keys'), keys.shape[0], bits, _dev(nbr, torch.int32, 'nbr', n == 0), n, k,
+                               out.data_ptr(), _stream()))
+    return out
+
+
+def nn_plane_dist2(keys: torch.Tensor, bits: int, normals: torch.Tensor, query: torch.Tensor):
+    """(point-to-plane squared error float64 [n], nearest squared distance int64 [n], nearest row int32 [n]) of every query against
+    the sorted key set whose rows carry `normals` float64 [m, 3]; ties at the nearest distance are averaged (fpcc_nn_plane_dist2)"""
+    n = query.shape[0]
+    plane = torch.empty(n, dtype=torch.float64, device=query.device)
+    d = torch.empty(n, dtype=torch.int64, device=query.device)
+    rows = torch.empty(n, dtype=torch.int32, device=query.device)
+    _ok(lib().fpcc_nn_plane_dist2(_dev(keys, torch.int64, 'keys', keys.numel() == 0), keys.shape[0], bits,
+                                  _dev(normals, torch.float64, 'normals', normals.numel() == 0), _dev(query, torch.int32, 'query', n == 0), n,
+                                  d.data_ptr(), rows.data_ptr(), plane.data_ptr(), _stream()))
+    return plane, d, rows
+
+
+def transfer_normals(keys_a: torch.Tensor, coords_a: torch.Tensor, normals_a: torch.Tensor, keys_b: torch.Tensor, coords_b: torch.Tensor,
+                     bits: int) -> torch.Tensor:
+    """pc_error's normals for cloud B from those of cloud A (fpcc_transfer_normals); coords_*: (batch, x, y, z) of keys_* in row order"""
+    n_a, n_b = keys_a.shape[0], keys_b.shape[0]
+    out = torch.empty((n_b, 3), dtype=torch.float64, device=keys_b.device)
+    L = lib()
+    need = _ok(L.fpcc_transfer_normals_ws_bytes(n_a, n_b))
+    ws = torch.empty(max(need // 8, 2), dtype=torch.int64, device=keys_b.device)
+    _ok(L.fpcc_transfer_normals(_dev(keys_a, torch.int64, 'keys_a', n_a == 0), n_a, _dev(coords_a, torch.int32, 'coords_a', n_a == 0),
+                                _dev(normals_a, torch.float64, 'normals_a', n_a == 0), _dev(keys_b, torch.int64, 'keys_b', n_b == 0), n_b,
+                                _dev(coords_b, torch.int32, 'coords_b', n_b == 0), bits, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()))
+    return out
+
+
+def sum_max_f64(values: torch.Tensor) -> torch.Tensor:
+    """float64 [2] = (sum, maximum) of a float64 vector, evaluated in a fixed order (fpcc_sum_max_f64)"""
+    n = values.numel()
+    out = torch.empty(2, dtype=torch.float64, device=values.device)
+    ws = torch.empty(max(2 * ((n + 4095) // 4096), 2), dtype=torch.float64, device=values.device)
+    _ok(lib().fpcc_sum_max_f64(_dev(values, torch.float64, 'values', n == 0), n, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()))
     return out
 
 

@@ -403,7 +403,10 @@ int fpcc_child_mask(const int32_t *child_row, int64_t m, uint8_t *mask_out, void
 
 /* Adaptive top-k pruning of Decoder.get_keep (models/convolutional/lossy_coord_v2/layers.py:151-180) for one sample:
  * logit[8*m] in (parent, octant) order; keep = logit > kth_smallest(non-local-max logits, 8m - target) OR local max.
- * A voxel is a local max when it equals the maximum over the 8 candidates of its parent.  keep_out uint8[8m]. */
+ * A voxel is a local max when it equals the maximum over the 8 candidates of its parent.  keep_out uint8[8m].
+ * The threshold is found by radix SELECT (three histogram passes over the logits, ~12 bytes read per candidate; rounds 1-5 sorted
+ * them all): an order statistic does not depend on how it is found, so the mask is unchanged.  ws (16-byte aligned): the size the
+ * call returns with ws == NULL. */
 int64_t fpcc_topk_keep(const float *logit, int64_t m, int64_t target, uint8_t *keep_out,
                        void *ws, int64_t ws_bytes, void *stream);
 
@@ -461,6 +464,35 @@ int fpcc_nn_dist2(const int64_t *keys, int64_t m, int bits, const int32_t *query
 int fpcc_knn3d(const float *p1, int64_t n1, const float *p2, int64_t n2, int k, int64_t *idx_out, float *dist2_out, void *stream);
 /* *sum_out (device) = sum of the non-negative entries; integer, so independent of the reduction order. */
 int fpcc_sum_i64(const int64_t *values, int64_t n, uint64_t *sum_out, void *stream);
+
+/* Point-to-plane (D2) and Hausdorff distortion -- what the reference obtains from `pc_error -a A -b B -n normals --hausdorff=1`
+ * (lib/metrics/pc_error_wrapper.py:40-76; the normals of A come from its PLY file or from Open3D's estimate_normals, :57-72).
+ * All clouds are SORTED unique Morton key sets (fpcc_keys_from_coords + fpcc_sort_keys); rows index those sorted sets; queries are
+ * int32 (batch, x, y, z) rows, 16-byte aligned.
+ *
+ * fpcc_knn_voxels: the k (1..32) nearest voxels of every query in the total order (squared distance, row) -- idx_out int32 [n][k]
+ *   (-1 where m < k), dist2_out int64 [n][k].  The search starts at block edge 2^start_level (a hint; any value gives the same result).
+ * fpcc_pca_normals: one unit normal per point (double [n][3]) = the eigenvector of the smallest eigenvalue of the covariance of its
+ *   k neighbours `nbr` int32 [n][k] (rows of `keys`, negative = absent), closed-form symmetric 3x3 eigen-decomposition; sign chosen so
+ *   that n . (1, sqrt 2, sqrt 5) > 0; (0, 0, 1) where fewer than 3 neighbours or a vanishing covariance (Open3D's rule).
+ * fpcc_nn_plane_dist2: per query, over ALL voxels j at the minimum distance (pc_error's neighbours "at the same distance"):
+ *   plane_out[i] = mean_j ((q_i - p_j) . normals[j])^2, dist2_out[i] = that minimum (int64, optional), nn_row_out[i] = the first such
+ *   row (optional).  normals: double [m][3] in row order (NULL: plane_out = 0); rows whose normal is NaN are skipped.
+ * fpcc_transfer_normals: pc_error's normals for the second cloud B from those of A: every point of A adds its normal to its nearest
+ *   voxel of B (first row among ties); a voxel of B that received c > 0 normals takes their mean, every other voxel the mean normal
+ *   of its own nearest voxels of A.  coords_a / coords_b: the voxels of keys_a / keys_b in row order.  Sums in 2^-40 fixed point: independent of the order of the atomics.  ws: caller-owned,
+ *   16-byte aligned, fpcc_transfer_normals_ws_bytes(n_a, n_b) bytes.
+ * fpcc_sum_max_f64: sum_max_out[0] = sum, [1] = maximum of `values` in a fixed order (slices of 4096, fixed tree, slices added in
+ *   ascending order): a function of the data alone.  ws: 16 bytes per 4096 values. */
+int fpcc_knn_voxels(const int64_t *keys, int64_t m, int bits, const int32_t *query, int64_t n, int k, int start_level, int32_t *idx_out,
+                    int64_t *dist2_out, void *stream);
+int fpcc_pca_normals(const int64_t *keys, int64_t m, int bits, const int32_t *nbr, int64_t n, int k, double *normals_out, void *stream);
+int fpcc_nn_plane_dist2(const int64_t *keys, int64_t m, int bits, const double *normals, const int32_t *query, int64_t n,
+                        int64_t *dist2_out, int32_t *nn_row_out, double *plane_out, void *stream);
+int64_t fpcc_transfer_normals_ws_bytes(int64_t n_a, int64_t n_b);
+int fpcc_transfer_normals(const int64_t *keys_a, int64_t n_a, const int32_t *coords_a, const double *normals_a, const int64_t *keys_b,
+                          int64_t n_b, const int32_t *coords_b, int bits, double *normals_b_out, void *ws, int64_t ws_bytes, void *stream);
+int fpcc_sum_max_f64(const double *values, int64_t n, double *sum_max_out, void *ws, int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Integer-only pipeline (lossl_coord_int).  Replaces the pybind module `int_sparse_conv_ext`                      */

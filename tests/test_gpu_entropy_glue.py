@@ -84,3 +84,38 @@ def test_topk_keep_with_ties(ops):
     for target in (3, 5, 9, 15):          # at least the three local maxima are always kept
         got = ops.topk_keep(torch.from_numpy(v).cuda(), target).cpu().numpy().astype(bool)
         assert (got == _keep_reference(v, target)).all()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_topk_keep_select_on_heavy_ties_and_every_sign(ops, seed):
+    """the radix select behind fpcc_topk_keep: coarsely quantised logits (thousands of equal keys per bin, both signs, +-0, values that
+    differ in the LAST key bits only) must give the mask of a full sort for any target, including 'keep everything'"""
+    rng = np.random.default_rng(seed)
+    m = 30000
+    base = rng.normal(size=8 * m).astype(np.float32)
+    v = [np.round(base * 4) / 4, np.where(rng.random(8 * m) < 0.5, np.float32(-0.0), np.float32(0.0)) + np.round(base),
+         (np.float32(1.0) + rng.integers(0, 7, 8 * m).astype(np.float32) * np.float32(2.0 ** -23)) * np.sign(base)][seed].astype(np.float32)
+    for target in (m, 8 * m // 3, 8 * m - 5, 8 * m):
+        got = ops.topk_keep(torch.from_numpy(v).cuda(), target).cpu().numpy().astype(bool)
+        if target == 8 * m:
+            assert got.all()
+        else:
+            assert (got == _keep_reference(v, target)).all(), target
+
+
+def test_topk_keep_cells_select_matches_a_sort(ops):
+    """fpcc_topk_keep_cells: cells of several candidate groups; threshold = the (8m - target)-th smallest of the candidates that are not
+    their cell's maximum"""
+    rng = np.random.default_rng(7)
+    m, n_cells = 20000, 2500
+    v = np.round(rng.normal(size=8 * m) * 8).astype(np.float32) / 8
+    cell = np.sort(rng.integers(0, n_cells, m)).astype(np.int32)
+    cell_max = np.full(n_cells, -np.inf, np.float32)
+    np.maximum.at(cell_max, np.repeat(cell, 8), v)
+    is_max = v == cell_max[np.repeat(cell, 8)]
+    for target in (m, 3 * m, 8 * m - 1):
+        ranked = np.sort(np.where(is_max, np.inf, v))
+        thr = ranked[8 * m - target - 1]
+        want = (v > thr) | is_max
+        got = ops.topk_keep_cells(torch.from_numpy(v).cuda(), torch.from_numpy(cell).cuda(), n_cells, target).cpu().numpy().astype(bool)
+        assert (got == want).all(), target

@@ -106,3 +106,46 @@ def test_d1_known_answers():
     rng = np.random.default_rng(0)
     q, p = rng.integers(0, 50, (300, 3)), rng.integers(0, 50, (200, 3))
     assert (om.nn_dist2(q, p)[0] == om.brute_nn_dist2(q, p)).all()
+
+
+def test_d2_and_hausdorff_known_answers():
+    """hand-derived point-to-plane / Hausdorff values of oracle.metrics.d2 (pc_error's definitions with normals):
+    (1) the plane z = 3 against z = 4: every error vector is the unit normal -> p2point = p2plane = h. = 1;
+    (2) the same plane slid by one voxel inside itself: the border column is 1 away, but along the plane -> p2plane 0, h.(p2point) 1;
+    (3) given normals: A = {0} with n = (0.6, 0.8, 0), B = {(5, 0, 0)}: p2point 25, both plane errors (5 * 0.6)^2 = 9;
+    (4) a tie: A = {0}, n = (1, 0, 0); B = {(1,0,0), (0,1,0)} both at distance 1 -> A->B averages the projections 1 and 0 = 0.5; the first
+        of B in Morton order receives A's normal, the other takes it from its nearest voxel of A: B->A = (1 + 0) / 2."""
+    from oracle import metrics as om
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), indexing='ij'), -1).reshape(-1, 2)
+    a = np.concatenate([g, np.full((len(g), 1), 3)], 1)
+    r = om.d2(a, a + np.array([0, 0, 1]), 64, knn=9)
+    for key in ('mse1      (p2plane)', 'mse2      (p2plane)', 'mseF      (p2plane)', 'h.        (p2point)', 'h.        (p2plane)'):
+        assert r[key] == pytest.approx(1.0, abs=1e-12), key
+    assert r['mseF,PSNR (p2plane)'] == pytest.approx(10 * np.log10(3 * 63 ** 2), rel=1e-12)
+    r = om.d2(a, a + np.array([1, 0, 0]), 64, knn=9)
+    assert r['mseF      (p2plane)'] == pytest.approx(0.0, abs=1e-12) and r['h.        (p2plane)'] == pytest.approx(0.0, abs=1e-12)
+    assert r['h.        (p2point)'] == 1.0 and r['h.,PSNR   (p2plane)'] == float('inf')
+    r = om.d2(np.array([[0, 0, 0]]), np.array([[5, 0, 0]]), 16, org_normals=np.array([[0.6, 0.8, 0.0]]))
+    assert r['mse1      (p2plane)'] == pytest.approx(9.0, rel=1e-12) and r['mse2      (p2plane)'] == pytest.approx(9.0, rel=1e-12)
+    assert r['h.       1(p2point)'] == 25.0 and r['h.       2(p2plane)'] == pytest.approx(9.0, rel=1e-12)
+    r = om.d2(np.array([[0, 0, 0]]), np.array([[0, 1, 0], [1, 0, 0]]), 16, org_normals=np.array([[1.0, 0.0, 0.0]]))
+    assert r['mse1      (p2plane)'] == pytest.approx(0.5, rel=1e-12) and r['mse2      (p2plane)'] == pytest.approx(0.5, rel=1e-12)
+    assert r['h.        (p2plane)'] == pytest.approx(1.0, rel=1e-12) and r['h.        (p2point)'] == 1.0
+
+
+def test_pca_normals_of_the_oracle_on_a_sphere():
+    """voxelised sphere of radius 20: PCA normals over 30 neighbours point along the radius (within the voxelisation's few degrees),
+    with the sign rule n . (1, sqrt 2, sqrt 5) > 0; a concentric sphere of radius 21 is ~1 away along them"""
+    from oracle import metrics as om
+    g = np.stack(np.meshgrid(*(np.arange(-24, 25),) * 3, indexing='ij'), -1).reshape(-1, 3)
+    r = np.sqrt((g ** 2).sum(1))
+    shell = g[np.abs(r - 20) < 0.5] + 24
+    order = om.morton_rows(shell)
+    pts = shell[order]
+    n = om.pca_normals(pts, om.knn_rows(pts, pts, 30)[0])
+    radial = (pts - 24) / np.linalg.norm(pts - 24, axis=1, keepdims=True)
+    assert (np.abs((n * radial).sum(1)) > 0.97).all()
+    assert (n @ np.array([1.0, np.sqrt(2.0), np.sqrt(5.0)]) > 0).all()
+    outer = g[np.abs(r - 21) < 0.5] + 24
+    res = om.d2(shell, outer, 64)
+    assert 0.6 < res['mseF      (p2plane)'] < 1.4 and res['mseF      (p2plane)'] <= om.d1(shell, outer, 64)['mseF      (p2point)'] + 1e-9
