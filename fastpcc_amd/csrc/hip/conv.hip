@@ -1321,34 +1321,81 @@ int launch_pointwise(const ConvArgs &a, const float *wp, hipStream_t s) {
 // 3x3x3 convolution of a CONSTANT-ONE one-channel input (the codec's first layer: every voxel carries the feature 1): the sum
 // over the neighbours that exist of w[k][j], in ascending offset order -- the same chain the general kernel evaluates with
 // x = 1 (fmaf(1, w, acc) == acc + w), so the result is bit-identical -- read from the row's 27-bit presence mask instead of
-// the 108-byte neighbour row.  One thread per (row, 4 output columns); weights through LDS.
+// the 108-byte neighbour row.
+// Round 6: a thread owns CPT (8 or 4) output columns of a row and keeps their 27 x CPT weights in REGISTERS for all the rows it walks;
+// an absent neighbour contributes fmaf(0, w, acc) == acc (acc is never -0: it starts at +0 and a sum that cancels is +0), so there is
+// no divergent branch: per row 27 mask-bit -> {0, 1} conversions (two integer instructions each) and 27 x CPT / 2 packed FMAs
+// (v_pk_fma_f32 with the bit broadcast through op_sel).  4 bytes read and 4 c_out bytes written per row: HBM-bound
+// (rounds 2-5: one thread per (row, 4 columns) re-reading the weights from LDS per row behind 27 exec-mask branches, 24 % of 8 TB/s).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int CPT>
 __global__ __launch_bounds__(256) void k_conv_ones_k3(const uint32_t *__restrict__ masks, int64_t n, const float *__restrict__ w,
                                                       const float *__restrict__ bias, int c_out, int act,
-                                                      const float *__restrict__ slope, float clip, float *__restrict__ out, int ldo) {
-    __shared__ float s_w[27 * 32];
-    for (int e = threadIdx.x; e < 27 * c_out; e += 256) s_w[e] = w[e];
+                                                      const float *__restrict__ slope, float clip, float *__restrict__ out, int ldo,
+                                                      int rows_per_block) {
+    __shared__ f32x4 s_w[27 * 8];
+    for (int e = threadIdx.x; e < 27 * c_out / 4; e += 256) s_w[e] = reinterpret_cast<const f32x4 *>(w)[e];
     __syncthreads();
-    const int q4 = c_out / 4;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n * q4) return;
-    const int64_t o = e / q4;
-    const int j0 = 4 * (int)(e - o * q4);
-    const uint32_t m = masks[o];
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const int tpr = c_out / CPT;                          // threads per row
+    const int q = threadIdx.x % tpr, slot = threadIdx.x / tpr, slots = 256 / tpr;
+    if (slot >= slots) return;                            // (c_out / CPT does not divide 256: the spare threads rest)
+    const int j0 = q * CPT;
+    f32x2_t wk[27][CPT / 2];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        if (m >> k & 1u) {
-            const float *wk = s_w + k * c_out + j0;
-            a0 = fmaf(1.0f, wk[0], a0); a1 = fmaf(1.0f, wk[1], a1); a2 = fmaf(1.0f, wk[2], a2); a3 = fmaf(1.0f, wk[3], a3);
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+        for (int h = 0; h < CPT / 4; ++h) {
+            const f32x4 t = s_w[(k * c_out + j0) / 4 + h];
+            wk[k][2 * h] = {t.x, t.y};
+            wk[k][2 * h + 1] = {t.z, t.w};
+        }
+    float bj[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) bj[j] = bias ? bias[j0 + j] : 0.0f;
+    const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    // software pipeline of depth 4: the masks of the next four rows of this thread are in flight while the current four are summed
+    // (one row's chain is ~700 cycles of packed FMAs, a load from HBM under load ~2 us, and the registers allow 1-2 waves per SIMD)
+    uint32_t nxt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int64_t ri = r0 + slot + (int64_t)i * slots; nxt[i] = ri < r1 ? masks[ri] : 0u; }
+    for (int64_t r = r0 + slot; r < r1; r += 4 * slots) {
+        uint32_t cur[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cur[i] = nxt[i];
+            const int64_t ri = r + (int64_t)(4 + i) * slots;
+            nxt[i] = ri < r1 ? masks[ri] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t ri = r + (int64_t)i * slots;
+            if (ri >= r1) break;
+            const uint32_t m = cur[i];
+            f32x2_t acc[CPT / 2];
+#pragma unroll
+            for (int h = 0; h < CPT / 2; ++h) acc[h] = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                // bit k -> 0.0f / 1.0f: sign-extend the bit to 0 / ~0 and keep the bits of 1.0f
+                const float bit = __int_as_float((((int32_t)(m << (31 - k))) >> 31) & 0x3f800000);
+                const f32x2_t bb = {bit, bit};
+#pragma unroll
+                for (int h = 0; h < CPT / 2; ++h) acc[h] = __builtin_elementwise_fma(bb, wk[k][h], acc[h]);
+            }
+            float *dst = out + ri * ldo + j0;
+#pragma unroll
+            for (int h = 0; h < CPT / 4; ++h) {
+                f32x4 o;
+                o.x = finish(acc[2 * h].x, bj[4 * h], act, sl, clip);
+                o.y = finish(acc[2 * h].y, bj[4 * h + 1], act, sl, clip);
+                o.z = finish(acc[2 * h + 1].x, bj[4 * h + 2], act, sl, clip);
+                o.w = finish(acc[2 * h + 1].y, bj[4 * h + 3], act, sl, clip);
+                reinterpret_cast<f32x4 *>(dst)[h] = o;
+            }
         }
     }
-    const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
-    f32x4 r;
-    r.x = finish(a0, bias ? bias[j0] : 0.0f, act, sl, clip);
-    r.y = finish(a1, bias ? bias[j0 + 1] : 0.0f, act, sl, clip);
-    r.z = finish(a2, bias ? bias[j0 + 2] : 0.0f, act, sl, clip);
-    r.w = finish(a3, bias ? bias[j0 + 3] : 0.0f, act, sl, clip);
-    *reinterpret_cast<f32x4 *>(out + o * ldo + j0) = r;
 }
 
 template <int JB>
@@ -1392,8 +1439,18 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
     if (n == 0) return FPCC_OK;
     if (!masks || !w || !out || !aligned16(out)) return fail_arg("conv_ones_k3: null or unaligned pointer");
     if (act == FPCC_ACT_PRELU && !slope) return fail_arg("conv_ones_k3: PReLU needs a slope pointer");
-    hipLaunchKernelGGL(k_conv_ones_k3, dim3(blocks_for(n * (c_out / 4), 256)), dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out,
-                       act, slope, clip, out, ldo);
+    // >= ~2048 workgroups where the map allows it, each walking a contiguous slice of rows (whole passes of its 256 threads)
+    static const int cpt_env = [] { const char *e = getenv("FPCC_ONES_CPT"); return e ? atoi(e) : 0; }();     // A/B of the two forms
+    const int cpt = (c_out % 8 == 0 && cpt_env != 4) ? 8 : 4;
+    const int slots = 256 / (c_out / cpt);
+    int64_t rpb = (n + 2047) / 2048;
+    rpb = (rpb + slots - 1) / slots * slots;
+    rpb = rpb < slots ? slots : (rpb > 8192 ? 8192 : rpb);
+    const dim3 grid(blocks_for(n, (int)rpb));
+    if (cpt == 8)
+        hipLaunchKernelGGL(k_conv_ones_k3<8>, grid, dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out, act, slope, clip, out, ldo, (int)rpb);
+    else
+        hipLaunchKernelGGL(k_conv_ones_k3<4>, grid, dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out, act, slope, clip, out, ldo, (int)rpb);
     return check_hip(hipGetLastError(), "k_conv_ones_k3");
 }
 
@@ -1553,6 +1610,27 @@ __global__ void k_conv_row_keys(const int32_t *__restrict__ nbr, int n_off, int6
     keys[o] = ((o >> window_log2) << 32) | (int64_t)m;
 }
 
+// the same keys from the rows' presence masks (written by the table's producer: fpcc_nbr27_from_parent_ex) -- 4 bytes read per row
+// instead of the row's 27 table entries
+__global__ void k_conv_row_keys_masks(const uint32_t *__restrict__ masks, int64_t n, int window_log2, int64_t *__restrict__ keys) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    uint32_t m = masks[o];
+    m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
+    keys[o] = ((o >> window_log2) << 32) | (int64_t)m;
+}
+
+// rows of a row-major table in position order: out[p] = rows[order[p]], whole 16-byte pieces (ld / 4 per row): eight consecutive lanes
+// move one 128-byte line, a wave's loads are eight scattered lines, its stores 1 KB contiguous
+__global__ __launch_bounds__(256) void k_gather_table_rows(const int4 *__restrict__ rows, const int32_t *__restrict__ order, int64_t n,
+                                                           int pieces, int4 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * pieces) return;
+    const int64_t p = e / pieces;
+    const int j = (int)(e - p * pieces);
+    out[e] = rows[(int64_t)order[p] * pieces + j];
+}
+
 // one wave per group of `group` (<= 64) consecutive positions of row_order: key = (offsets the group lacks) << 32 | group
 __global__ __launch_bounds__(256) void k_conv_tile_keys(const uint32_t *__restrict__ row_masks, int n_off,
                                                         const int32_t *__restrict__ row_order, int64_t n, int group,
@@ -1664,6 +1742,23 @@ extern "C" int fpcc_conv_regroup_rows(const int32_t *row_order, const int32_t *g
     hipLaunchKernelGGL(k_conv_regroup_rows, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), row_order, group_perm, n,
                        group, n / group, row_order_out);
     return check_hip(hipGetLastError(), "k_conv_regroup_rows");
+}
+
+extern "C" int fpcc_conv_row_keys_masks(const uint32_t *masks, int64_t n, int window_log2, int64_t *keys_out, void *stream) {
+    if (n < 0 || window_log2 < 5 || window_log2 > 31) return fail_arg("conv_row_keys_masks: bad sizes");
+    if (n == 0) return FPCC_OK;
+    if (!masks || !keys_out) return fail_arg("conv_row_keys_masks: null pointer");
+    hipLaunchKernelGGL(k_conv_row_keys_masks, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), masks, n, window_log2, keys_out);
+    return check_hip(hipGetLastError(), "k_conv_row_keys_masks");
+}
+
+extern "C" int fpcc_gather_table_rows_i32(const int32_t *rows, int ld, const int32_t *order, int64_t n, int32_t *out, void *stream) {
+    if (n < 0 || ld < 4 || ld % 4) return fail_arg("gather_table_rows: ld must be a positive multiple of 4");
+    if (n == 0) return FPCC_OK;
+    if (!rows || !order || !out || !aligned16(rows) || !aligned16(out)) return fail_arg("gather_table_rows: null or unaligned pointer");
+    hipLaunchKernelGGL(k_gather_table_rows, dim3(blocks_for(n * (ld / 4), 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const int4 *>(rows), order, n, ld / 4, reinterpret_cast<int4 *>(out));
+    return check_hip(hipGetLastError(), "k_gather_table_rows");
 }
 
 extern "C" int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n,

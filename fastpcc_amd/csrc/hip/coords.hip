@@ -140,17 +140,22 @@ __global__ void k_coarsen_scatter(const int64_t *__restrict__ keys, int64_t n, c
     const int32_t p = pos[i] - 1;
     parent_of[i] = p;
     if (flag[i]) {
-        // first child of its parent: siblings are the following rows (at most 8, sorted by octant)
-        const int64_t pk = keys[i] >> 3;
+        // first child of its parent: siblings are the following rows (at most 8, sorted by octant).  All eight candidate keys are
+        // requested at once (round 6; a loop that stopped at the first foreign key made up to eight DEPENDENT loads of it)
+        int64_t kj[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) kj[t] = keys[i + t < n ? i + t : n - 1];
+        const int64_t pk = kj[0] >> 3;
         int32_t rows[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) rows[k] = -1;
-        for (int64_t j = i; j < n && j < i + 8; ++j) {
-            const int64_t kj = keys[j];
-            if ((kj >> 3) != pk) break;
-            const int oct = (int)(kj & 7);
+        bool mine = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (k == oct) rows[k] = (int32_t)j;   // static indexing keeps rows[] in registers
+        for (int t = 0; t < 8; ++t) {
+            mine = mine && i + t < n && (kj[t] >> 3) == pk;
+            const int oct = (int)(kj[t] & 7);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (mine && k == oct) rows[k] = (int32_t)(i + t);   // static indexing keeps rows[] in registers
         }
         pkeys[p] = pk;
         int4 *dst = reinterpret_cast<int4 *>(child_row + (int64_t)p * 8);
@@ -214,20 +219,39 @@ struct ByteToInt {
     __host__ __device__ int32_t operator()(uint8_t b) const { return b ? 1 : 0; }
 };
 
+// one thread per PARENT (round 6; was one per candidate): its 8 mask bytes as one load, its 8 scan values as two 16-byte loads, its
+// child_row row as two 16-byte stores; keys and parent rows of the kept children go to consecutive output rows
+template <bool MASK_ALIGNED>
 __global__ void k_refine_scatter(const int64_t *__restrict__ pkeys, int64_t n_cand, const uint8_t *__restrict__ mask,
                                  const int32_t *__restrict__ pos, int64_t *__restrict__ keys_out,
                                  int32_t *__restrict__ parent_of, int32_t *__restrict__ child_row,
                                  int32_t *__restrict__ count) {
-    int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
-    int32_t row = -1;
-    if (mask[c]) {
-        row = pos[c] - 1;
-        keys_out[row] = (pkeys[c >> 3] << 3) | (c & 7);
-        parent_of[row] = (int32_t)(c >> 3);
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (8 * p >= n_cand) return;
+    uint64_t mk = 0;
+    if (MASK_ALIGNED) {
+        mk = reinterpret_cast<const uint64_t *>(mask)[p];
+    } else {                                              // a mask that starts inside another tensor at an odd byte
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mk |= (uint64_t)mask[8 * p + k] << (8 * k);
     }
-    child_row[c] = row;
-    if (c == n_cand - 1) count[0] = pos[c];
+    const int4 lo = reinterpret_cast<const int4 *>(pos)[2 * p], hi = reinterpret_cast<const int4 *>(pos)[2 * p + 1];
+    const int32_t ps[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const int64_t pk = pkeys[p] << 3;
+    int32_t rows[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        rows[k] = -1;
+        if ((mk >> (8 * k)) & 0xffull) {
+            rows[k] = ps[k] - 1;
+            keys_out[rows[k]] = pk | k;
+            parent_of[rows[k]] = (int32_t)p;
+        }
+    }
+    int4 *dst = reinterpret_cast<int4 *>(child_row + 8 * p);
+    dst[0] = make_int4(rows[0], rows[1], rows[2], rows[3]);
+    dst[1] = make_int4(rows[4], rows[5], rows[6], rows[7]);
+    if (8 * p + 8 == n_cand) count[0] = ps[7];
 }
 
 __global__ void k_compact_coords(const int64_t *__restrict__ pkeys, int64_t n_cand, const uint8_t *__restrict__ mask,
@@ -276,10 +300,14 @@ __global__ void k_nbr27_search(const int64_t *__restrict__ keys, int64_t n, int 
 
 // MASK_ONLY: instead of the 27 neighbour rows, one word per row with bit d set where neighbour d exists (all a convolution of
 // a constant input needs): 4 bytes written per row instead of 108
+// rows_out (table form only, may be NULL): the same entries once more ROW-MAJOR, [n][32] with entries 27 .. 31 = -1 -- the layout
+// the MFMA kernels' prologue reads (a row = one 128-byte line); every thread writes its own line as eight 16-byte pieces straight
+// from its column of the LDS tile (round 6: was a separate transposition pass over the finished table, 236 bytes per row).
+// masks_out (table form only, may be NULL): bit d of word i set where neighbour d of row i exists -- what the row-order keys need.
 template <bool MASK_ONLY>
 __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
                                     const int32_t *__restrict__ pnbr, int64_t m, const int32_t *__restrict__ child_row,
-                                    int32_t *__restrict__ nbr) {
+                                    int32_t *__restrict__ nbr, int32_t *__restrict__ rows_out, uint32_t *__restrict__ masks_out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int oct = keys ? (int)(keys[i] & 7) : (int)(i & 7);   // keys == NULL: generated set, row = 8*parent + octant
@@ -319,14 +347,27 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
             const int dx = 2 * px + (c & 1) - ox, dy = 2 * py + ((c >> 1) & 1) - oy, dz = 2 * pz + (c >> 2) - oz;
             if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
             const int d = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
-            if (MASK_ONLY) bits |= (uint32_t)(kid[c] >= 0) << d;
-            else mine[d * kThreads] = kid[c];
+            bits |= (uint32_t)(kid[c] >= 0) << d;
+            if (!MASK_ONLY) mine[d * kThreads] = kid[c];
         }
     }
     if (!MASK_ONLY) {
         // own column of the tile only: no barrier needed
 #pragma unroll
         for (int d = 0; d < 27; ++d) nbr[(int64_t)d * n + i] = mine[d * kThreads];
+        if (rows_out) {
+            int4 *dst = reinterpret_cast<int4 *>(rows_out + i * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int4 v;                                               // (d is a compile-time constant after unrolling)
+                v.x = 4 * j < 27 ? mine[(4 * j < 27 ? 4 * j : 0) * kThreads] : -1;
+                v.y = 4 * j + 1 < 27 ? mine[(4 * j + 1 < 27 ? 4 * j + 1 : 0) * kThreads] : -1;
+                v.z = 4 * j + 2 < 27 ? mine[(4 * j + 2 < 27 ? 4 * j + 2 : 0) * kThreads] : -1;
+                v.w = 4 * j + 3 < 27 ? mine[(4 * j + 3 < 27 ? 4 * j + 3 : 0) * kThreads] : -1;
+                dst[j] = v;
+            }
+        }
+        if (masks_out) masks_out[i] = bits;
     }
     if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }
@@ -693,8 +734,13 @@ extern "C" int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *m
     void *tmp = static_cast<char *>(ws) + arr;
     size_t tb = (size_t)tmp_bytes;
     FPCC_HIP(rocprim::inclusive_scan(tmp, tb, in, pos, (size_t)n_cand, rocprim::plus<int32_t>(), as_stream(stream)));
-    hipLaunchKernelGGL(k_refine_scatter, dim3(blocks_for(n_cand, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
-                       n_cand, mask, (const int32_t *)pos, keys_out, parent_of, child_row, count_out);
+    if (reinterpret_cast<uintptr_t>(child_row) & 15) return fail_arg("refine: child_row must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(mask) & 7)
+        hipLaunchKernelGGL(k_refine_scatter<false>, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
+                           n_cand, mask, (const int32_t *)pos, keys_out, parent_of, child_row, count_out);
+    else
+        hipLaunchKernelGGL(k_refine_scatter<true>, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, as_stream(stream), pkeys,
+                           n_cand, mask, (const int32_t *)pos, keys_out, parent_of, child_row, count_out);
     FPCC_LAUNCHED(k_refine_scatter);
     return FPCC_OK;
 }
@@ -744,7 +790,21 @@ extern "C" int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent
         return fail_arg("nbr27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (n == 0) return FPCC_OK;
     hipLaunchKernelGGL(k_nbr27_from_parent<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
-                       parent_of, n, parent_nbr, m, child_row, nbr);
+                       parent_of, n, parent_nbr, m, child_row, nbr, (int32_t *)nullptr, (uint32_t *)nullptr);
+    FPCC_LAUNCHED(k_nbr27_from_parent);
+    return FPCC_OK;
+}
+
+extern "C" int fpcc_nbr27_from_parent_ex(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr, int64_t m,
+                                         const int32_t *child_row, int32_t *nbr, int32_t *rows_out, uint32_t *masks_out, void *stream) {
+    if (n < 0 || m < 0 || (n > 0 && (!parent_nbr || !nbr))) return fail_arg("nbr27_from_parent_ex: null pointer");
+    if (!keys && (parent_of || child_row)) return fail_arg("nbr27_from_parent_ex: keys may only be omitted for a full generated set");
+    if (!parent_of && !(child_row == nullptr && n == 8 * m))
+        return fail_arg("nbr27_from_parent_ex: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
+    if (rows_out && (reinterpret_cast<uintptr_t>(rows_out) & 15)) return fail_arg("nbr27_from_parent_ex: rows_out must be 16-byte aligned");
+    if (n == 0) return FPCC_OK;
+    hipLaunchKernelGGL(k_nbr27_from_parent<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+                       parent_of, n, parent_nbr, m, child_row, nbr, rows_out, masks_out);
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
 }
@@ -757,7 +817,7 @@ extern "C" int fpcc_mask27_from_parent(const int64_t *keys, const int32_t *paren
         return fail_arg("mask27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (n == 0) return FPCC_OK;
     hipLaunchKernelGGL(k_nbr27_from_parent<true>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
-                       parent_of, n, parent_nbr, m, child_row, reinterpret_cast<int32_t *>(masks_out));
+                       parent_of, n, parent_nbr, m, child_row, reinterpret_cast<int32_t *>(masks_out), (int32_t *)nullptr, (uint32_t *)nullptr);
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
 }

@@ -327,12 +327,25 @@ class CoordinateManager:
         """[27, n] int32 input row per (offset, output row) of the 3x3x3 kernel on m, offsets x fastest, -1 = absent."""
         if m.nbr27 is None:
             if m.generated:
-                m.nbr27 = ops.nbr27_from_parent(None, None, self._nbr27(m.parent), None, n=m.n)
+                if self.NBR_ROWS and m.n > self.ROW_ORDER_MIN_ROWS and m.nbr27_rows is None and m.nbr27_pos is None:
+                    m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(None, None, self._nbr27(m.parent), None, n=m.n)
+                    if m.mask27 is None:
+                        m.mask27 = masks
+                else:
+                    m.nbr27 = ops.nbr27_from_parent(None, None, self._nbr27(m.parent), None, n=m.n)
             else:
                 if m.parent is None and m.n > self.ROOT_ROWS and m.bits > 1:
                     self._ensure_parent(m)
                 if m.parent is not None:
-                    m.nbr27 = ops.nbr27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+                    if self.NBR_ROWS and m.n > self.ROW_ORDER_MIN_ROWS and m.nbr27_rows is None and m.nbr27_pos is None:
+                        # a map this large runs its 3x3x3 layers in pattern order, which reads the table row-major and needs the rows'
+                        # presence masks for the order: both come out of the producer's pass (round 6; was a transposition pass
+                        # and a pass of 27 reads per row)
+                        m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+                        if m.mask27 is None:
+                            m.mask27 = masks
+                    else:
+                        m.nbr27 = ops.nbr27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
                 else:
                     m.nbr27 = ops.nbr27_search(m.keys, m.bits)
         return m.nbr27
@@ -360,7 +373,7 @@ class CoordinateManager:
         if row_order is not m.row_order:
             raise ValueError('a foreign row order')
         if m.nbr27_pos is None:
-            m.nbr27_pos = rows.index_select(0, row_order.long())              # 128-byte rows: one gather per map
+            m.nbr27_pos = ops.gather_table_rows(rows, row_order)              # 128-byte rows: one gather per map
             m.nbr27_rows = None                                              # only the position-ordered copy is read from here on
         return dict(nbr=m.nbr27_pos, n_offsets=27, nbr_ks=1, nbr_os=32)
 
@@ -389,7 +402,11 @@ class CoordinateManager:
         if m.row_order is False or (m.row_order is None and training and m.n > self.ROW_ORDER_MIN_ROWS_TRAINING):
             m.row_order = None
             if m.n > (self.ROW_ORDER_MIN_ROWS_TRAINING if training else self.ROW_ORDER_MIN_ROWS):
-                m.row_order = ops.conv_row_order(self._nbr27(m), 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2)
+                nbr = self._nbr27(m)
+                # the masks of a table made by nbr27_from_parent_ex describe exactly that table (a mask derived earlier from the parent
+                # level does too: same rule); without them the keys are read off the table
+                m.row_order = ops.conv_row_order(nbr, 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2,
+                                                 masks=m.mask27 if m.nbr27_rows is not None else None)
         return m.row_order
 
     def get_coordinates(self, key: CoordinateMapKey) -> torch.Tensor:

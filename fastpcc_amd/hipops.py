@@ -32,6 +32,9 @@ _SIGS = {
     'fpcc_refine': (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'fpcc_nbr27_search': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'fpcc_nbr27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'fpcc_nbr27_from_parent_ex': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'fpcc_conv_row_keys_masks': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'fpcc_gather_table_rows_i32': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'fpcc_mask27_from_parent': (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     'fpcc_conv_ones_k3_f32': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, C.c_float, _vp, _i32, _vp]),
     'fpcc_conv_f32': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _i32,
@@ -403,6 +406,31 @@ def nbr27_from_parent(keys: Optional[torch.Tensor], parent_of: Optional[torch.Te
                                      n, _dev(parent_nbr, torch.int32, 'parent_nbr'), m,
                                      _dev(child_row, torch.int32, 'child_row', True), nbr.data_ptr(), _stream()))
     return nbr
+
+
+def nbr27_from_parent_ex(keys: Optional[torch.Tensor], parent_of: Optional[torch.Tensor], parent_nbr: torch.Tensor,
+                         child_row: Optional[torch.Tensor], n: Optional[int] = None):
+    """nbr27_from_parent plus, from the same pass, the table row-major [n, 32] and the rows' 27-bit presence masks:
+    -> (nbr [27, n], rows [n, 32], masks int32 [n])"""
+    m = parent_nbr.shape[1]
+    n = (8 * m if n is None else n) if keys is None else keys.shape[0]
+    dev = parent_nbr.device
+    nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
+    rows = torch.empty((n, 32), dtype=torch.int32, device=dev)
+    masks = torch.empty(n, dtype=torch.int32, device=dev)
+    _ok(lib().fpcc_nbr27_from_parent_ex(_dev(keys, torch.int64, 'keys', True), _dev(parent_of, torch.int32, 'parent_of', True),
+                                        n, _dev(parent_nbr, torch.int32, 'parent_nbr'), m,
+                                        _dev(child_row, torch.int32, 'child_row', True), nbr.data_ptr(), rows.data_ptr(),
+                                        masks.data_ptr(), _stream()))
+    return nbr, rows, masks
+
+
+def gather_table_rows(rows: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
+    """rows[order] of a row-major int32 table [n, ld] (ld % 4 == 0) as one launch of whole 16-byte pieces"""
+    n, ld = rows.shape
+    out = torch.empty_like(rows)
+    _ok(lib().fpcc_gather_table_rows_i32(_dev(rows, torch.int32, 'rows'), ld, _dev(order, torch.int32, 'order'), n, out.data_ptr(), _stream()))
+    return out
 
 
 def mask27_from_parent(keys: Optional[torch.Tensor], parent_of: Optional[torch.Tensor], parent_nbr: torch.Tensor,
@@ -936,26 +964,30 @@ def noisy_normal_bits(y: torch.Tensor, index: torch.Tensor, log_scale_offset: fl
     return out[0], dy, di
 
 
-def conv_row_order(nbr: torch.Tensor, n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13,
-                   heaviest_first: bool = True) -> torch.Tensor:
+def conv_row_order(nbr: Optional[torch.Tensor], n_offsets: int, nbr_ks: int, nbr_os: int, n: int, window_log2: int = 13,
+                   heaviest_first: bool = True, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """permutation of the n output rows that puts rows with like neighbour patterns into the same MFMA block (windows of
     2^window_log2 rows) and, tile by tile, the tiles that execute most kernel offsets first; pass it to
     conv_f32(row_order=...) / conv_i8(row_order=...)"""
     L = lib()
-    keys = torch.empty(n, dtype=torch.int64, device=nbr.device)
+    dev = masks.device if masks is not None else nbr.device
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
     group = 64 if n >= 32 * 1024 else 32              # the tile heights fpcc_conv_f32 uses for these map sizes
     n_groups = n // group
     # (on maps of millions of rows the launch has no tail worth shaping and the extra sort costs more than it returns)
     heaviest_first = heaviest_first and 2 <= n_groups <= LPT_MAX_GROUPS
-    masks = torch.empty(n, dtype=torch.int32, device=nbr.device) if heaviest_first else None
-    _ok(L.fpcc_conv_row_keys(_dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(),
-                             None if masks is None else masks.data_ptr(), _stream()))
+    if masks is not None:                             # the rows' presence masks exist (the table's producer wrote them): 4 bytes per row
+        _ok(L.fpcc_conv_row_keys_masks(_dev(masks, torch.int32, 'masks'), n, window_log2, keys.data_ptr(), _stream()))
+    else:
+        masks = torch.empty(n, dtype=torch.int32, device=dev) if heaviest_first else None
+        _ok(L.fpcc_conv_row_keys(_dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n, window_log2, keys.data_ptr(),
+                                 None if masks is None else masks.data_ptr(), _stream()))
     order = sort_keys(keys, 32 + max(1, (n >> window_log2).bit_length()))[1]
     if not heaviest_first:
         return order
-    gkeys = torch.empty(n_groups, dtype=torch.int64, device=nbr.device)
+    gkeys = torch.empty(n_groups, dtype=torch.int64, device=dev)
     _ok(L.fpcc_conv_tile_keys(masks.data_ptr(), n_offsets, order.data_ptr(), n, group, gkeys.data_ptr(), _stream()))
-    gperm = torch.empty(n_groups, dtype=torch.int32, device=nbr.device)
+    gperm = torch.empty(n_groups, dtype=torch.int32, device=dev)
     _ok(L.fpcc_conv_group_order(gkeys.data_ptr(), n_groups, gperm.data_ptr(), _stream()))
     out = torch.empty_like(order)
     _ok(L.fpcc_conv_regroup_rows(order.data_ptr(), gperm.data_ptr(), n, group, out.data_ptr(), _stream()))

@@ -126,6 +126,12 @@ int64_t fpcc_refine(const int64_t *pkeys, int64_t m, const uint8_t *mask, int64_
 int fpcc_nbr27_search(const int64_t *keys, int64_t n, int bits, int32_t *nbr, void *stream);
 int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr,
                            int64_t m, const int32_t *child_row, int32_t *nbr, void *stream);
+/* The same pass with up to two more results from the entries it has in hand (round 6; each may be NULL): rows_out int32 [n][32],
+ * the table once more ROW-MAJOR (entries 27 .. 31 = -1; 16-byte aligned) -- the layout the MFMA kernels' prologue reads, which
+ * rounds 2-5 made by a transposition pass over the finished table --, and masks_out uint32 [n], bit d set where neighbour d of the
+ * row exists -- what fpcc_conv_row_keys_masks and fpcc_conv_tile_keys need. */
+int fpcc_nbr27_from_parent_ex(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr, int64_t m,
+                              const int32_t *child_row, int32_t *nbr, int32_t *rows_out, uint32_t *masks_out, void *stream);
 /* the same derivation, keeping only WHICH of the 27 neighbours exist: masks_out[i] bit d = neighbour d of row i exists */
 int fpcc_mask27_from_parent(const int64_t *keys, const int32_t *parent_of, int64_t n, const int32_t *parent_nbr, int64_t m,
                             const int32_t *child_row, uint32_t *masks_out, void *stream);
@@ -312,6 +318,12 @@ int fpcc_pointwise_head_f32(const float *x, int c0, int ldx, const float *w1, co
 int fpcc_conv_row_keys(const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os, int64_t n, int window_log2,
                        int64_t *keys_out, uint32_t *masks_out, void *stream);
 /* masks_out (may be NULL): per row, bit k set iff the row has kernel offset k. */
+/* The same keys from presence masks that exist already (fpcc_nbr27_from_parent_ex / fpcc_mask27_from_parent write them):
+ * 4 bytes read per row instead of the row's 27 table entries. */
+int fpcc_conv_row_keys_masks(const uint32_t *masks, int64_t n, int window_log2, int64_t *keys_out, void *stream);
+/* out[p][0..ld) = rows[order[p]][0..ld): the rows of a row-major table (ld a multiple of 4, 16-byte aligned) put into position
+ * order as whole 16-byte pieces -- the copy the paragraph above asks for, once per coordinate map. */
+int fpcc_gather_table_rows_i32(const int32_t *rows, int ld, const int32_t *order, int64_t n, int32_t *out, void *stream);
 /* Heaviest tiles first.  fpcc_conv_tile_keys writes, per group of `group` (<= 64) consecutive positions of row_order
  * (NULL = identity), from the row masks of fpcc_conv_row_keys, the key (kernel offsets the group's rows lack) << 32 | group index; sorting the keys (fpcc_sort_keys) gives a
  * group permutation with the groups that execute most offsets first, and fpcc_conv_regroup_rows applies it:

@@ -510,6 +510,29 @@ def test_constant_one_first_layer_from_presence_masks(ops, scene, c_out):
     assert derived is not None and torch.equal(derived, masks)
 
 
+@pytest.mark.parametrize('c_out,n', [(16, 1), (16, 100003), (4, 777), (12, 5000), (24, 33333), (32, 70001), (8, 4099)])
+def test_constant_one_first_layer_on_random_masks(ops, c_out, n):
+    """the register-weight form of fpcc_conv_ones_k3_f32 (a thread owns 8 or 4 columns, absent neighbours enter as fmaf(0, w, acc)):
+    the ascending-offset fp32 chain over the present neighbours, bit for bit, for every column split, ragged sizes, empty masks and
+    weights of either sign including -0"""
+    rng = np.random.default_rng(c_out * 1000 + n)
+    masks = rng.integers(0, 1 << 27, n, dtype=np.int64)
+    masks[rng.random(n) < 0.05] = 0
+    masks[rng.random(n) < 0.05] = (1 << 27) - 1
+    w = (rng.normal(size=(27, 1, c_out)) / 4).astype(np.float32)
+    w[rng.random(w.shape) < 0.05] = -0.0
+    b = rng.normal(size=c_out).astype(np.float32)
+    acc = np.zeros((n, c_out), np.float32)
+    for k in range(27):
+        bit = ((masks >> k) & 1).astype(bool)[:, None]
+        acc = np.where(bit, acc + w[k, 0][None, :], acc).astype(np.float32)
+    want = (acc + b[None, :]).astype(np.float32)
+    want = np.where(want < 0, (want * np.float32(0.3)).astype(np.float32), want)
+    slope = torch.tensor([0.3], device='cuda')
+    got = ops.conv_ones_k3(torch.from_numpy(masks.astype(np.int32)).cuda(), _cuda(w), c_out, bias=_cuda(b), act=ops.ACT_PRELU, slope=slope)
+    assert (_bits(got.cpu().numpy()) == _bits(want)).all()
+
+
 @pytest.mark.parametrize('c1,c2,c_out,n_off', [(128, 0, 128, 27), (128, 128, 128, 27), (64, 0, 64, 27), (64, 0, 128, 8), (32, 0, 32, 27)])
 @pytest.mark.parametrize('nbw', [1, 2])
 def test_grouped_evaluation_is_order_3(ops, scene, c1, c2, c_out, n_off, nbw):

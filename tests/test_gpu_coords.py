@@ -88,9 +88,20 @@ def test_pyramid_and_neighbour_tables(ops, res, n):
     for li in range(len(levels) - 2, -1, -1):
         keys_l, lvl_l, _, _ = levels[li]
         _, _, parent_of, child_row = levels[li + 1]
+        parent_nbr = nbr
         nbr = ops.nbr27_from_parent(keys_l, parent_of, nbr, child_row)
         want = oc.dense_table(oc.kernel_map(lvl_l, lvl_l, 3), lvl_l.n)
         assert (nbr.cpu().numpy() == want).all()
+        # the same pass with the row-major copy and the presence masks (round 6), and what is built on them
+        nbr2, rows, masks = ops.nbr27_from_parent_ex(keys_l, parent_of, parent_nbr, child_row)
+        assert torch.equal(nbr2, nbr)
+        assert rows.shape == (lvl_l.n, 32) and torch.equal(rows[:, :27], nbr.t()) and bool((rows[:, 27:] == -1).all())
+        want_masks = ((want >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+        assert (masks.cpu().numpy().astype(np.int64) == want_masks).all()
+        order_t = ops.conv_row_order(nbr, 27, lvl_l.n, 1, lvl_l.n, 13)
+        order_m = ops.conv_row_order(None, 27, lvl_l.n, 1, lvl_l.n, 13, masks=masks)
+        assert torch.equal(order_t, order_m)
+        assert torch.equal(ops.gather_table_rows(rows, order_m), rows.index_select(0, order_m.long()))
         if lvl_l.n < 60000:
             assert (ops.nbr27_search(keys_l, bits - li).cpu().numpy() == want).all()
 
@@ -100,6 +111,9 @@ def test_pyramid_and_neighbour_tables(ops, res, n):
     gen = oc.generated(lvl1)
     got = ops.nbr27_from_parent(None, None, nbr1, None).cpu().numpy()
     assert (got == oc.dense_table(oc.kernel_map(gen, gen, 3), gen.n)).all()
+    got2, rows_g, masks_g = ops.nbr27_from_parent_ex(None, None, nbr1, None)
+    assert (got2.cpu().numpy() == got).all() and (rows_g[:, :27].t().cpu().numpy() == got).all() and bool((rows_g[:, 27:] == -1).all())
+    assert (masks_g.cpu().numpy().astype(np.int64) == ((got >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)).all()
 
     # --- refine: a random mask over the candidates -------------------------------------------------------------------
     mask = rng.random(8 * lvl1.n) < 0.4
