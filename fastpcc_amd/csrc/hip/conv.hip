@@ -1322,80 +1322,88 @@ int launch_pointwise(const ConvArgs &a, const float *wp, hipStream_t s) {
 // over the neighbours that exist of w[k][j], in ascending offset order -- the same chain the general kernel evaluates with
 // x = 1 (fmaf(1, w, acc) == acc + w), so the result is bit-identical -- read from the row's 27-bit presence mask instead of
 // the 108-byte neighbour row.
-// Round 6: a thread owns CPT (8 or 4) output columns of a row and keeps their 27 x CPT weights in REGISTERS for all the rows it walks;
-// an absent neighbour contributes fmaf(0, w, acc) == acc (acc is never -0: it starts at +0 and a sum that cancels is +0), so there is
-// no divergent branch: per row 27 mask-bit -> {0, 1} conversions (two integer instructions each) and 27 x CPT / 2 packed FMAs
-// (v_pk_fma_f32 with the bit broadcast through op_sel).  4 bytes read and 4 c_out bytes written per row: HBM-bound
-// (rounds 2-5: one thread per (row, 4 columns) re-reading the weights from LDS per row behind 27 exec-mask branches, 24 % of 8 TB/s).
+// Round 6: ONE THREAD PER ROW, all CO columns: the row's mask bit k becomes the float 0 / 1 once (two integer instructions) and
+// feeds CO / 2 packed FMAs whose other operand -- w[k][2p], w[k][2p + 1] -- is the same for every lane, i.e. lives in SGPRs streamed
+// by scalar loads; an absent neighbour contributes fmaf(0, w, acc) == acc (acc is never -0: it starts at +0 and a sum that cancels
+// is +0), so there is no divergent branch and the chain is the general kernel's.
+// 4 bytes read and 4 CO bytes written per row: HBM-bound (rounds 2-5: one thread per (row, 4 columns), weights re-read from LDS for
+// every row behind 27 exec-mask branches, 24 % of 8 TB/s).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-template <int CPT>
+template <int CO, int R>
 __global__ __launch_bounds__(256) void k_conv_ones_k3(const uint32_t *__restrict__ masks, int64_t n, const float *__restrict__ w,
-                                                      const float *__restrict__ bias, int c_out, int act,
-                                                      const float *__restrict__ slope, float clip, float *__restrict__ out, int ldo,
-                                                      int rows_per_block) {
-    __shared__ f32x4 s_w[27 * 8];
-    for (int e = threadIdx.x; e < 27 * c_out / 4; e += 256) s_w[e] = reinterpret_cast<const f32x4 *>(w)[e];
-    __syncthreads();
-    const int tpr = c_out / CPT;                          // threads per row
-    const int q = threadIdx.x % tpr, slot = threadIdx.x / tpr, slots = 256 / tpr;
-    if (slot >= slots) return;                            // (c_out / CPT does not divide 256: the spare threads rest)
-    const int j0 = q * CPT;
-    f32x2_t wk[27][CPT / 2];
+                                                      const float *__restrict__ bias, int act, const float *__restrict__ slope, float clip,
+                                                      float *__restrict__ out, int ldo) {
+    const int64_t base = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
+    uint32_t m[R];
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
+    for (int i = 0; i < R; ++i) { const int64_t r = base + i * 256; m[i] = r < n ? masks[r] : 0u; }
+    f32x2_t acc[R][CO / 2];
 #pragma unroll
-        for (int h = 0; h < CPT / 4; ++h) {
-            const f32x4 t = s_w[(k * c_out + j0) / 4 + h];
-            wk[k][2 * h] = {t.x, t.y};
-            wk[k][2 * h + 1] = {t.z, t.w};
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int p = 0; p < CO / 2; ++p) acc[i][p] = {0.0f, 0.0f};
+    // A ROLLED loop over the offsets with the next offset's weights requested before the current one's FMAs: unrolled, the compiler
+    // gathers all 27 x CO scalar weight loads at the top and spills the SGPRs they do not fit into VGPR lanes (3 440 v_readlane in
+    // the ISA; 3x slower than round 5's kernel on the GPU) -- a scheduling barrier per offset does not stop it
+    f32x2_t wcur[CO / 2];
+#pragma unroll
+    for (int p = 0; p < CO / 2; ++p) wcur[p] = {w[2 * p], w[2 * p + 1]};
+#pragma unroll 1
+    for (int k = 0; k < 27; ++k) {
+        const float *wn = w + (k < 26 ? k + 1 : 26) * CO;                    // uniform address: scalar loads
+        f32x2_t wnext[CO / 2];
+#pragma unroll
+        for (int p = 0; p < CO / 2; ++p) wnext[p] = {wn[2 * p], wn[2 * p + 1]};
+        f32x2_t bb[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            // bit k -> 0.0f / 1.0f: sign-extend the bit to 0 / ~0 and keep the bits of 1.0f
+            const float bit = __int_as_float((((int32_t)(m[i] << (31 - k))) >> 31) & 0x3f800000);
+            bb[i] = {bit, bit};
         }
-    float bj[CPT];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) bj[j] = bias ? bias[j0 + j] : 0.0f;
+        for (int p = 0; p < CO / 2; ++p)
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i][p] = __builtin_elementwise_fma(bb[i], wcur[p], acc[i][p]);
+#pragma unroll
+        for (int p = 0; p < CO / 2; ++p) wcur[p] = wnext[p];
+    }
     const float sl = (act == FPCC_ACT_PRELU && slope) ? slope[0] : 0.0f;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    // software pipeline of depth 4: the masks of the next four rows of this thread are in flight while the current four are summed
-    // (one row's chain is ~700 cycles of packed FMAs, a load from HBM under load ~2 us, and the registers allow 1-2 waves per SIMD)
-    uint32_t nxt[4];
+    // The finished rows leave through LDS so that a wave's store instruction writes consecutive 16-byte pieces (1 KB when the rows are
+    // contiguous): a thread storing its own row as CO / 4 pieces writes 16 bytes at a 4 CO-byte stride per instruction, which held the
+    // kernel at 2.6 TB/s.  Row stride CO + 1 words: conflict-free for the writes (lane = row) and 2-way at worst for the reads.
+    static_assert(R == 1, "one row per thread");
+    __shared__ float s_rows[256 * (CO + 1)];
+    float *mine = s_rows + threadIdx.x * (CO + 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int64_t ri = r0 + slot + (int64_t)i * slots; nxt[i] = ri < r1 ? masks[ri] : 0u; }
-    for (int64_t r = r0 + slot; r < r1; r += 4 * slots) {
-        uint32_t cur[4];
+    for (int h = 0; h < CO / 4; ++h) {
+        mine[4 * h] = finish(acc[0][2 * h].x, bias ? bias[4 * h] : 0.0f, act, sl, clip);
+        mine[4 * h + 1] = finish(acc[0][2 * h].y, bias ? bias[4 * h + 1] : 0.0f, act, sl, clip);
+        mine[4 * h + 2] = finish(acc[0][2 * h + 1].x, bias ? bias[4 * h + 2] : 0.0f, act, sl, clip);
+        mine[4 * h + 3] = finish(acc[0][2 * h + 1].y, bias ? bias[4 * h + 3] : 0.0f, act, sl, clip);
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    constexpr int kPieces = CO / 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            cur[i] = nxt[i];
-            const int64_t ri = r + (int64_t)(4 + i) * slots;
-            nxt[i] = ri < r1 ? masks[ri] : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t ri = r + (int64_t)i * slots;
-            if (ri >= r1) break;
-            const uint32_t m = cur[i];
-            f32x2_t acc[CPT / 2];
-#pragma unroll
-            for (int h = 0; h < CPT / 2; ++h) acc[h] = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 27; ++k) {
-                // bit k -> 0.0f / 1.0f: sign-extend the bit to 0 / ~0 and keep the bits of 1.0f
-                const float bit = __int_as_float((((int32_t)(m << (31 - k))) >> 31) & 0x3f800000);
-                const f32x2_t bb = {bit, bit};
-#pragma unroll
-                for (int h = 0; h < CPT / 2; ++h) acc[h] = __builtin_elementwise_fma(bb, wk[k][h], acc[h]);
-            }
-            float *dst = out + ri * ldo + j0;
-#pragma unroll
-            for (int h = 0; h < CPT / 4; ++h) {
-                f32x4 o;
-                o.x = finish(acc[2 * h].x, bj[4 * h], act, sl, clip);
-                o.y = finish(acc[2 * h].y, bj[4 * h + 1], act, sl, clip);
-                o.z = finish(acc[2 * h + 1].x, bj[4 * h + 2], act, sl, clip);
-                o.w = finish(acc[2 * h + 1].y, bj[4 * h + 3], act, sl, clip);
-                reinterpret_cast<f32x4 *>(dst)[h] = o;
-            }
+    for (int j = 0; j < kPieces; ++j) {
+        const int e = j * 256 + (int)threadIdx.x;
+        const int r = e / kPieces, piece = e - r * kPieces;
+        if (row0 + r < n) {
+            const float *src = s_rows + r * (CO + 1) + 4 * piece;
+            f32x4 o;
+            o.x = src[0]; o.y = src[1]; o.z = src[2]; o.w = src[3];
+            *reinterpret_cast<f32x4 *>(out + (row0 + r) * ldo + 4 * piece) = o;
         }
     }
+}
+
+template <int CO>
+int launch_ones_k3(const uint32_t *masks, int64_t n, const float *w, const float *bias, int act, const float *slope, float clip,
+                   float *out, int ldo, hipStream_t s) {
+    // one row per thread (the offset loop is rolled and double-buffers its scalar weight loads; see the kernel)
+    hipLaunchKernelGGL((k_conv_ones_k3<CO, 1>), dim3(blocks_for(n, 256)), dim3(256), 0, s, masks, n, w, bias, act, slope, clip, out, ldo);
+    return check_hip(hipGetLastError(), "k_conv_ones_k3");
 }
 
 template <int JB>
@@ -1439,19 +1447,17 @@ extern "C" int fpcc_conv_ones_k3_f32(const uint32_t *masks, int64_t n, const flo
     if (n == 0) return FPCC_OK;
     if (!masks || !w || !out || !aligned16(out)) return fail_arg("conv_ones_k3: null or unaligned pointer");
     if (act == FPCC_ACT_PRELU && !slope) return fail_arg("conv_ones_k3: PReLU needs a slope pointer");
-    // >= ~2048 workgroups where the map allows it, each walking a contiguous slice of rows (whole passes of its 256 threads)
-    static const int cpt_env = [] { const char *e = getenv("FPCC_ONES_CPT"); return e ? atoi(e) : 0; }();     // A/B of the two forms
-    const int cpt = (c_out % 8 == 0 && cpt_env != 4) ? 8 : 4;
-    const int slots = 256 / (c_out / cpt);
-    int64_t rpb = (n + 2047) / 2048;
-    rpb = (rpb + slots - 1) / slots * slots;
-    rpb = rpb < slots ? slots : (rpb > 8192 ? 8192 : rpb);
-    const dim3 grid(blocks_for(n, (int)rpb));
-    if (cpt == 8)
-        hipLaunchKernelGGL(k_conv_ones_k3<8>, grid, dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out, act, slope, clip, out, ldo, (int)rpb);
-    else
-        hipLaunchKernelGGL(k_conv_ones_k3<4>, grid, dim3(256), 0, as_stream(stream), masks, n, w, bias, c_out, act, slope, clip, out, ldo, (int)rpb);
-    return check_hip(hipGetLastError(), "k_conv_ones_k3");
+    hipStream_t st = as_stream(stream);
+    switch (c_out) {
+        case 4: return launch_ones_k3<4>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 8: return launch_ones_k3<8>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 12: return launch_ones_k3<12>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 16: return launch_ones_k3<16>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 20: return launch_ones_k3<20>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 24: return launch_ones_k3<24>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        case 28: return launch_ones_k3<28>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+        default: return launch_ones_k3<32>(masks, n, w, bias, act, slope, clip, out, ldo, st);
+    }
 }
 
 extern "C" int fpcc_conv_debug_stamps(unsigned long long *buf, int64_t n_u64) {

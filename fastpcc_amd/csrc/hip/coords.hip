@@ -308,8 +308,9 @@ template <bool MASK_ONLY>
 __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
                                     const int32_t *__restrict__ pnbr, int64_t m, const int32_t *__restrict__ child_row,
                                     int32_t *__restrict__ nbr, int32_t *__restrict__ rows_out, uint32_t *__restrict__ masks_out) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t i_raw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (MASK_ONLY && i_raw >= n) return;
+    const int64_t i = i_raw < n ? i_raw : n - 1;               // (table form: a thread past the end recomputes the last row and stores nothing)
     const int oct = keys ? (int)(keys[i] & 7) : (int)(i & 7);   // keys == NULL: generated set, row = 8*parent + octant
     const int ox = oct & 1, oy = (oct >> 1) & 1, oz = oct >> 2;
     const int32_t p = parent_of ? parent_of[i] : (int32_t)(i >> 3);
@@ -319,11 +320,13 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
     // {-1, 0, 1}; the 27 of the 64 children whose offsets lie in {-1, 0, 1}^3 are the answers.  They go through an LDS tile
     // [27][threads] (so that every store instruction writes consecutive rows of ONE offset): 27 KB per workgroup -- five
     // workgroups per CU; the [64][threads] tile of all children that round 2 kept allowed two, and the kernel ran latency-bound.
-    __shared__ int32_t s_out[MASK_ONLY ? 1 : 27 * kThreads];
+    // (plane stride kThreads + 1: the row-major copy below reads the tile across planes, 8 lanes per row)
+    constexpr int kPlane = kThreads + 1;
+    __shared__ int32_t s_out[MASK_ONLY ? 1 : 27 * kPlane];
     int32_t *mine = s_out + (MASK_ONLY ? 0 : threadIdx.x);
     if (!MASK_ONLY) {
 #pragma unroll
-        for (int d = 0; d < 27; ++d) mine[d * kThreads] = -1;
+        for (int d = 0; d < 27; ++d) mine[d * kPlane] = -1;
     }
     uint32_t bits = 0;
 #pragma unroll
@@ -348,26 +351,36 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
             if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
             const int d = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
             bits |= (uint32_t)(kid[c] >= 0) << d;
-            if (!MASK_ONLY) mine[d * kThreads] = kid[c];
+            if (!MASK_ONLY) mine[d * kPlane] = kid[c];
         }
     }
     if (!MASK_ONLY) {
         // own column of the tile only: no barrier needed
+        if (i_raw < n) {
 #pragma unroll
-        for (int d = 0; d < 27; ++d) nbr[(int64_t)d * n + i] = mine[d * kThreads];
+            for (int d = 0; d < 27; ++d) nbr[(int64_t)d * n + i] = mine[d * kPlane];
+            if (masks_out) masks_out[i] = bits;
+        }
         if (rows_out) {
-            int4 *dst = reinterpret_cast<int4 *>(rows_out + i * 32);
+            // the tile once more, row-major: lane e of pass j moves the 16-byte piece (row e / 8, piece e % 8) -- a wave's store is 1 KB
+            // of consecutive addresses (writing each thread's own line piece by piece, 16 bytes at a 128-byte stride per
+            // instruction, doubled the kernel's time)
+            __syncthreads();
+            const int64_t row0 = blockIdx.x * (int64_t)blockDim.x;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                int4 v;                                               // (d is a compile-time constant after unrolling)
-                v.x = 4 * j < 27 ? mine[(4 * j < 27 ? 4 * j : 0) * kThreads] : -1;
-                v.y = 4 * j + 1 < 27 ? mine[(4 * j + 1 < 27 ? 4 * j + 1 : 0) * kThreads] : -1;
-                v.z = 4 * j + 2 < 27 ? mine[(4 * j + 2 < 27 ? 4 * j + 2 : 0) * kThreads] : -1;
-                v.w = 4 * j + 3 < 27 ? mine[(4 * j + 3 < 27 ? 4 * j + 3 : 0) * kThreads] : -1;
-                dst[j] = v;
+                const int e = j * kThreads + (int)threadIdx.x;
+                const int r = e >> 3, piece = e & 7;
+                if (row0 + r < n) {
+                    int4 v;
+                    v.x = 4 * piece < 27 ? s_out[(4 * piece) * kPlane + r] : -1;
+                    v.y = 4 * piece + 1 < 27 ? s_out[(4 * piece + 1) * kPlane + r] : -1;
+                    v.z = 4 * piece + 2 < 27 ? s_out[(4 * piece + 2) * kPlane + r] : -1;
+                    v.w = 4 * piece + 3 < 27 ? s_out[(4 * piece + 3) * kPlane + r] : -1;
+                    reinterpret_cast<int4 *>(rows_out + (row0 + r) * 32)[piece] = v;
+                }
             }
         }
-        if (masks_out) masks_out[i] = bits;
     }
     if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }

@@ -86,23 +86,28 @@ struct SelectState {
     unsigned long long rank;      // 1-based rank still to find among the keys matching `prefix`; 0 = no threshold (keep everything)
     unsigned prefix;              // the key bits fixed so far (right-aligned)
     float thr;                    // the result, after the last pass
+    unsigned arrived[3];          // workgroups that have merged their histogram, per pass: the last one walks the bins
 };
 constexpr int kSelBins = 2048;
-__global__ void k_select_init(SelectState *st, SelectState v) { *st = v; }
 
+// one pass: histogram of the key bits [kShift, kShift + 11) (10 in the last pass) of the candidates whose higher bits equal the prefix
+// found so far; the LAST workgroup to merge its bins into the global histogram finds the bin that holds the wanted rank, extends the
+// prefix and clears the bins for the next pass (no launch of its own, no host round trip).  PASS 0 takes the rank as an argument.
 template <int PASS, bool SEG>
-__global__ __launch_bounds__(256) void k_select_hist(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
-                                                     const unsigned *__restrict__ seg_max, const SelectState *__restrict__ st,
-                                                     unsigned *__restrict__ hist) {
+__global__ __launch_bounds__(256) void k_select_pass(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
+                                                     const unsigned *__restrict__ seg_max, SelectState *__restrict__ st,
+                                                     unsigned *__restrict__ hist, unsigned long long rank0) {
     __shared__ unsigned s_h[kSelBins];
+    __shared__ unsigned long long s_part[256];
+    __shared__ bool s_last;
     for (int i = threadIdx.x; i < kSelBins; i += 256) s_h[i] = 0;
     __syncthreads();
+    const unsigned long long rank = PASS ? st->rank : rank0;
     const unsigned prefix = PASS ? st->prefix : 0u;
-    const bool live = st->rank != 0ull;
     // PASS 0: bits 31..21, PASS 1: bits 20..10 under an 11-bit prefix, PASS 2: bits 9..0 under a 22-bit prefix
     constexpr int kShift = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
     constexpr unsigned kMask = PASS == 2 ? 1023u : 2047u;
-    if (live)
+    if (rank != 0ull)
         for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < m; p += (int64_t)gridDim.x * 256) {
             const float4 a = logit[2 * p], b = logit[2 * p + 1];
             const float mx = SEG ? ord2f(seg_max[seg[p]]) : max8(a, b);
@@ -116,19 +121,19 @@ __global__ __launch_bounds__(256) void k_select_hist(const float4 *__restrict__ 
     __syncthreads();
     for (int i = threadIdx.x; i < kSelBins; i += 256)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-}
-
-template <int PASS>
-__global__ __launch_bounds__(256) void k_select_pick(unsigned *__restrict__ hist, SelectState *__restrict__ st) {
-    __shared__ unsigned long long s_part[256];
-    const unsigned long long rank = st->rank;
+    __threadfence();                                                            // my bins before my arrival
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&st->arrived[PASS], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     if (rank == 0ull) {                                                         // no threshold: everything above -inf is kept
-        if (threadIdx.x == 0 && PASS == 2) st->thr = -__builtin_huge_valf();
+        if (threadIdx.x == 0) { st->rank = 0ull; if (PASS == 2) st->thr = -__builtin_huge_valf(); }
         return;
     }
-    // 8 bins per thread, ascending
+    volatile unsigned *vh = hist;                                               // written by other workgroups' atomics: read past the L1
     unsigned long long mine = 0;
-    for (int j = 0; j < 8; ++j) mine += hist[threadIdx.x * 8 + j];
+    for (int j = 0; j < 8; ++j) mine += vh[threadIdx.x * 8 + j];               // 8 bins per thread, ascending
     s_part[threadIdx.x] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -141,14 +146,14 @@ __global__ __launch_bounds__(256) void k_select_pick(unsigned *__restrict__ hist
         unsigned long long before = acc;
         int bin = c * 8 + 7;
         for (int j = 0; j < 8; ++j) {
-            const unsigned h = hist[c * 8 + j];
+            const unsigned h = vh[c * 8 + j];
             if (before + h >= rank) { bin = c * 8 + j; break; }
             before += h;
         }
         st->rank = rank - before;
-        const unsigned prefix = PASS == 0 ? (unsigned)bin : ((st->prefix << (PASS == 2 ? 10 : 11)) | (unsigned)bin);
-        st->prefix = prefix;
-        if (PASS == 2) st->thr = ord2f(prefix);
+        const unsigned np = PASS == 0 ? (unsigned)bin : ((prefix << (PASS == 2 ? 10 : 11)) | (unsigned)bin);
+        st->prefix = np;
+        if (PASS == 2) st->thr = ord2f(np);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kSelBins; i += 256) hist[i] = 0;              // clean for the next pass
@@ -169,24 +174,21 @@ __global__ void k_keep_thr(const float4 *__restrict__ logit, int64_t m, const in
     reinterpret_cast<uint64_t *>(keep)[p] = bits;
 }
 
-// the three passes + the final mask; ws = SelectState (16 B, padded to 256) + 2048 bins
+// the three passes + the final mask (4 launches and a memset); ws = SelectState (padded to 256 bytes) + 2048 bins
 template <bool SEG>
 int select_and_keep(const float *logit, int64_t m, const int32_t *seg, const unsigned *seg_max, int64_t kth, uint8_t *keep_out, void *ws,
                     hipStream_t s) {
     SelectState *st = static_cast<SelectState *>(ws);
     unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 256);
-    SelectState init{kth >= 1 ? (unsigned long long)kth : 0ull, 0u, -__builtin_huge_valf()};
-    // the state goes through a kernel argument copy: hipMemcpyAsync from a stack variable would race with the return
     FPCC_HIP(hipMemsetAsync(ws, 0, 256 + 4 * kSelBins, s));
-    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, s, st, init);
     const float4 *lg = reinterpret_cast<const float4 *>(logit);
-    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 2048);
-    hipLaunchKernelGGL((k_select_hist<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
-    hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(256), 0, s, hist, st);
-    hipLaunchKernelGGL((k_select_hist<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
-    hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(256), 0, s, hist, st);
-    hipLaunchKernelGGL((k_select_hist<2, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist);
-    hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(256), 0, s, hist, st);
+    // few, long-lived workgroups: every one of them merges its bins into the global histogram with atomics, and on real logits most of
+    // the candidates share a few dozen bins (sign + exponent) -- ~12 ns per atomic on one address
+    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 512);
+    const unsigned long long rank = kth >= 1 ? (unsigned long long)kth : 0ull;
+    hipLaunchKernelGGL((k_select_pass<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, rank);
+    hipLaunchKernelGGL((k_select_pass<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, 0ull);
+    hipLaunchKernelGGL((k_select_pass<2, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, 0ull);
     hipLaunchKernelGGL(k_keep_thr<SEG>, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s, lg, m, seg, seg_max, (const SelectState *)st, keep_out);
     return check_hip(hipGetLastError(), "topk select");
 }
