@@ -120,35 +120,48 @@ __global__ __launch_bounds__(256) void k_select_pass(const float4 *__restrict__ 
         }
     __syncthreads();
     for (int i = threadIdx.x; i < kSelBins; i += 256)
-        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-    __threadfence();                                                            // my bins before my arrival
+        if (s_h[i]) __hip_atomic_fetch_add(&hist[i], s_h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // my bins before my arrival: the bins are device-scope atomics (performed at the memory side, never dirty in this XCD's L2), so
+    // waiting for this wave's outstanding operations is all the ordering needed -- a device-scope fence (__threadfence) writes the
+    // whole L2 back and cost ~50 us per pass here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&st->arrived[PASS], 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&st->arrived[PASS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (rank == 0ull) {                                                         // no threshold: everything above -inf is kept
         if (threadIdx.x == 0) { st->rank = 0ull; if (PASS == 2) st->thr = -__builtin_huge_valf(); }
         return;
     }
-    volatile unsigned *vh = hist;                                               // written by other workgroups' atomics: read past the L1
+    // 8 bins per thread, ascending; read past the L1 (other workgroups' atomics wrote them), all eight loads in flight at once
+    unsigned h8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h8[j] = __hip_atomic_load(&hist[threadIdx.x * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long mine = 0;
-    for (int j = 0; j < 8; ++j) mine += vh[threadIdx.x * 8 + j];               // 8 bins per thread, ascending
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += h8[j];
+    // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk holds the rank walks its 8 bins
     s_part[threadIdx.x] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long acc = 0;
-        int c = 255;
-        for (int t = 0; t < 256; ++t) {
-            if (acc + s_part[t] >= rank) { c = t; break; }
-            acc += s_part[t];
-        }
-        unsigned long long before = acc;
-        int bin = c * 8 + 7;
+    unsigned long long incl = mine;
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned long long other = (int)threadIdx.x >= d ? s_part[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        incl += other;
+        s_part[threadIdx.x] = incl;
+        __syncthreads();
+    }
+    const unsigned long long excl = incl - mine;
+    // (a rank beyond the total -- cannot happen for 1 <= rank <= 8 m -- would fall to the last chunk's last bin)
+    const bool holder = (excl < rank && rank <= incl) || (threadIdx.x == 255 && rank > incl);
+    if (holder) {
+        unsigned long long before = excl;
+        int bin = (int)threadIdx.x * 8 + 7;
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned h = vh[c * 8 + j];
-            if (before + h >= rank) { bin = c * 8 + j; break; }
-            before += h;
+            if (before + h8[j] >= rank) { bin = (int)threadIdx.x * 8 + j; break; }
+            before += h8[j];
         }
         st->rank = rank - before;
         const unsigned np = PASS == 0 ? (unsigned)bin : ((prefix << (PASS == 2 ? 10 : 11)) | (unsigned)bin);
@@ -183,8 +196,8 @@ int select_and_keep(const float *logit, int64_t m, const int32_t *seg, const uns
     FPCC_HIP(hipMemsetAsync(ws, 0, 256 + 4 * kSelBins, s));
     const float4 *lg = reinterpret_cast<const float4 *>(logit);
     // few, long-lived workgroups: every one of them merges its bins into the global histogram with atomics, and on real logits most of
-    // the candidates share a few dozen bins (sign + exponent) -- ~12 ns per atomic on one address
-    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 512);
+    // the candidates share a few dozen bins (sign + exponent) -- ~12 ns per atomic on one address, one workgroup per CU
+    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 256);
     const unsigned long long rank = kth >= 1 ? (unsigned long long)kth : 0ull;
     hipLaunchKernelGGL((k_select_pass<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, rank);
     hipLaunchKernelGGL((k_select_pass<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, 0ull);
