@@ -86,20 +86,17 @@ struct SelectState {
     unsigned long long rank;      // 1-based rank still to find among the keys matching `prefix`; 0 = no threshold (keep everything)
     unsigned prefix;              // the key bits fixed so far (right-aligned)
     float thr;                    // the result, after the last pass
-    unsigned arrived[3];          // workgroups that have merged their histogram, per pass: the last one walks the bins
 };
 constexpr int kSelBins = 2048;
 
 // one pass: histogram of the key bits [kShift, kShift + 11) (10 in the last pass) of the candidates whose higher bits equal the prefix
-// found so far; the LAST workgroup to merge its bins into the global histogram finds the bin that holds the wanted rank, extends the
-// prefix and clears the bins for the next pass (no launch of its own, no host round trip).  PASS 0 takes the rank as an argument.
+// found so far.  PASS 0 takes the rank as an argument.  One workgroup per CU at most: every workgroup merges its bins into the global
+// histogram with atomics, and on real logits most candidates share a few dozen bins (sign + exponent) -- ~12 ns per atomic on one address.
 template <int PASS, bool SEG>
-__global__ __launch_bounds__(256) void k_select_pass(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
-                                                     const unsigned *__restrict__ seg_max, SelectState *__restrict__ st,
+__global__ __launch_bounds__(256) void k_select_hist(const float4 *__restrict__ logit, int64_t m, const int32_t *__restrict__ seg,
+                                                     const unsigned *__restrict__ seg_max, const SelectState *__restrict__ st,
                                                      unsigned *__restrict__ hist, unsigned long long rank0) {
     __shared__ unsigned s_h[kSelBins];
-    __shared__ unsigned long long s_part[256];
-    __shared__ bool s_last;
     for (int i = threadIdx.x; i < kSelBins; i += 256) s_h[i] = 0;
     __syncthreads();
     const unsigned long long rank = PASS ? st->rank : rank0;
@@ -120,24 +117,24 @@ __global__ __launch_bounds__(256) void k_select_pass(const float4 *__restrict__ 
         }
     __syncthreads();
     for (int i = threadIdx.x; i < kSelBins; i += 256)
-        if (s_h[i]) __hip_atomic_fetch_add(&hist[i], s_h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // my bins before my arrival: the bins are device-scope atomics (performed at the memory side, never dirty in this XCD's L2), so
-    // waiting for this wave's outstanding operations is all the ordering needed -- a device-scope fence (__threadfence) writes the
-    // whole L2 back and cost ~50 us per pass here
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(&st->arrived[PASS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// one workgroup after each pass (its own launch: the kernel boundary is what orders it behind every workgroup's atomics -- a
+// last-arriver scheme inside the pass kernel raced on this hardware and a device-scope fence per workgroup cost ~50 us): finds the bin
+// that holds the wanted rank by a scan over 256 chunk sums, extends the prefix, clears the bins for the next pass
+template <int PASS>
+__global__ __launch_bounds__(256) void k_select_pick(unsigned *__restrict__ hist, SelectState *__restrict__ st, unsigned long long rank0) {
+    __shared__ unsigned long long s_part[256];
+    const unsigned long long rank = PASS ? st->rank : rank0;
+    const unsigned prefix = PASS ? st->prefix : 0u;
     if (rank == 0ull) {                                                         // no threshold: everything above -inf is kept
         if (threadIdx.x == 0) { st->rank = 0ull; if (PASS == 2) st->thr = -__builtin_huge_valf(); }
         return;
     }
-    // 8 bins per thread, ascending; read past the L1 (other workgroups' atomics wrote them), all eight loads in flight at once
-    unsigned h8[8];
+    unsigned h8[8];                                                              // 8 bins per thread, ascending
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h8[j] = __hip_atomic_load(&hist[threadIdx.x * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < 8; ++j) h8[j] = hist[threadIdx.x * 8 + j];
     unsigned long long mine = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) mine += h8[j];
@@ -168,8 +165,8 @@ __global__ __launch_bounds__(256) void k_select_pass(const float4 *__restrict__ 
         st->prefix = np;
         if (PASS == 2) st->thr = ord2f(np);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kSelBins; i += 256) hist[i] = 0;              // clean for the next pass
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hist[threadIdx.x * 8 + j] = 0;                  // clean for the next pass
 }
 
 template <bool SEG>
@@ -187,7 +184,7 @@ __global__ void k_keep_thr(const float4 *__restrict__ logit, int64_t m, const in
     reinterpret_cast<uint64_t *>(keep)[p] = bits;
 }
 
-// the three passes + the final mask (4 launches and a memset); ws = SelectState (padded to 256 bytes) + 2048 bins
+// the three passes + the final mask; ws = SelectState (padded to 256 bytes) + 2048 bins
 template <bool SEG>
 int select_and_keep(const float *logit, int64_t m, const int32_t *seg, const unsigned *seg_max, int64_t kth, uint8_t *keep_out, void *ws,
                     hipStream_t s) {
@@ -195,13 +192,14 @@ int select_and_keep(const float *logit, int64_t m, const int32_t *seg, const uns
     unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 256);
     FPCC_HIP(hipMemsetAsync(ws, 0, 256 + 4 * kSelBins, s));
     const float4 *lg = reinterpret_cast<const float4 *>(logit);
-    // few, long-lived workgroups: every one of them merges its bins into the global histogram with atomics, and on real logits most of
-    // the candidates share a few dozen bins (sign + exponent) -- ~12 ns per atomic on one address, one workgroup per CU
     const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(m, 256), 256);
     const unsigned long long rank = kth >= 1 ? (unsigned long long)kth : 0ull;
-    hipLaunchKernelGGL((k_select_pass<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, rank);
-    hipLaunchKernelGGL((k_select_pass<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, 0ull);
-    hipLaunchKernelGGL((k_select_pass<2, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, st, hist, 0ull);
+    hipLaunchKernelGGL((k_select_hist<0, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist, rank);
+    hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(256), 0, s, hist, st, rank);
+    hipLaunchKernelGGL((k_select_hist<1, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist, 0ull);
+    hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(256), 0, s, hist, st, 0ull);
+    hipLaunchKernelGGL((k_select_hist<2, SEG>), dim3(blocks), dim3(256), 0, s, lg, m, seg, seg_max, (const SelectState *)st, hist, 0ull);
+    hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(256), 0, s, hist, st, 0ull);
     hipLaunchKernelGGL(k_keep_thr<SEG>, dim3(blocks_for(m, kThreads)), dim3(kThreads), 0, s, lg, m, seg, seg_max, (const SelectState *)st, keep_out);
     return check_hip(hipGetLastError(), "topk select");
 }
