@@ -323,29 +323,34 @@ class CoordinateManager:
             m.keys = ((p << 3).unsqueeze(1) + torch.arange(8, device=p.device, dtype=torch.int64)).reshape(-1)
         return m.keys
 
-    def _nbr27(self, m: _Map) -> torch.Tensor:
-        """[27, n] int32 input row per (offset, output row) of the 3x3x3 kernel on m, offsets x fastest, -1 = absent."""
+    def _nbr27(self, m: _Map, want_rows: bool = False) -> torch.Tensor:
+        """[27, n] int32 input row per (offset, output row) of the 3x3x3 kernel on m, offsets x fastest, -1 = absent.
+        want_rows: the caller is going to run an MFMA layer in pattern order on m, which reads the table row-major and sorts the rows
+        by their presence masks -- both are then written by the producer's pass (a map whose table only feeds gather_sum or a narrow
+        layer does not pay the 132 bytes per row; should rows be wanted later after all, _nbr27_rows transposes the table).  A PARENT's
+        table is always asked for with rows: every pyramid level of the codecs hosts 3x3x3 layers, and it is 4-8x smaller than the child's"""
+        want_rows = want_rows and self.NBR_ROWS and m.n > self.ROW_ORDER_MIN_ROWS and m.nbr27_rows is None and m.nbr27_pos is None
         if m.nbr27 is None:
             if m.generated:
-                if self.NBR_ROWS and m.n > self.ROW_ORDER_MIN_ROWS and m.nbr27_rows is None and m.nbr27_pos is None:
-                    m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(None, None, self._nbr27(m.parent), None, n=m.n)
+                if want_rows:
+                    m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(None, None, self._nbr27(m.parent, True), None, n=m.n)
                     if m.mask27 is None:
                         m.mask27 = masks
                 else:
-                    m.nbr27 = ops.nbr27_from_parent(None, None, self._nbr27(m.parent), None, n=m.n)
+                    m.nbr27 = ops.nbr27_from_parent(None, None, self._nbr27(m.parent, True), None, n=m.n)
             else:
                 if m.parent is None and m.n > self.ROOT_ROWS and m.bits > 1:
                     self._ensure_parent(m)
                 if m.parent is not None:
-                    if self.NBR_ROWS and m.n > self.ROW_ORDER_MIN_ROWS and m.nbr27_rows is None and m.nbr27_pos is None:
+                    if want_rows:
                         # a map this large runs its 3x3x3 layers in pattern order, which reads the table row-major and needs the rows'
                         # presence masks for the order: both come out of the producer's pass (round 6; was a transposition pass
                         # and a pass of 27 reads per row)
-                        m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+                        m.nbr27, m.nbr27_rows, masks = ops.nbr27_from_parent_ex(m.keys, m.parent_of, self._nbr27(m.parent, True), m.child_row)
                         if m.mask27 is None:
                             m.mask27 = masks
                     else:
-                        m.nbr27 = ops.nbr27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+                        m.nbr27 = ops.nbr27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent, True), m.child_row)
                 else:
                     m.nbr27 = ops.nbr27_search(m.keys, m.bits)
         return m.nbr27
@@ -387,7 +392,7 @@ class CoordinateManager:
                 self._ensure_parent(m)
             if m.parent is None:
                 return None
-            m.mask27 = ops.mask27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent), m.child_row)
+            m.mask27 = ops.mask27_from_parent(m.keys, m.parent_of, self._nbr27(m.parent, True), m.child_row)
         return m.mask27
 
     # maps with more rows than this run their 3x3x3 convolutions in neighbour-pattern order (fpcc_conv_row_keys)
@@ -402,7 +407,7 @@ class CoordinateManager:
         if m.row_order is False or (m.row_order is None and training and m.n > self.ROW_ORDER_MIN_ROWS_TRAINING):
             m.row_order = None
             if m.n > (self.ROW_ORDER_MIN_ROWS_TRAINING if training else self.ROW_ORDER_MIN_ROWS):
-                nbr = self._nbr27(m)
+                nbr = self._nbr27(m, want_rows=not training)
                 # the masks of a table made by nbr27_from_parent_ex describe exactly that table (a mask derived earlier from the parent
                 # level does too: same rule); without them the keys are read off the table
                 m.row_order = ops.conv_row_order(nbr, 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2,
