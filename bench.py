@@ -344,7 +344,7 @@ def secondary(device):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args.cpu_resolution, 60.0, args.cpu_baseline_worker)
+        return cpu_baseline_worker(args.cpu_resolution, 90.0, args.cpu_baseline_worker)
     import statistics
     from fastpcc_amd import replicas
     rank, world, local = replicas.env_rank()

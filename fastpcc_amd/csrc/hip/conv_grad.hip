@@ -133,79 +133,32 @@ __global__ __launch_bounds__(64 * NBT) void k_wgrad_mfma_wide(WgradArgs a) {
 // order ~1.1x the useful work is executed.  Operands are fetched one half block (16 rows) ahead of the MFMAs that use
 // them and the row indices (row_order -> nbr) one active block ahead, so the two dependent loads and the gather hide
 // behind 32 MFMAs each.  Geometry as k_wgrad_mfma_wide: 32*CB input channels x all output columns per workgroup.
-// (round 6) The same pass counts, per offset, the blocks that have it: the row splits of an offset are sized by that count
-// (k_wgrad_plan) -- with the same number of splits for every offset the launch lasted as long as its heaviest offset (the centre
-// one is in every block, a corner offset in 40 % of them: max / mean 1.25-1.73 over the maps of a training batch).
-constexpr int kMaskBlocksPerWg = 64;       // 16 per wave
 __global__ __launch_bounds__(256) void k_wgrad_blockmask(const int32_t *__restrict__ nbr, int n_off, int64_t nbr_ks, int64_t nbr_os,
                                                          const int32_t *__restrict__ row_order, int64_t n, int64_t n_blocks,
-                                                         uint32_t *__restrict__ masks, uint32_t *__restrict__ active) {
-    __shared__ uint32_t s_cnt[32];
-    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t mine = 0;                                           // lane k: blocks of this wave that have offset k
-    for (int it = 0; it < kMaskBlocksPerWg / 4; ++it) {
-        const int64_t b = (int64_t)blockIdx.x * kMaskBlocksPerWg + it * 4 + wave;
-        if (b >= n_blocks) break;                                // wave-uniform
-        const int64_t pos = b * 32 + lane;
-        const int64_t row = (lane < 32 && pos < n) ? (int64_t)row_order[pos] : -1;
-        uint32_t m = 0;
-        for (int k = 0; k < n_off; ++k) {
-            const bool has = row >= 0 && nbr[(int64_t)k * nbr_ks + row * nbr_os] >= 0;
-            m |= (__ballot(has) != 0ull ? 1u : 0u) << k;
-        }
-        if (lane == 0) masks[b] = m;
-        mine += lane < 32 ? (m >> lane) & 1u : 0u;
+                                                         uint32_t *__restrict__ masks) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= n_blocks) return;
+    const int64_t pos = b * 32 + lane;
+    const int64_t row = (lane < 32 && pos < n) ? (int64_t)row_order[pos] : -1;
+    uint32_t m = 0;
+    for (int k = 0; k < n_off; ++k) {
+        const bool has = row >= 0 && nbr[(int64_t)k * nbr_ks + row * nbr_os] >= 0;
+        m |= (__ballot(has) != 0ull ? 1u : 0u) << k;
     }
-    if (lane < 32 && mine) atomicAdd(&s_cnt[lane], mine);
-    __syncthreads();
-    if (active && threadIdx.x < 32 && s_cnt[threadIdx.x]) atomicAdd(&active[threadIdx.x], s_cnt[threadIdx.x]);
-}
-
-// Row splits per offset, proportional to the offset's active blocks: of `total` workgroup slots offset k takes
-// max(1, floor(total * active_k / sum active)), at most `cap`.  plan[0 .. 31] = splits_k, plan[32 .. 64] = exclusive prefix (plan[32 + n_off]
-// = workgroups that have work).  One wave.
-struct WgradPlan { uint32_t splits[32]; uint32_t first[33]; };
-__global__ void k_wgrad_plan(const uint32_t *__restrict__ active, int n_off, uint32_t total, uint32_t cap, uint32_t even,
-                             WgradPlan *__restrict__ plan) {
-    const int lane = threadIdx.x;
-    unsigned long long sum = 0;
-    for (int k = 0; k < n_off; ++k) sum += active[k];
-    uint32_t mine = 0;
-    if (lane < n_off) {
-        const unsigned long long a = active[lane];
-        mine = sum ? (uint32_t)(a * total / sum) : 1u;
-        mine = mine < 1u ? 1u : (mine > cap ? cap : mine);
-        if (a == 0) mine = 1u;                                   // an offset nobody has: one workgroup that writes zeros
-        if (even) mine = even;                                   // A/B switch: the same number of splits for every offset
-    }
-    if (lane < 32) plan->splits[lane] = lane < n_off ? mine : 0u;
-    // exclusive prefix over the 32 lanes (every lane takes part in the shuffles)
-    uint32_t incl = lane < n_off ? mine : 0u;
-    for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if ((lane & 31) >= d) incl += up;
-    }
-    if (lane < 32) plan->first[lane] = incl - (lane < n_off ? mine : 0u);
-    if (lane == 31) plan->first[32] = incl;
+    if (lane == 0) masks[b] = m;
 }
 
 template <int NBT, int CB>
 __global__ __launch_bounds__(64 * NBT, 2) void k_wgrad_rows(WgradArgs a, const uint32_t *__restrict__ masks,
-                                                            const int32_t *__restrict__ row_order, const WgradPlan *__restrict__ plan) {
+                                                            const int32_t *__restrict__ row_order) {
     typedef float fvec __attribute__((ext_vector_type(CB)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    // workgroup w of the launch -> (offset k, row split s of that offset): the plan's prefix table (wave-uniform scalar reads)
-    const uint32_t w = blockIdx.x;
-    if (w >= plan->first[a.n_off]) return;
-    int k = 0;
-    while (k + 1 < a.n_off && plan->first[k + 1] <= w) ++k;
-    const int s = (int)(w - plan->first[k]), cg = blockIdx.z;
-    // row split s takes blocks s, s + splits_k, ...: in pattern order the rows that have an offset are clustered, a
+    const int s = blockIdx.x, k = blockIdx.y, cg = blockIdx.z;
+    // row split s takes blocks s, s + splits, ...: in pattern order the rows that have an offset are clustered, a
     // contiguous range per split would give some workgroups all of an offset's blocks and others none
-    const int64_t b_begin = s, b_end = (a.n + 31) / 32, b_step = plan->splits[k];
+    const int64_t b_begin = s, b_end = (a.n + 31) / 32, b_step = a.splits;
     f32x16 acc[CB];
 #pragma unroll
     for (int q = 0; q < CB; ++q)
@@ -371,18 +324,6 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     dw[e] = acc;
 }
 
-// the same for the planned launches: offset k has plan->splits[k] partial sums (slots s < splits[k] of its column of the buffer)
-__global__ __launch_bounds__(256) void k_wgrad_reduce_plan(const float *__restrict__ partial, const WgradPlan *__restrict__ plan, int n_off,
-                                                           int64_t per_offset, int64_t count, float *__restrict__ dw, int accumulate) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
-    const int k = (int)((e / per_offset) % n_off);
-    const int splits = (int)plan->splits[k];
-    float acc = accumulate ? dw[e] : 0.0f;
-    for (int s = 0; s < splits; ++s) acc = acc + partial[(int64_t)s * count + e];
-    dw[e] = acc;
-}
-
 // row splits: enough workgroups to fill the chip ~3x, at least 256 rows each, at most 512 splits
 int pick_splits(int c_in, int c_out, int kg, int64_t n, bool mfma) {
     const int64_t per_split_items = mfma ? (int64_t)kg * (c_in % 128 == 0 ? c_in / 128 : c_in % 64 == 0 ? c_in / 64 : c_in / 32) : kg;
@@ -395,8 +336,6 @@ int pick_splits(int c_in, int c_out, int kg, int64_t n, bool mfma) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-constexpr int kPlanCap = 2;                // an offset takes at most twice the even share of the row splits
-
 bool wgrad_mfma_ok(int c_in, int c_out) { return c_in % 32 == 0 && (c_out == 32 || c_out == 64 || c_out == 128); }
 
 }  // namespace
@@ -408,8 +347,7 @@ extern "C" int64_t fpcc_conv_wgrad_ws_bytes(int c_in, int c_out, int n_offsets, 
     if (c_in < 1 || c_out < 1 || n_offsets < 1 || groups < 1 || n < 0) return FPCC_E_ARG;
     const int kg = n_offsets * groups;
     const int splits = pick_splits(c_in, c_out, kg, n, wgrad_mfma_ok(c_in, c_out));
-    // partial sums (the planned launches give an offset up to kPlanCap x the even share of splits) + one mask per 32 rows + counters / plan
-    return (int64_t)splits * kPlanCap * kg * c_in * c_out * 4 + ((n + 31) / 32 + 4) * 4 + 1024;
+    return (int64_t)splits * kg * c_in * c_out * 4 + ((n + 31) / 32 + 4) * 4;      // partial sums + one mask per 32 rows
 }
 
 extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const float *dy, int c_out, int ldy,
@@ -431,7 +369,7 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
     if (!x || !dy) return fail_arg("conv_wgrad: null pointer");
     const bool mfma = wgrad_mfma_ok(c_in, c_out);
     const int splits = pick_splits(c_in, c_out, kg, n, mfma);
-    const int64_t need = (int64_t)splits * kPlanCap * count * 4 + ((n + 31) / 32 + 4) * 4 + 1024;
+    const int64_t need = (int64_t)splits * count * 4 + ((n + 31) / 32 + 4) * 4;
     if (!ws || ws_bytes < need) return fail_arg("conv_wgrad: workspace of fpcc_conv_wgrad_ws_bytes() bytes required");
     const int64_t rows_per_split = ((n + splits - 1) / splits + 31) / 32 * 32;
     WgradArgs a{x, c_in, ldx, dy, c_out, ldy, nbr, n_offsets, nbr_ks, nbr_os, out_map, om_os, om_gs, groups, n,
@@ -439,35 +377,20 @@ extern "C" int fpcc_conv_wgrad_f32(const float *x, int c_in, int ldx, const floa
     static const int skip_rows = [] { const char *e = getenv("FPCC_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
     if (skip_rows && mfma && row_order && nbr && !out_map && groups == 1 && n_offsets <= 32 && c_in % 64 == 0 && aligned16(x) &&
         ldx % 4 == 0 && (c_out == 128 || c_out == 64)) {
+        uint32_t *masks = reinterpret_cast<uint32_t *>(static_cast<float *>(ws) + (int64_t)splits * count);
         const int64_t n_blocks = (n + 31) / 32;
-        uint32_t *masks = reinterpret_cast<uint32_t *>(static_cast<float *>(ws) + (int64_t)splits * kPlanCap * count);
-        // (256-byte aligned behind the masks) 32 counters, then the plan
-        char *tail = reinterpret_cast<char *>(masks + n_blocks + 4);
-        tail += (256 - (reinterpret_cast<uintptr_t>(tail) & 255)) & 255;
-        uint32_t *active = reinterpret_cast<uint32_t *>(tail);
-        WgradPlan *plan = reinterpret_cast<WgradPlan *>(tail + 128);
-        static const int planned = [] { const char *e = getenv("FPCC_WGRAD_PLAN"); return e ? atoi(e) : 1; }();   // 0: even splits (A/B)
-        if (int rc = check_hip(hipMemsetAsync(active, 0, 128, s), "hipMemsetAsync")) return rc;
-        hipLaunchKernelGGL(k_wgrad_blockmask, dim3(blocks_for(n_blocks, kMaskBlocksPerWg)), dim3(256), 0, s, nbr, n_offsets, nbr_ks, nbr_os,
-                           row_order, n, n_blocks, masks, planned ? active : (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_wgrad_blockmask, dim3(blocks_for(n_blocks, 4)), dim3(256), 0, s, nbr, n_offsets, nbr_ks, nbr_os,
+                           row_order, n, n_blocks, masks);
         if (int rc = check_hip(hipGetLastError(), "k_wgrad_blockmask")) return rc;
-        const uint32_t total = (uint32_t)splits * (uint32_t)n_offsets;
-        hipLaunchKernelGGL(k_wgrad_plan, dim3(1), dim3(64), 0, s, (const uint32_t *)active, n_offsets, total, (uint32_t)(splits * kPlanCap),
-                           (uint32_t)(planned ? 0 : splits), plan);
-        const unsigned gx = total + (unsigned)n_offsets;          // floor shares sum to <= total; + one for every offset raised to 1
         if (c_in % 128 == 0) {
-            const dim3 grid(gx, 1, c_in / 128);
-            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 4>), grid, dim3(256), 0, s, a, masks, row_order, (const WgradPlan *)plan);
-            else hipLaunchKernelGGL((k_wgrad_rows<2, 4>), grid, dim3(128), 0, s, a, masks, row_order, (const WgradPlan *)plan);
+            const dim3 grid(splits, kg, c_in / 128);
+            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 4>), grid, dim3(256), 0, s, a, masks, row_order);
+            else hipLaunchKernelGGL((k_wgrad_rows<2, 4>), grid, dim3(128), 0, s, a, masks, row_order);
         } else {
-            const dim3 grid(gx, 1, c_in / 64);
-            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 2>), grid, dim3(256), 0, s, a, masks, row_order, (const WgradPlan *)plan);
-            else hipLaunchKernelGGL((k_wgrad_rows<2, 2>), grid, dim3(128), 0, s, a, masks, row_order, (const WgradPlan *)plan);
+            const dim3 grid(splits, kg, c_in / 64);
+            if (c_out == 128) hipLaunchKernelGGL((k_wgrad_rows<4, 2>), grid, dim3(256), 0, s, a, masks, row_order);
+            else hipLaunchKernelGGL((k_wgrad_rows<2, 2>), grid, dim3(128), 0, s, a, masks, row_order);
         }
-        if (int rc = check_hip(hipGetLastError(), "k_wgrad_rows")) return rc;
-        hipLaunchKernelGGL(k_wgrad_reduce_plan, dim3(blocks_for(count, 256)), dim3(256), 0, s, static_cast<const float *>(ws),
-                           (const WgradPlan *)plan, n_offsets, (int64_t)c_in * c_out, count, dw, accumulate);
-        return check_hip(hipGetLastError(), "k_wgrad_reduce_plan");
     } else if (mfma && c_in % 128 == 0 && aligned16(x) && ldx % 4 == 0) {
         const dim3 grid(splits, kg, c_in / 128);
         if (c_out == 128) hipLaunchKernelGGL((k_wgrad_mfma_wide<4, 4>), grid, dim3(256), 0, s, a);
