@@ -541,8 +541,10 @@ def main():
 
     # rate / distortion of the frame just coded (outside the timed region): bpp and D1-PSNR as the reference's evaluator
     # reports them, distortion computed on the device (fastpcc_amd/evaluators.py)
-    from fastpcc_amd.evaluators import d1_metrics
-    quality = d1_metrics(frame[:, 1:], rec, args.resolution)
+    # (point-to-point and point-to-plane lines of pc_error; normals estimated on the device as the reference does with Open3D when
+    # the PLY carries none -- 14 ms for the 1 M-voxel pair, profiles/r06/README.md)
+    from fastpcc_amd.evaluators import pc_error_metrics
+    quality = pc_error_metrics(frame[:, 1:], rec, args.resolution)
 
     n_bytes = len(data)
     out = None
@@ -623,6 +625,7 @@ def main():
                        'encode_ms': round(enc_ms, 3), 'decode_ms': round(dec_ms, 3), 'one_frame_ms': round(one_frame_ms, 3),
                        'bytes': n_bytes, 'bpp': round(8 * n_bytes / n_points, 4),
                        'd1_psnr_db': round(quality['mseF,PSNR (p2point)'], 3),
+                       'd2_psnr_db': round(quality['mseF,PSNR (p2plane)'], 3),
                        'quality_note': 'random-init weights: bpp / PSNR are parity checks, not RD results',
                        'coder_handover_retries': GeoLosslessEntropyModel.handover_retries,
                        'hbm_peak_gib': round(hbm_peak_gib, 1),
