@@ -904,8 +904,13 @@ class _ConvBase(nn.Module):
             plan = _pad_plan(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, plan_rows)
             if x2 is None and 'k3_w' in d:
                 y = ops.conv_f32(x1, d['k3_w'], 32, src.n, pack=True)       # per input row: its dot product with every offset's kernel
-                out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
-                                     slope=act.slope, clip=clip)
+                if src.generated and src.nbr27 is None and src.n == 8 * src.parent.n:
+                    # a full generated set (the occupancy predictors' 8 candidates per voxel): the neighbour rows follow from the
+                    # PARENT's table in registers -- the candidates' own table (108 bytes per row) is never written or read
+                    out = ops.gather_sum_generated(y, cm._nbr27(src.parent, True), bias=kw['bias'], act=act.kind, slope=act.slope, clip=clip)
+                else:
+                    out = ops.gather_sum(y, cm._nbr27(src), 27, src.n, 1, src.n, bias=kw['bias'], act=act.kind,
+                                         slope=act.slope, clip=clip)
             elif plan is not None:
                 wp, bp = self._padded_weights(x1.shape[1], 0 if x2 is None else x2.shape[1], plan)
                 ro = cm._row_order(src) if plan[0] + plan[1] > 16 else None

@@ -76,6 +76,7 @@ _SIGS = {
     'fpcc_conv_f32_order': (_i32, [_i32, _i32, _i32]),
     'fpcc_conv_f32_order_ex': (_i32, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'fpcc_gather_sum_f32': (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _f32, _vp, _vp]),
+    'fpcc_gather_sum_generated_f32': (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _f32, _vp, _vp]),
     'fpcc_logit_to_prob16': (_i32, [_vp, _i64, _vp, _vp]),
     'fpcc_quantize_symbols': (_i32, [_vp, _i64, _f32, _vp, _vp]),
     'fpcc_child_mask': (_i32, [_vp, _i64, _vp, _vp]),
@@ -1022,6 +1023,20 @@ def gather_sum(y: torch.Tensor, nbr: torch.Tensor, n_offsets: int, nbr_ks: int, 
     _ok(lib().fpcc_gather_sum_f32(py, ldy, _dev(nbr, torch.int32, 'nbr'), n_offsets, nbr_ks, nbr_os, n,
                                   _dev(bias, torch.float32, 'bias', True), act,
                                   _dev(slope, torch.float32, 'slope', True), float(clip), out.data_ptr(), _stream()))
+    return out
+
+
+def gather_sum_generated(y: torch.Tensor, parent_nbr: torch.Tensor, *, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                         slope: Optional[torch.Tensor] = None, clip: float = 0.0) -> torch.Tensor:
+    """gather_sum on the generated set of a level (8 candidates per parent row) from the PARENT level's table [27, m]: the candidates'
+    own 27-entry table is never built"""
+    py, cy, ldy = _rows2d(y, 'y')
+    m = parent_nbr.shape[1]
+    if y.shape[0] != 8 * m:
+        raise ValueError('y must have 8 rows per parent')
+    out = torch.empty((8 * m, 1), dtype=torch.float32, device=y.device)
+    _ok(lib().fpcc_gather_sum_generated_f32(py, ldy, _dev(parent_nbr, torch.int32, 'parent_nbr'), m, _dev(bias, torch.float32, 'bias', True),
+                                            act, _dev(slope, torch.float32, 'slope', True), float(clip), out.data_ptr(), _stream()))
     return out
 
 

@@ -388,6 +388,11 @@ int fpcc_epilogue_bwd_f32(const float *y, int ldy, const float *dy, int lddy, in
  * sums added in ascending offset order, then the bias. */
 int fpcc_gather_sum_f32(const float *y, int ldy, const int32_t *nbr, int n_offsets, int64_t nbr_ks, int64_t nbr_os,
                         int64_t n, const float *bias, int act, const float *slope, float clip, float *out, void *stream);
+/* The same on the GENERATED set of a level (row = 8 parent + octant, all 8 m candidates; fpcc_nbr27_from_parent with keys == NULL)
+ * without building that set's table: parent_nbr is the PARENT level's offset-major table [27][m]; the 27 neighbour rows of every
+ * candidate are derived in registers.  y has 8 m rows; out float [8 m].  Same sum, same bits as fpcc_gather_sum_f32 on the built table. */
+int fpcc_gather_sum_generated_f32(const float *y, int ldy, const int32_t *parent_nbr, int64_t m, const float *bias, int act,
+                                  const float *slope, float clip, float *out, void *stream);
 
 /* out[i, :] = x[index[i], :] -- features re-ordered into the canonical (Morton) row order of a coordinate map, the
  * permutation ME.SparseTensor applies to its features (models/convolutional/lossy_coord_v2/model.py:147-153). */

@@ -111,6 +111,13 @@ def test_pyramid_and_neighbour_tables(ops, res, n):
     gen = oc.generated(lvl1)
     got = ops.nbr27_from_parent(None, None, nbr1, None).cpu().numpy()
     assert (got == oc.dense_table(oc.kernel_map(gen, gen, 3), gen.n)).all()
+    # the one-output-channel gather on the generated set straight from the PARENT's table (no table of the candidates' own): the bits of
+    # fpcc_gather_sum_f32 on the built table
+    y = torch.from_numpy(rng.normal(size=(gen.n, 32)).astype(np.float32)).cuda()
+    bias, slope = torch.tensor([0.37], device='cuda'), torch.tensor([0.2], device='cuda')
+    want_sum = ops.gather_sum(y, torch.from_numpy(got).cuda(), 27, gen.n, 1, gen.n, bias=bias, act=ops.ACT_PRELU, slope=slope, clip=3.0)
+    got_sum = ops.gather_sum_generated(y, nbr1, bias=bias, act=ops.ACT_PRELU, slope=slope, clip=3.0)
+    assert torch.equal(got_sum.view(torch.int32), want_sum.view(torch.int32))
     got2, rows_g, masks_g = ops.nbr27_from_parent_ex(None, None, nbr1, None)
     assert (got2.cpu().numpy() == got).all() and (rows_g[:, :27].t().cpu().numpy() == got).all() and bool((rows_g[:, 27:] == -1).all())
     assert (masks_g.cpu().numpy().astype(np.int64) == ((got >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)).all()
