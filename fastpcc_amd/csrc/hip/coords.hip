@@ -298,73 +298,86 @@ __global__ void k_nbr27_search(const int64_t *__restrict__ keys, int64_t n, int 
     }
 }
 
-// MASK_ONLY: instead of the 27 neighbour rows, one word per row with bit d set where neighbour d exists (all a convolution of
-// a constant input needs): 4 bytes written per row instead of 108
-// rows_out (table form only, may be NULL): the same entries once more ROW-MAJOR, [n][32] with entries 27 .. 31 = -1 -- the layout
-// the MFMA kernels' prologue reads (a row = one 128-byte line); every thread writes its own line as eight 16-byte pieces straight
-// from its column of the LDS tile (round 6: was a separate transposition pass over the finished table, 236 bytes per row).
-// masks_out (table form only, may be NULL): bit d of word i set where neighbour d of row i exists -- what the row-order keys need.
-template <bool MASK_ONLY>
-__global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
-                                    const int32_t *__restrict__ pnbr, int64_t m, const int32_t *__restrict__ child_row,
-                                    int32_t *__restrict__ nbr, int32_t *__restrict__ rows_out, uint32_t *__restrict__ masks_out) {
+// Round 6 formulation.  The 27 neighbours of a child lie in the 2 x 2 x 2 block of parents {ox - 1, ox} x {oy - 1, oy} x {oz - 1, oz} (parent
+// offsets, o = the child's octant bits); their 8 x 8 children form a 4 x 4 x 4 CUBE indexed per axis by v = 2 b + c (b: which parent of
+// the block, c: which child of it), and neighbour d in {-1, 0, 1} is cube entry v = d + 2 - o: the answers are the 3 x 3 x 3 sub-cube at
+// offset s = 1 - o in {0, 1}^3.  So:
+//   1. the 8 parent rows: 8 independent loads;
+//   2. their child rows: 16 independent 16-byte loads (an absent parent reads row 0 and is masked afterwards) -- ALL in flight at once.
+//      Rounds 2-5 walked the parents in a loop that skipped absent ones: a branch around each pair of loads, i.e. nine DEPENDENT round
+//      trips per thread (75-83 % of the wave cycles parked, 42 % of 8 TB/s);
+//   3. each of the 27 outputs is a select among 8 cube registers by the three bits of s (7 v_cndmask): no dynamic register index, no LDS,
+//      no exec-masked stores; the offset-major table is stored straight from registers (one coalesced store per offset).
+// MODE 0: the table [27][n].  MODE 1: instead of the table one word per row with bit d set where neighbour d exists (all a
+// convolution of a constant input needs): 4 bytes written per row instead of 108.  MODE 2: the table and, from the same registers, the
+// table once more ROW-MAJOR [n][32] (entries 27 .. 31 = -1; through an LDS tile so that a wave's store is 1 KB of consecutive
+// addresses) and the masks (each may be NULL).
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int32_t *__restrict__ parent_of, int64_t n,
+                                                               const int32_t *__restrict__ pnbr, int64_t m,
+                                                               const int32_t *__restrict__ child_row, int32_t *__restrict__ nbr,
+                                                               int32_t *__restrict__ rows_out, uint32_t *__restrict__ masks_out) {
+    constexpr int kPlane = kThreads + 1;
+    __shared__ int32_t s_out[MODE == 2 ? 27 * kPlane : 1];
     const int64_t i_raw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (MASK_ONLY && i_raw >= n) return;
-    const int64_t i = i_raw < n ? i_raw : n - 1;               // (table form: a thread past the end recomputes the last row and stores nothing)
+    if (MODE != 2 && i_raw >= n) return;
+    const int64_t i = i_raw < n ? i_raw : n - 1;               // (MODE 2: a thread past the end recomputes the last row and stores nothing)
     const int oct = keys ? (int)(keys[i] & 7) : (int)(i & 7);   // keys == NULL: generated set, row = 8*parent + octant
     const int ox = oct & 1, oy = (oct >> 1) & 1, oz = oct >> 2;
     const int32_t p = parent_of ? parent_of[i] : (int32_t)(i >> 3);
-    // The 27 neighbours of a child lie in the 2x2x2 block of parents {ox-1, ox} x {oy-1, oy} x {oz-1, oz} (parent offsets):
-    // 8 parent rows are looked up once (instead of once per neighbour) and their 8 children each fetched as two 16-byte
-    // loads.  Child c of block parent b sits at offset (2 P + c_axis - o_axis) per axis from this row, P = o - 1 + b in
-    // {-1, 0, 1}; the 27 of the 64 children whose offsets lie in {-1, 0, 1}^3 are the answers.  They go through an LDS tile
-    // [27][threads] (so that every store instruction writes consecutive rows of ONE offset): 27 KB per workgroup -- five
-    // workgroups per CU; the [64][threads] tile of all children that round 2 kept allowed two, and the kernel ran latency-bound.
-    // (plane stride kThreads + 1: the row-major copy below reads the tile across planes, 8 lanes per row)
-    constexpr int kPlane = kThreads + 1;
-    __shared__ int32_t s_out[MASK_ONLY ? 1 : 27 * kPlane];
-    int32_t *mine = s_out + (MASK_ONLY ? 0 : threadIdx.x);
-    if (!MASK_ONLY) {
-#pragma unroll
-        for (int d = 0; d < 27; ++d) mine[d * kPlane] = -1;
-    }
-    uint32_t bits = 0;
+    int32_t q[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const int bx = b & 1, by = (b >> 1) & 1, bz = b >> 2;
-        const int px = ox - 1 + bx, py = oy - 1 + by, pz = oz - 1 + bz;                             // in {-1, 0, 1}
+        const int px = ox - 1 + (b & 1), py = oy - 1 + ((b >> 1) & 1), pz = oz - 1 + (b >> 2);      // in {-1, 0, 1}
         const int pd = (px + 1) + 3 * (py + 1) + 9 * (pz + 1);
-        const int32_t q = (pd == 13) ? p : pnbr[(int64_t)pd * m + p];
-        if (q < 0) continue;
-        int32_t kid[8];
-        if (child_row) {
-            const int4 lo = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8);
-            const int4 hi = *reinterpret_cast<const int4 *>(child_row + (int64_t)q * 8 + 4);
-            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w; kid[4] = hi.x; kid[5] = hi.y; kid[6] = hi.z; kid[7] = hi.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) kid[c] = q * 8 + c;
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int dx = 2 * px + (c & 1) - ox, dy = 2 * py + ((c >> 1) & 1) - oy, dz = 2 * pz + (c >> 2) - oz;
-            if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
-            const int d = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
-            bits |= (uint32_t)(kid[c] >= 0) << d;
-            if (!MASK_ONLY) mine[d * kPlane] = kid[c];
-        }
+        q[b] = pnbr[(int64_t)pd * m + (pd == 13 ? 0 : p)];                                           // (the centre is p itself: loaded and dropped, no branch)
+        q[b] = pd == 13 ? p : q[b];
     }
-    if (!MASK_ONLY) {
-        // own column of the tile only: no barrier needed
-        if (i_raw < n) {
+    // cube[vx][vy][vz], v = 2 b + c per axis
+    int32_t cube[4][4][4];
+    if (child_row) {
+        int4 lo[8], hi[8];
 #pragma unroll
-            for (int d = 0; d < 27; ++d) nbr[(int64_t)d * n + i] = mine[d * kPlane];
-            if (masks_out) masks_out[i] = bits;
+        for (int b = 0; b < 8; ++b) {
+            const int64_t row = q[b] < 0 ? 0 : q[b];
+            lo[b] = *reinterpret_cast<const int4 *>(child_row + row * 8);
+            hi[b] = *reinterpret_cast<const int4 *>(child_row + row * 8 + 4);
         }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int32_t kid[8] = {lo[b].x, lo[b].y, lo[b].z, lo[b].w, hi[b].x, hi[b].y, hi[b].z, hi[b].w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                cube[2 * (b & 1) + (c & 1)][2 * ((b >> 1) & 1) + ((c >> 1) & 1)][2 * (b >> 2) + (c >> 2)] = q[b] < 0 ? -1 : kid[c];
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                cube[2 * (b & 1) + (c & 1)][2 * ((b >> 1) & 1) + ((c >> 1) & 1)][2 * (b >> 2) + (c >> 2)] = q[b] < 0 ? -1 : q[b] * 8 + c;
+    }
+    const bool sx = ox == 0, sy = oy == 0, sz = oz == 0;       // s = 1 - o
+    uint32_t bits = 0;
+    int32_t *mine = s_out + (MODE == 2 ? threadIdx.x : 0);
+#pragma unroll
+    for (int d = 0; d < 27; ++d) {
+        const int dx = d % 3, dy = (d / 3) % 3, dz = d / 9;
+        const int32_t a00 = sx ? cube[dx + 1][dy][dz] : cube[dx][dy][dz], a01 = sx ? cube[dx + 1][dy + 1][dz] : cube[dx][dy + 1][dz];
+        const int32_t a10 = sx ? cube[dx + 1][dy][dz + 1] : cube[dx][dy][dz + 1], a11 = sx ? cube[dx + 1][dy + 1][dz + 1] : cube[dx][dy + 1][dz + 1];
+        const int32_t b0 = sy ? a01 : a00, b1 = sy ? a11 : a10;
+        const int32_t v = sz ? b1 : b0;
+        bits |= (uint32_t)(v >= 0) << d;
+        if (MODE != 1 && i_raw < n) nbr[(int64_t)d * n + i] = v;
+        if (MODE == 2) mine[d * kPlane] = v;
+    }
+    if (MODE == 1) { nbr[i] = (int32_t)bits; return; }
+    if (MODE == 2) {
+        if (masks_out && i_raw < n) masks_out[i] = bits;
         if (rows_out) {
-            // the tile once more, row-major: lane e of pass j moves the 16-byte piece (row e / 8, piece e % 8) -- a wave's store is 1 KB
-            // of consecutive addresses (writing each thread's own line piece by piece, 16 bytes at a 128-byte stride per
-            // instruction, doubled the kernel's time)
+            // the tile row-major: lane e of pass j moves the 16-byte piece (row e / 8, piece e % 8) -- a wave's store is 1 KB of
+            // consecutive addresses (each thread writing its own line piece by piece, 16 bytes at a 128-byte stride per instruction,
+            // doubled the kernel's time)
             __syncthreads();
             const int64_t row0 = blockIdx.x * (int64_t)blockDim.x;
 #pragma unroll
@@ -382,7 +395,6 @@ __global__ void k_nbr27_from_parent(const int64_t *__restrict__ keys, const int3
             }
         }
     }
-    if (MASK_ONLY) nbr[i] = (int32_t)bits;
 }
 
 
@@ -802,7 +814,7 @@ extern "C" int fpcc_nbr27_from_parent(const int64_t *keys, const int32_t *parent
     if (!parent_of && !(child_row == nullptr && n == 8 * m))
         return fail_arg("nbr27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (n == 0) return FPCC_OK;
-    hipLaunchKernelGGL(k_nbr27_from_parent<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+    hipLaunchKernelGGL(k_nbr27_from_parent<0>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
                        parent_of, n, parent_nbr, m, child_row, nbr, (int32_t *)nullptr, (uint32_t *)nullptr);
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
@@ -816,8 +828,12 @@ extern "C" int fpcc_nbr27_from_parent_ex(const int64_t *keys, const int32_t *par
         return fail_arg("nbr27_from_parent_ex: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (rows_out && (reinterpret_cast<uintptr_t>(rows_out) & 15)) return fail_arg("nbr27_from_parent_ex: rows_out must be 16-byte aligned");
     if (n == 0) return FPCC_OK;
-    hipLaunchKernelGGL(k_nbr27_from_parent<false>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
-                       parent_of, n, parent_nbr, m, child_row, nbr, rows_out, masks_out);
+    if (rows_out || masks_out)
+        hipLaunchKernelGGL(k_nbr27_from_parent<2>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+                           parent_of, n, parent_nbr, m, child_row, nbr, rows_out, masks_out);
+    else
+        hipLaunchKernelGGL(k_nbr27_from_parent<0>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+                           parent_of, n, parent_nbr, m, child_row, nbr, rows_out, masks_out);
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
 }
@@ -829,7 +845,7 @@ extern "C" int fpcc_mask27_from_parent(const int64_t *keys, const int32_t *paren
     if (!parent_of && !(child_row == nullptr && n == 8 * m))
         return fail_arg("mask27_from_parent: parent_of may only be omitted for a full generated set (n == 8m, child_row NULL)");
     if (n == 0) return FPCC_OK;
-    hipLaunchKernelGGL(k_nbr27_from_parent<true>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
+    hipLaunchKernelGGL(k_nbr27_from_parent<1>, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, as_stream(stream), keys,
                        parent_of, n, parent_nbr, m, child_row, reinterpret_cast<int32_t *>(masks_out), (int32_t *)nullptr, (uint32_t *)nullptr);
     FPCC_LAUNCHED(k_nbr27_from_parent);
     return FPCC_OK;
