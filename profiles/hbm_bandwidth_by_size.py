@@ -8,8 +8,10 @@ import csv
 import os
 import sys
 
-KERNELS = ('k_nbr27_from_parent<false>', 'k_nbr27_from_parent<true>', 'k_gather_sum', 'k_coarsen_scatter', 'k_refine_scatter',
-           'k_conv_row_keys', 'k_pointwise_head', 'k_conv_ones_k3', 'k_logit_to_prob16', 'k_child_mask')
+# (round 6: the table producer's template argument is a mode -- 0 table, 1 masks only, 2 table + row-major copy + masks; rounds 2-5: <false> / <true>)
+KERNELS = ('k_nbr27_from_parent<false>', 'k_nbr27_from_parent<true>', 'k_nbr27_from_parent<2>', 'k_nbr27_from_parent<1>', 'k_nbr27_from_parent<0>',
+           'k_gather_sum_generated', 'k_gather_sum', 'k_gather_table_rows', 'k_coarsen_scatter', 'k_refine_scatter',
+           'k_conv_row_keys', 'k_conv_row_keys_masks', 'k_pointwise_head', 'k_conv_ones_k3', 'k_unique_scatter', 'k_logit_to_prob16', 'k_child_mask')
 
 
 def counters(d):
@@ -34,7 +36,10 @@ def main(fetch_dir, write_dir):
     print('|---|---:|---:|---:|---|---:|')
     for key in KERNELS:
         for name in fetch:
-            if key + '(' not in name.replace(' ', '').replace('>(', '>(') and key not in name:
+            flat = name.replace(' ', '')
+            at = flat.find(key)
+            # the key must be the whole kernel name (k_gather_sum is not k_gather_sum_generated) or name + template arguments as given
+            if at < 0 or not (key.endswith('>') or flat[at + len(key): at + len(key) + 1] in ('(', '<', '')):
                 continue
             rows = sorted(((2 * f + w) * 1024, us) for f, w, us in zip(fetch[name], write.get(name, []), dur.get(name, [])))[::-1]
             if not rows:
