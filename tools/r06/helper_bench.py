@@ -85,4 +85,9 @@ y = torch.randn(n1, 32, device='cuda')
 t = timed(lambda: ops.gather_sum(y, nbr, 27, n1, 1, n1))
 line('k_gather_sum (stride-2 level)', n1, t, n1 * (108 + 128 + 4))
 xh = torch.randn(8 * m1.n, 16, device='cuda')
-print('rows of the head input:', xh.shape[0], flush=True)
+w1 = torch.randn(16, 8, device='cuda') / 4
+b1 = torch.randn(8, device='cuda')
+w2 = torch.randn(8, 1, device='cuda') / 3
+b2 = torch.randn(1, device='cuda')
+t = timed(lambda: ops.pointwise_head(xh, w1, b1, ops.ACT_PRELU, slope, 1, w2, b2), reps=5)
+line('k_pointwise_head<16, 8> (the 8 M candidates)', xh.shape[0], t, xh.shape[0] * (64 + 4))
