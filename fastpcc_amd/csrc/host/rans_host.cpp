@@ -277,6 +277,21 @@ int64_t indexed_decode(const uint8_t *stream, int64_t stream_len, const int32_t 
 
 int64_t binary_encode(const uint8_t *bits, const uint16_t *p1, int64_t n, uint8_t *out, int64_t cap) {
     BackWriter w(out, cap);
+    if (w.room(2 * n + 8)) {
+        // room for the worst case (two bytes per symbol): the branch-free step (round 6 -- the loop below spends more on mispredicted
+        // renormalisation branches than on arithmetic: the largest occupancy level of a 1 M-voxel frame, 709 K symbols, is the serial
+        // tail the GPU waits for at the end of every encode).  Same state sequence, same bytes.
+        uint32_t bad = 0;
+        for (int64_t i = n - 1; i >= 0; --i) {
+            const uint32_t p = p1[i];
+            bad |= uint32_t(p == 0);
+            const uint32_t mask = 0u - uint32_t(bits[i] != 0);
+            const uint32_t split = kProbOne - p;
+            w.put_roomy<kProbBits>(split & mask, ((p & mask) | (split & ~mask)) | uint32_t(p == 0));     // (a zero probability: any valid frequency; the result is discarded)
+        }
+        if (bad) return FPCC_HOST_E_ARG;
+        return w.finish();
+    }
     for (int64_t i = n - 1; i >= 0; --i) {
         const uint32_t p = p1[i];
         if (p == 0) return FPCC_HOST_E_ARG;
