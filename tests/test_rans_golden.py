@@ -213,6 +213,29 @@ def test_multi_stream_encoder_matches_single():
         assert out[s, cap - lens[s]:].tobytes() == want
 
 
+def test_binary_encoder_paths_with_and_without_room_write_the_same_bytes():
+    """fpcc_rans_binary_encode takes its branch-free step when the buffer holds the worst case (2 bytes per symbol) and the
+    renormalisation loop otherwise: both must write the oracle's bytes; a buffer that is too small for the stream is an error, a zero
+    probability an invalid argument on either path"""
+    from fastpcc_amd._native import host
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 4096, 50001):
+        prob = np.clip(np.round(rng.beta(0.4, 0.4, n) * 65536), 1, 65535).astype(np.uint16)
+        bits = (rng.random(n) < prob / 65536).astype(np.uint8)
+        want = orc.BinaryRansCoder(1).encode(bits.astype(bool)[None], prob.astype(np.uint32)[None])[0]
+        for cap in (4 * n + 64, 2 * n + 8, 2 * n + 7, len(want) + 1, len(want)):          # roomy, exactly roomy, loop, loop, loop (tight)
+            out = np.empty(cap, np.uint8)
+            ln = host().fpcc_rans_binary_encode(bits.ctypes.data, prob.ctypes.data, n, out.ctypes.data, cap)
+            assert ln == len(want) and out[cap - ln:].tobytes() == want, (n, cap)
+        out = np.empty(max(len(want) - 1, 1), np.uint8)
+        assert host().fpcc_rans_binary_encode(bits.ctypes.data, prob.ctypes.data, n, out.ctypes.data, len(want) - 1) < 0
+        bad = prob.copy()
+        bad[n // 2] = 0
+        for cap in (4 * n + 64, 2 * n + 7):
+            out = np.empty(cap, np.uint8)
+            assert host().fpcc_rans_binary_encode(bits.ctypes.data, bad.ctypes.data, n, out.ctypes.data, cap) < 0
+
+
 def test_wide_row_decoder_with_row_warmers_and_concurrent_decoders():
     """the 255-ary decoder on blocks of >= 2048 cold rows can start the library's row-warming helpers (FPCC_HOST_WARMERS, read once per
     process: off by default, so this runs in a child process with two helpers; one decoder at a time owns them, a second decoder running
