@@ -137,7 +137,7 @@ class KernelGenerator:
 class _Map:
     """One coordinate map: sorted unique keys at pyramid level `level` (tensor stride 1 << level)."""
     __slots__ = ('level', 'bits', 'n', 'keys', 'parent', 'parent_of', 'child_row', 'generated', 'nbr27', 'coords',
-                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows', 'nbr27_pos', 'edges')
+                 'gen_child', 'key', 'row_order', 'mask27', 'nbr27_rows', 'nbr27_pos', 'edges', 'k2_order', 'k2_pos')
 
     def __init__(self, level: int, bits: int, n: int, keys: Optional[torch.Tensor]):
         self.level, self.bits, self.n, self.keys = level, bits, n, keys
@@ -154,6 +154,10 @@ class _Map:
         self.gen_child: Optional['_Map'] = None
         self.key: Optional[CoordinateMapKey] = None
         self.edges: Optional[List[int]] = None            # host copy of the row ranges of the batch's clouds (rows are cloud-major)
+        # stride-2 convolution ONTO this map's parent (child_row read as a 2x2x2 kernel map): the parent's rows grouped by which of
+        # their 8 children exist (False: not decided), and child_row with its rows in that order
+        self.k2_order = False
+        self.k2_pos: Optional[torch.Tensor] = None
 
 
 class CoordinateManager:
@@ -413,6 +417,23 @@ class CoordinateManager:
                 m.row_order = ops.conv_row_order(nbr, 27, m.n, 1, m.n, self.ROW_ORDER_WINDOW_LOG2,
                                                  masks=m.mask27 if m.nbr27_rows is not None else None)
         return m.row_order
+
+    def _k2_order(self, src: _Map):
+        """(row order, table) of the stride-2 2x2x2 convolution from `src` onto its parent on the MFMA path.  A parent has ~3.7 of its 8
+        children on a surface, yet in Morton order nearly every 32-row block of parents has all 8 octants between its rows, so the
+        kernel executed all 8 offsets for every block (0.33 of the matrix peak on the large maps, rounds 2-5).  Grouping the parents by
+        their 8-bit child-presence pattern (the machinery of the 3x3x3 layers: fpcc_conv_row_keys + sort, tiles heaviest first) lets a
+        block skip the octants none of its rows has; the table travels in position order like the 3x3x3 one.  Results do not depend on
+        the order (every output row is its own chain).  -> (None, child_row) on small maps."""
+        m = src.parent.n
+        if src.k2_order is False:
+            src.k2_order = None
+            if self.NBR_ROWS and m > self.ROW_ORDER_MIN_ROWS and os.environ.get('FPCC_K2_ROW_ORDER', '1') != '0':
+                src.k2_order = ops.conv_row_order(src.child_row, 8, 1, 8, m, self.ROW_ORDER_WINDOW_LOG2)
+                src.k2_pos = ops.gather_table_rows(src.child_row, src.k2_order)
+        if src.k2_order is None:
+            return None, src.child_row
+        return src.k2_order, src.k2_pos
 
     def get_coordinates(self, key: CoordinateMapKey) -> torch.Tensor:
         m = self._map(key)
@@ -934,7 +955,12 @@ class _ConvBase(nn.Module):
             dst = cm._ensure_parent(src)
             if src.generated:
                 raise NotImplementedError('stride-2 convolution of a generated set')
-            out = ops.conv_f32(x1, w, c_out, dst.n, nbr=src.child_row, n_offsets=8, nbr_ks=1, nbr_os=8, **kw)
+            c_in = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+            if kw.get('pack', False) is True and c_in > 16 and ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, 8, 1, dst.n) == 3:
+                ro, table = cm._k2_order(src)              # grouped MFMA shapes: parents in child-pattern order on large maps
+            else:
+                ro, table = None, src.child_row
+            out = ops.conv_f32(x1, w, c_out, dst.n, nbr=table, n_offsets=8, nbr_ks=1, nbr_os=8, row_order=ro, **kw)
         return SparseTensor(out, coordinate_map_key=dst.key, coordinate_manager=cm)
 
 
