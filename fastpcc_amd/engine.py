@@ -956,7 +956,9 @@ class _ConvBase(nn.Module):
             if src.generated:
                 raise NotImplementedError('stride-2 convolution of a generated set')
             c_in = x1.shape[1] + (0 if x2 is None else x2.shape[1])
-            if kw.get('pack', False) is True and c_in > 16 and ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, 8, 1, dst.n) == 3:
+            # (16 input channels: the one such layer -- 16 -> 64 onto the stride-2 map -- gains 0.19 ms per batch in pattern order and its
+            # order costs more than that to build: measured, left in Morton order)
+            if kw.get('pack', False) is True and c_in > 16 and ops.conv_order(x1.shape[1], 0 if x2 is None else x2.shape[1], c_out, 8, 1, dst.n) != 0:
                 ro, table = cm._k2_order(src)              # grouped MFMA shapes: parents in child-pattern order on large maps
             else:
                 ro, table = None, src.child_row
